@@ -1,0 +1,285 @@
+"""TEST INFRASTRUCTURE ONLY - runs in the build container, where /root/reference exists.
+
+Imports the reference's own model files through oracle/ref_shim.py, runs them on CPU
+(fp32) on deterministic synthetic weights/inputs and writes small golden vectors to
+tests/golden/*.npz.  Those fixtures pin oracle/torch_ref.py (tests/test_oracle_golden.py).
+
+    python -m oracle.gen_golden [--only NAME]
+
+Fixtures hold inputs' seeds and expected outputs only (slices, statistics, hashes) -
+never reference source text.
+"""
+import argparse
+import hashlib
+import os
+import tempfile
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from oracle import ref_shim
+from vfmseg_amd import presets
+from vfmseg_amd.synth import synth_image, synth_label, synth_like
+
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def stats(t):
+    t = t.detach().double()
+    return np.array([t.mean().item(), t.abs().mean().item(), t.std().item(), t.abs().max().item()])
+
+
+def sl(t, n=8):
+    """Small deterministic slice of a tensor (first n along every dim)."""
+    idx = tuple(slice(0, min(n, s)) for s in t.shape)
+    return t.detach()[idx].contiguous().numpy().copy()
+
+
+def mask_digest(m):
+    return hashlib.sha256(np.ascontiguousarray(m.astype(np.uint8)).tobytes()).hexdigest()
+
+
+def build_reference_model(depth=24):
+    """The reference's MsVFMEncoderDecoder with synthetic parameters."""
+    M = ref_shim.load_all()
+    cfg = presets.dinov2_ms_masked(depth=depth)
+    # LoRABackbone loads a checkpoint unconditionally (lora_backbone.py:27-35): give it one, in the
+    # *un-renamed* key scheme the converters emit, so the reference's own rename path runs.
+    bb = M.build(cfg["backbone"]["backbone"])
+    base_sd = synth_like(bb.state_dict())
+    del bb
+    with tempfile.NamedTemporaryFile(suffix=".pth", delete=False) as f:
+        torch.save(base_sd, f.name)
+        ck = f.name
+    cfg["backbone"]["checkpoint"] = ck
+    cfg["train_cfg"]["work_dir"] = tempfile.mkdtemp()
+    model = M.build(cfg)
+    os.unlink(ck)
+    # non-base parameters (LoRA A/B, heads): key-hashed synthetic values
+    sd = model.state_dict()
+    new = synth_like(sd)
+    for k in sd:
+        if ".base_layer." in k or ("backbone." in k and "lora_" not in k):
+            # keep what the reference's loader put there; must equal synth of the un-renamed key
+            new[k] = sd[k]
+    model.load_state_dict(new)
+    model._synth_sd = {k: v.clone() for k, v in new.items()}
+    model.local_iter = 1  # skip the matplotlib debug dump at iter 0 (Ms_VFM_encoder_decoder.py:197-199)
+    return model
+
+
+def reset(model):
+    """Every fixture starts from the same synthetic state (train-mode passes move the BN running stats)."""
+    model.load_state_dict(model._synth_sd)
+    model.zero_grad()
+
+
+def set_dropout_zero(model):
+    for m in model.modules():
+        if isinstance(m, (nn.Dropout, nn.Dropout2d)):
+            m.p = 0.0
+
+
+class RandRecorder:
+    """Records torch.rand outputs (the query mask, Transformer.py:265) without touching reference code."""
+
+    def __init__(self):
+        self.vals = []
+        self._orig = torch.rand
+
+    def __enter__(self):
+        def rec(*a, **k):
+            v = self._orig(*a, **k)
+            self.vals.append(v.clone())
+            return v
+
+        torch.rand = rec
+        return self
+
+    def __exit__(self, *a):
+        torch.rand = self._orig
+
+
+# --------------------------------------------------------------------------------- fixtures
+def gen_dinov2(model):
+    reset(model)
+    bb = model.backbone
+    bb.eval()
+    out = {}
+    with torch.no_grad():
+        for tag, size in (("sq", (512, 512)), ("rect", (512, 1024))):
+            x = synth_image(1, size, seed=11)
+            taps = bb(x)
+            for i, t in enumerate(taps):
+                out[f"{tag}_tap{i}_stats"] = stats(t)
+                out[f"{tag}_tap{i}_slice"] = sl(t)
+                out[f"{tag}_tap{i}_tail"] = t[0, -4:, -3:, -5:].numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "dinov2_taps.npz"), **out)
+    print("dinov2_taps", {k: v[:2] for k, v in out.items() if k.endswith("stats")})
+
+
+def synth_feats(b, c=1024, hw=32, seed=0):
+    g = torch.Generator().manual_seed(3000 + seed)
+    return [torch.randn(b, c, hw, hw, generator=g) for _ in range(4)]
+
+
+def gen_heads(model):
+    reset(model)
+    out = {}
+    lab = synth_label(2, 512, seed=5)
+    # --- LinearHead, train-mode BN (batch stats), dropout off
+    model.train()
+    set_dropout_zero(model)
+    feats = synth_feats(2, seed=1)
+    head = model.decode_head
+    rm0 = head.output_upscaling[1].running_mean.clone()
+    losses, logits = head.loss([f.clone().requires_grad_(True) for f in feats], lab, return_logits=True)
+    out["lin_train_logits_stats"] = stats(logits)
+    out["lin_train_logits_slice"] = sl(logits)
+    out["lin_train_loss"] = np.array([losses["loss_ce"].item(), losses["acc_seg"].item()])
+    out["lin_bn_running_mean_delta"] = stats(head.output_upscaling[1].running_mean - rm0)
+    out["lin_bn_running_var"] = stats(head.output_upscaling[1].running_var)
+    # --- LinearHead eval (running stats of the synthetic state)
+    reset(model)
+    model.eval()
+    with torch.no_grad():
+        lo = head(feats)
+    out["lin_eval_logits_stats"] = stats(lo)
+    out["lin_eval_logits_slice"] = sl(lo)
+    # --- VFMHead with recorded mask, and with mask disabled
+    aux = model.aux_decoder
+    g = torch.Generator().manual_seed(77)
+    ctx = torch.randn(2, 19, 256, 256, generator=g)
+    torch.manual_seed(1234)
+    with RandRecorder() as rr:
+        losses, hl = aux.loss(feats, ctx, lab, return_logits=True)
+    assert len(rr.vals) == 1
+    out["vfm_mask_rand"] = rr.vals[0].numpy()
+    out["vfm_logits_stats"] = stats(hl)
+    out["vfm_logits_slice"] = sl(hl)
+    out["vfm_loss"] = np.array([losses["loss_ce"].item(), losses["acc_seg"].item()])
+    aux.transformer_decoder.mask_enable = False
+    with torch.no_grad():
+        lo = aux(feats, ctx)
+    aux.transformer_decoder.mask_enable = True
+    out["vfm_nomask_logits_stats"] = stats(lo)
+    out["vfm_nomask_logits_slice"] = sl(lo)
+    np.savez_compressed(os.path.join(GOLD, "heads.npz"), **out)
+    print("heads", out["lin_train_loss"], out["vfm_loss"])
+
+
+def gen_train_step(model):
+    reset(model)
+    """Full MsVFMEncoderDecoder.forward_train (B=2, 1024^2) + backward: losses and gradient probes."""
+    out = {}
+    model.train()
+    set_dropout_zero(model)
+    model.zero_grad()
+    img = synth_image(2, 1024, seed=3)
+    lab = synth_label(2, 1024, seed=3)
+    samples = [ref_shim.SegDataSample(gt=lab[i]) for i in range(2)]
+    np.random.seed(0)
+    torch.manual_seed(4321)
+    with RandRecorder() as rr:
+        losses = model.loss(img, samples)
+    assert len(rr.vals) == 1
+    out["mask_rand"] = rr.vals[0].numpy()
+    out["hr_crop_box"] = np.array(model.hr_crop_box)
+    keys = ["decode_lr.loss_ce", "decode_lr.acc_seg", "decode_hr.loss_ce", "decode_hr.acc_seg"]
+    out["losses"] = np.array([float(losses[k]) for k in keys])
+    total = sum(v for k, v in losses.items() if "loss" in k)
+    total.backward()
+    named = dict(model.named_parameters())
+    groups = {"lora": 0.0, "decode_head": 0.0, "aux_decoder": 0.0}
+    n_train = 0
+    for k, p in named.items():
+        if p.grad is None:
+            continue
+        n_train += p.numel()
+        g2 = p.grad.double().pow(2).sum().item()
+        if "lora_" in k:
+            groups["lora"] += g2
+        elif k.startswith("decode_head"):
+            groups["decode_head"] += g2
+        elif k.startswith("aux_decoder"):
+            groups["aux_decoder"] += g2
+    out["grad_norms"] = np.sqrt(np.array([groups["lora"], groups["decode_head"], groups["aux_decoder"]]))
+    out["n_trainable"] = np.array([n_train])
+    pre = "backbone.model.base_model.model.blocks."
+    probes = [
+        pre + "0.attn.qkv.lora_A.default.weight",
+        pre + "0.attn.qkv.lora_B.default.weight",
+        pre + "23.attn.qkv.lora_A.default.weight",
+        pre + "23.attn.qkv.lora_B.default.weight",
+        "decode_head.conv_seg.weight",
+        "decode_head.conv_seg.bias",
+        "decode_head.fusion_conv.conv.weight",
+        "decode_head.output_upscaling.0.weight",
+        "decode_head.output_upscaling.1.weight",
+        "aux_decoder.conv_seg.weight",
+        "aux_decoder.transformer_decoder.mask_token",
+        "aux_decoder.transformer_decoder.transformer_blocks.0.attn2.to_k.weight",
+        "aux_decoder.transformer_decoder.transformer_blocks.2.ff.net.0.proj.weight",
+        "aux_decoder.seg_logits_embed.0.weight",
+        "aux_decoder.fuse_conv.0.weight",
+    ]
+    for k in probes:
+        g = named[k].grad
+        out["grad_stats::" + k] = stats(g)
+        out["grad_slice::" + k] = sl(g.reshape(g.shape[0], -1) if g.dim() > 1 else g)
+    np.savez_compressed(os.path.join(GOLD, "train_step.npz"), **out)
+    print("train_step", out["losses"], out["grad_norms"], out["hr_crop_box"], n_train)
+
+
+def gen_ms_inference(model):
+    reset(model)
+    """MsVFMEncoderDecoder.inference('ms_slide_inference') on one 1024^2 image; argmax mask digest."""
+    out = {}
+    model.eval()
+    img = synth_image(1, 1024, seed=9)
+    # thresholds chosen so that both branches of the confidence gate are taken with random weights
+    thr, conf = out_thr = (0.3, 0.341)
+    model.test_cfg["threadshod"], model.test_cfg["conf"] = thr, conf
+    refined = []
+    orig = model.enc_dec
+
+    def spy(inputs, context=None):
+        if context is not None:
+            refined.append(tuple(int(v) for v in model.hr_crop_box))
+        return orig(inputs, context)
+
+    model.enc_dec = spy
+    metas = [dict(ori_shape=(1024, 1024), img_shape=(1024, 1024), pad_shape=(1024, 1024), padding_size=[0, 0, 0, 0])]
+    with torch.no_grad():
+        logits = model.inference(img, metas)
+    model.enc_dec = orig
+    assert 0 < len(refined) < 9, "thresholds no longer exercise both gate branches"
+    pred = logits.argmax(dim=1)[0].numpy().astype(np.uint8)
+    out["test_cfg"] = np.array(out_thr)
+    out["refined_boxes"] = np.array(refined).reshape(-1, 4)
+    out["logits_stats"] = stats(logits)
+    out["logits_slice"] = sl(logits)
+    out["logits_center"] = logits[0, :, 500:504, 636:644].numpy().copy()
+    out["pred_sub4"] = pred[::4, ::4].copy()
+    out["pred_sha256"] = np.array(mask_digest(pred))
+    out["pred_hist"] = np.bincount(pred.reshape(-1), minlength=19)
+    np.savez_compressed(os.path.join(GOLD, "ms_inference.npz"), **out)
+    print("ms_inference refined", len(refined), "of 9;", out["pred_sha256"], out["pred_hist"])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    model = build_reference_model()
+    steps = dict(dinov2=gen_dinov2, heads=gen_heads, train_step=gen_train_step, ms_inference=gen_ms_inference)
+    for name, fn in steps.items():
+        if a.only in (None, name):
+            fn(model)
+
+
+if __name__ == "__main__":
+    main()

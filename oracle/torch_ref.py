@@ -1,0 +1,367 @@
+"""TEST INFRASTRUCTURE ONLY - CPU (torch fp32) restatement of the reference's hot path.
+
+Functional style over a flat ``state_dict`` that uses the reference's key scheme
+(SURVEY.md §8b), so the same dict feeds this oracle and the HIP product modules.
+Pinned against outputs of the reference's own code by tests/test_oracle_golden.py
+(fixtures from oracle/gen_golden.py).  Third-party semantics that are not under
+/root/reference (mmseg BaseDecodeHead/CrossEntropyLoss/accuracy/EncoderDecoder, mmcv
+ConvModule, peft LoRA, SyncBatchNorm) are restated from the pinned upstream versions
+ - "pinned by restatement" at those boundaries.
+
+All citations are relative to /root/reference/.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BB = "backbone.model.base_model.model."  # LoRABackbone -> PeftModel -> base_model.model (lora_backbone.py:23)
+IGNORE = 255
+
+
+# =============================================================================== backbone
+def lora_linear(sd, prefix, x, lora=True, drop_mask=None):
+    """peft 0.10 lora.Linear.forward: base(x) + B(A(dropout(x))) * alpha/r (lora_backbone.py:16-23).
+    `drop_mask` is the already-scaled dropout multiplier (1/(1-p) or 0) or None (= eval / p=0)."""
+    if prefix + "base_layer.weight" in sd:
+        y = F.linear(x, sd[prefix + "base_layer.weight"], sd.get(prefix + "base_layer.bias"))
+        if lora:
+            xa = x if drop_mask is None else x * drop_mask
+            a = sd[prefix + "lora_A.default.weight"]
+            b = sd[prefix + "lora_B.default.weight"]
+            scaling = sd.get("__lora_scaling__", 1.0)  # alpha / r = 32/32 in every reference config
+            y = y + F.linear(F.linear(xa, a), b) * scaling
+        return y
+    return F.linear(x, sd[prefix + "weight"], sd.get(prefix + "bias"))
+
+
+def dinov2_pos_embed(sd, npatch, h, w, patch=16, p=BB):
+    """dino_v2.py:184-215 interpolate_pos_encoding (bicubic, the +0.1 trick, non-square aware)."""
+    pos = sd[p + "pos_embed"]
+    n = pos.shape[1] - 1
+    if npatch == n and w == h:
+        return pos
+    cls_pos, patch_pos = pos[:, 0], pos[:, 1:]
+    dim = pos.shape[-1]
+    # NB the reference calls this with (x, w, h) where its "w" is dim 2 of the image (dino_v2.py:218,227)
+    w0, h0 = w // patch + 0.1, h // patch + 0.1
+    s = int(math.sqrt(n))
+    pp = F.interpolate(
+        patch_pos.reshape(1, s, s, dim).permute(0, 3, 1, 2),
+        scale_factor=(w0 / math.sqrt(n), h0 / math.sqrt(n)),
+        mode="bicubic",
+    )
+    assert int(w0) == pp.shape[-2] and int(h0) == pp.shape[-1]
+    pp = pp.permute(0, 2, 3, 1).reshape(1, -1, dim)
+    return torch.cat((cls_pos.unsqueeze(0), pp), dim=1)
+
+
+def dinov2_tokens(sd, x, patch=16, p=BB):
+    """dino_v2.py:217-228 prepare_tokens_with_masks + patch_embed.py:68-81."""
+    b, _, d2, d3 = x.shape
+    t = F.conv2d(x, sd[p + "patch_embed.proj.weight"], sd[p + "patch_embed.proj.bias"], stride=patch)
+    t = t.flatten(2).transpose(1, 2)
+    t = torch.cat((sd[p + "cls_token"].expand(b, -1, -1), t), dim=1)
+    return t + dinov2_pos_embed(sd, t.shape[1] - 1, d3, d2, patch, p)  # (w=d2, h=d3) naming as in the reference
+
+
+def attention(q, k, v, scale):
+    """attention.py:56-66 (plain softmax path) == xformers memory_efficient_attention. q,k,v: [B,H,N,d]."""
+    a = (q * scale) @ k.transpose(-2, -1)
+    return a.softmax(dim=-1) @ v
+
+
+def dinov2_block(sd, x, i, heads, lora=True, drop_mask=None, eps=1e-6, p=BB):
+    """block.py:89-114 (eval branch: base model is always in eval under LoRABackbone, utils.py:47-52)."""
+    q = f"{p}blocks.{i}."
+    b, n, c = x.shape
+    h = F.layer_norm(x, (c,), sd[q + "norm1.weight"], sd[q + "norm1.bias"], eps)
+    qkv = lora_linear(sd, q + "attn.qkv.", h, lora, drop_mask)
+    qkv = qkv.reshape(b, n, 3, heads, c // heads).permute(2, 0, 3, 1, 4)
+    o = attention(qkv[0], qkv[1], qkv[2], (c // heads) ** -0.5).transpose(1, 2).reshape(b, n, c)
+    o = F.linear(o, sd[q + "attn.proj.weight"], sd[q + "attn.proj.bias"])
+    x = x + o * sd[q + "ls1.gamma"]
+    h = F.layer_norm(x, (c,), sd[q + "norm2.weight"], sd[q + "norm2.bias"], eps)
+    h = F.gelu(F.linear(h, sd[q + "mlp.fc1.weight"], sd[q + "mlp.fc1.bias"]))
+    h = F.linear(h, sd[q + "mlp.fc2.weight"], sd[q + "mlp.fc2.bias"])
+    return x + h * sd[q + "ls2.gamma"]
+
+
+def dinov2_forward(sd, x, depth=24, heads=16, out_indices=(7, 11, 15, 23), patch=16, lora=True, drop_masks=None, p=BB):
+    """dino_v2.py:252-268 forward_features: taps are pre-final-norm, cls dropped, NCHW."""
+    b, _, hh, ww = x.shape
+    t = dinov2_tokens(sd, x, patch, p)
+    outs = []
+    for i in range(depth):
+        t = dinov2_block(sd, t, i, heads, lora, None if drop_masks is None else drop_masks[i], p=p)
+        if i in out_indices:
+            outs.append(t[:, 1:].permute(0, 2, 1).reshape(b, -1, hh // patch, ww // patch).contiguous())
+    return outs
+
+
+# =============================================================================== heads
+def batch_norm_train(x, w, b, running_mean, running_var, momentum=0.1, eps=1e-5, stats=None):
+    """nn.SyncBatchNorm without a process group == BatchNorm2d (linear_head.py:44). Returns y and new running stats.
+    `stats`=(mean, biased_var, count) overrides local batch stats (what a DP all-reduce of moments would give)."""
+    if stats is None:
+        mean = x.mean(dim=(0, 2, 3))
+        var = x.var(dim=(0, 2, 3), unbiased=False)
+        cnt = x.numel() // x.shape[1]
+    else:
+        mean, var, cnt = stats
+    y = (x - mean[None, :, None, None]) * torch.rsqrt(var[None, :, None, None] + eps)
+    y = y * w[None, :, None, None] + b[None, :, None, None]
+    new_rm = (1 - momentum) * running_mean + momentum * mean.detach()
+    new_rv = (1 - momentum) * running_var + momentum * var.detach() * (cnt / max(cnt - 1, 1))
+    return y, new_rm, new_rv
+
+
+def linear_head_forward(sd, feats, training=False, drop2d=None, p="decode_head.", bn_out=None):
+    """linear_head.py:50-70. feats: 4 x [B,C,h,w] -> logits [B,19,4h,4w].
+    drop2d: Dropout2d multiplier [B,C/4,1,1] or None.  bn_out: dict that receives new running stats in training."""
+    x = torch.cat(list(feats), dim=1)
+    x = F.conv2d(x, sd[p + "fusion_conv.conv.weight"])  # ConvModule: bias off when a norm follows
+    x = F.relu(F.group_norm(x, 32, sd[p + "fusion_conv.gn.weight"], sd[p + "fusion_conv.gn.bias"], 1e-5))
+    x = F.conv_transpose2d(x, sd[p + "output_upscaling.0.weight"], sd[p + "output_upscaling.0.bias"], stride=2)
+    if training:
+        x, rm, rv = batch_norm_train(
+            x, sd[p + "output_upscaling.1.weight"], sd[p + "output_upscaling.1.bias"],
+            sd[p + "output_upscaling.1.running_mean"], sd[p + "output_upscaling.1.running_var"])
+        if bn_out is not None:
+            bn_out["running_mean"], bn_out["running_var"] = rm, rv
+    else:
+        x = F.batch_norm(x, sd[p + "output_upscaling.1.running_mean"], sd[p + "output_upscaling.1.running_var"],
+                         sd[p + "output_upscaling.1.weight"], sd[p + "output_upscaling.1.bias"], False, 0.1, 1e-5)
+    x = F.gelu(x)
+    x = F.conv_transpose2d(x, sd[p + "output_upscaling.3.weight"], sd[p + "output_upscaling.3.bias"], stride=2)
+    x = F.gelu(x)
+    if drop2d is not None:
+        x = x * drop2d
+    return F.conv2d(x, sd[p + "conv_seg.weight"], sd[p + "conv_seg.bias"])
+
+
+def _mha(sd, q_pre, x, ctx, heads=8):
+    """Transformer.py:95-136 CrossAttention._forward (== the xformers branch :140-156)."""
+    q = F.linear(x, sd[q_pre + "to_q.weight"])
+    k = F.linear(ctx, sd[q_pre + "to_k.weight"])
+    v = F.linear(ctx, sd[q_pre + "to_v.weight"])
+    b, n, inner = q.shape
+    d = inner // heads
+    sp = lambda t: t.reshape(b, -1, heads, d).transpose(1, 2)
+    o = attention(sp(q), sp(k), sp(v), d ** -0.5).transpose(1, 2).reshape(b, n, inner)
+    return F.linear(o, sd[q_pre + "to_out.0.weight"], sd[q_pre + "to_out.0.bias"])
+
+
+def mask_decoder_forward(sd, query, ctx, mask_keep=None, depth=3, heads=8, p="aux_decoder.transformer_decoder."):
+    """Transformer.py:263-283 MaskTransformerDecoder.forward. query, ctx: [B,C,h,w].
+    mask_keep: bool [B,1,h,w] (True keeps the feature, False -> mask_token) or None (mask disabled)."""
+    b, c, h, w = ctx.shape
+    if mask_keep is not None:
+        query = torch.where(mask_keep, query, sd[p + "mask_token"].expand(b, -1, h, w))
+    x = F.group_norm(query, 32, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-6)  # Normalize(): eps 1e-6 (:91-92)
+    x = x.flatten(2).transpose(1, 2)
+    cx = ctx.flatten(2).transpose(1, 2)
+    for i in range(depth):
+        q = f"{p}transformer_blocks.{i}."
+        ln = lambda t, nm: F.layer_norm(t, (c,), sd[q + nm + ".weight"], sd[q + nm + ".bias"], 1e-5)
+        x = _mha(sd, q + "attn1.", ln(x, "norm1"), ln(x, "norm1"), heads) + x  # self-attention (:174)
+        x = _mha(sd, q + "attn2.", ln(x, "norm2"), cx, heads) + x  # cross-attention to the context (:175)
+        hgl = F.linear(ln(x, "norm3"), sd[q + "ff.net.0.proj.weight"], sd[q + "ff.net.0.proj.bias"])
+        a, gate = hgl.chunk(2, dim=-1)  # GEGLU (:52-59)
+        x = F.linear(a * F.gelu(gate), sd[q + "ff.net.2.weight"], sd[q + "ff.net.2.bias"]) + x
+    return x.transpose(1, 2).reshape(b, c, h, w)
+
+
+def vfm_head_forward(sd, feats, ctx_logits, mask_keep=None, drop2d=None, p="aux_decoder.", depth=3):
+    """VFMHead.py:61-89. feats 4x[B,C,h,w], ctx_logits [B,19,Hc,Wc] -> logits [B,19,h,w]."""
+    h, w = feats[0].shape[2:]
+    s = F.interpolate(ctx_logits, size=(h * 4, w * 4), mode="bilinear", align_corners=False)
+    gelu = F.gelu
+    f = F.conv2d(torch.cat(list(feats), dim=1), sd[p + "fuse_conv.0.weight"], sd[p + "fuse_conv.0.bias"])
+    f = gelu(F.group_norm(f, 32, sd[p + "fuse_conv.1.weight"], sd[p + "fuse_conv.1.bias"], 1e-5))
+    e = F.conv2d(s, sd[p + "seg_logits_embed.0.weight"], sd[p + "seg_logits_embed.0.bias"], stride=2)
+    e = gelu(F.group_norm(e, 32, sd[p + "seg_logits_embed.1.weight"], sd[p + "seg_logits_embed.1.bias"], 1e-5))
+    e = F.conv2d(e, sd[p + "seg_logits_embed.3.weight"], sd[p + "seg_logits_embed.3.bias"], stride=2)
+    e = gelu(F.group_norm(e, 32, sd[p + "seg_logits_embed.4.weight"], sd[p + "seg_logits_embed.4.bias"], 1e-5))
+    e = F.conv2d(e, sd[p + "seg_logits_embed.6.weight"], sd[p + "seg_logits_embed.6.bias"])
+    e = F.group_norm(e, 32, sd[p + "seg_logits_embed.7.weight"], sd[p + "seg_logits_embed.7.bias"], 1e-5)
+    # NB argument order (VFMHead.py:82 vs Transformer.py:270): query = fused image feats, context = logits embedding
+    o = mask_decoder_forward(sd, f, e, mask_keep, depth=depth, p=p + "transformer_decoder.")
+    if drop2d is not None:
+        o = o * drop2d
+    return F.conv2d(o, sd[p + "conv_seg.weight"], sd[p + "conv_seg.bias"])
+
+
+def ce_loss_acc(seg_logits, label, ignore=IGNORE):
+    """mmseg CrossEntropyLoss(avg_non_ignore=False) + accuracy (linear_head.py:93-108): the mean runs over ALL pixels."""
+    loss = F.cross_entropy(seg_logits, label, reduction="none", ignore_index=ignore).mean()
+    valid = label != ignore
+    hit = (seg_logits.argmax(1) == label) & valid
+    acc = hit.sum().float() * (100.0 / (valid.sum().float() + torch.finfo(torch.float32).eps))
+    return loss, acc
+
+
+def head_loss(logits_lowres, label):
+    """`.loss()` of both heads: bilinear to the label size, CE, acc. label [B,1,H,W] int64."""
+    up = F.interpolate(logits_lowres, size=label.shape[2:], mode="bilinear", align_corners=False)
+    loss, acc = ce_loss_acc(up, label.squeeze(1))
+    return loss, acc, up
+
+
+# =============================================================================== segmentor: training
+def get_crop_bbox(img_h, img_w, crop_size, divisible=1, rng=np.random):
+    """Ms_VFM_encoder_decoder.py:34-46."""
+    if img_h == crop_size[-2] and img_w == crop_size[-1]:
+        return (0, img_h, 0, img_w)
+    mh, mw = max(img_h - crop_size[-2], 0), max(img_w - crop_size[-1], 0)
+    oh = rng.randint(0, (mh + 1) // divisible) * divisible
+    ow = rng.randint(0, (mw + 1) // divisible) * divisible
+    return oh, oh + crop_size[0], ow, ow + crop_size[1]
+
+
+def forward_train(sd, img, label, hr_box, mask_keep, depth=24, heads=16, out_indices=(7, 11, 15, 23),
+                  lora_drop_masks=(None, None), drop2d=(None, None), detail_loss=1.0, bn_out=None, dec_depth=3):
+    """MsVFMEncoderDecoder.forward_train (Ms_VFM_encoder_decoder.py:125-200) with the RNG consumers made explicit
+    (SURVEY App. B): hr_box = (y1,y2,x1,x2), mask_keep = bool [B,1,32,32], optional dropout multipliers."""
+    y1, y2, x1, x2 = hr_box
+    lr_img = F.interpolate(img, scale_factor=0.5, mode="bilinear", align_corners=False)  # scales sorted [0.5, 1] (:87)
+    hr_img = img[:, :, y1:y2, x1:x2]
+    lr_feats = dinov2_forward(sd, lr_img, depth, heads, out_indices, drop_masks=lora_drop_masks[0])
+    hr_feats = dinov2_forward(sd, hr_img, depth, heads, out_indices, drop_masks=lora_drop_masks[1])
+    lr_gt = F.interpolate(label.float(), scale_factor=0.5, mode="nearest").long()  # get_lr_seg (:148-153)
+    hr_gt = label[:, :, y1:y2, x1:x2]  # get_hr_seg (:155-158)
+    lr_logits = linear_head_forward(sd, lr_feats, training=True, drop2d=drop2d[0], bn_out=bn_out)
+    l_lr, a_lr, lr_up = head_loss(lr_logits, lr_gt)
+    ctx = lr_up.detach()[:, :, y1 // 2:y2 // 2, x1 // 2:x2 // 2]  # get_seg_logits + resize_box(ratio=2) (:160-167)
+    hr_logits = vfm_head_forward(sd, hr_feats, ctx, mask_keep, drop2d=drop2d[1], depth=dec_depth)
+    l_hr, a_hr, _ = head_loss(hr_logits, hr_gt)
+    return {
+        "decode_lr.loss_ce": l_lr,
+        "decode_lr.acc_seg": a_lr,
+        "decode_hr.loss_ce": l_hr * detail_loss,
+        "decode_hr.acc_seg": a_hr,
+    }
+
+
+def trainable_keys(sd):
+    """LoRABackbone.train(): only names containing 'lora' train in the backbone (utils.py:9-23); heads train fully."""
+    out = []
+    for k, v in sd.items():
+        if not torch.is_tensor(v) or not v.is_floating_point():
+            continue
+        if "running_" in k:
+            continue
+        if k.startswith("backbone."):
+            if "lora_" in k:
+                out.append(k)
+        else:
+            out.append(k)
+    return out
+
+
+def total_loss(losses):
+    """mmengine BaseModel.parse_losses: sum of entries whose key contains 'loss'."""
+    return sum(v for k, v in losses.items() if "loss" in k)
+
+
+# =============================================================================== segmentor: inference
+def grid_boxes(h_img, w_img, crop=(512, 512), stride=(320, 320)):
+    """mmseg slide_inference window grid (also Ms_VFM_encoder_decoder.py:428-443)."""
+    hc, wc = crop
+    hs, ws = stride
+    hg = max(h_img - hc + hs - 1, 0) // hs + 1
+    wg = max(w_img - wc + ws - 1, 0) // ws + 1
+    boxes = []
+    for hi in range(hg):
+        for wi in range(wg):
+            y2 = min(hi * hs + hc, h_img)
+            x2 = min(wi * ws + wc, w_img)
+            boxes.append((max(y2 - hc, 0), y2, max(x2 - wc, 0), x2))
+    return boxes
+
+
+def whole_inference(sd, img, out_size, **kw):
+    """mmseg whole_inference -> encode_decode -> LinearHead.forward -> predict_by_feat (bilinear to img_shape)."""
+    feats = dinov2_forward(sd, img, **kw)
+    lg = linear_head_forward(sd, feats, training=False)
+    return F.interpolate(lg, size=out_size, mode="bilinear", align_corners=False)
+
+
+def slide_inference(sd, img, crop=(512, 512), stride=(320, 320), **kw):
+    """mmseg EncoderDecoder.slide_inference with the LinearHead (cfg5-style 'slide' / 'hr_slide_inference')."""
+    b, _, h, w = img.shape
+    preds = img.new_zeros((b, 19, h, w))
+    cnt = img.new_zeros((b, 1, h, w))
+    for (y1, y2, x1, x2) in grid_boxes(h, w, crop, stride):
+        lg = whole_inference(sd, img[:, :, y1:y2, x1:x2], (y2 - y1, x2 - x1), **kw)
+        preds[:, :, y1:y2, x1:x2] += lg
+        cnt[:, :, y1:y2, x1:x2] += 1
+    return preds / cnt
+
+
+def ms_inference(sd, img, thr=0.968, conf=0.8, crop=(512, 512), stride=(320, 320), trace=None, **kw):
+    """Ms_VFM_encoder_decoder.py:400-466: coarse whole pass at a hard-coded (512,1024), then confidence-gated
+    512^2 refinement with the VFMHead (mask disabled at test time, :422-423)."""
+    b, _, h, w = img.shape
+    small = F.interpolate(img, size=(512, 1024), mode="bilinear", align_corners=False)
+    seg = whole_inference(sd, small, (h, w), **kw)  # predict_by_feat resizes straight to the image size
+    preds = img.new_zeros((b, 19, h, w))
+    cnt = img.new_zeros((b, 1, h, w))
+    for (y1, y2, x1, x2) in grid_boxes(h, w, crop, stride):
+        ctx = seg[:, :, y1:y2, x1:x2]
+        frac = (ctx.softmax(dim=1).max(dim=1)[0] > thr).float().mean().item()
+        if frac < conf:
+            feats = dinov2_forward(sd, img[:, :, y1:y2, x1:x2], **kw)
+            lg = vfm_head_forward(sd, feats, ctx, mask_keep=None)
+            if trace is not None:
+                trace.append((y1, y2, x1, x2))
+        else:
+            lg = ctx
+        lg = F.interpolate(lg, size=(y2 - y1, x2 - x1), mode="bilinear", align_corners=False)
+        preds[:, :, y1:y2, x1:x2] += lg
+        cnt[:, :, y1:y2, x1:x2] += 1
+    return preds / cnt
+
+
+# =============================================================================== optimiser
+def param_group_options(name, module_is_norm, base_lr=1e-4, base_wd=0.05, custom_keys=None, norm_decay_mult=0.0):
+    """peft_optimizer_constructor.py:25-147 for one parameter: custom key (longest first, substring of the full
+    name) wins; otherwise norm-module params get wd * norm_decay_mult."""
+    custom_keys = custom_keys or {}
+    for key in sorted(sorted(custom_keys), key=len, reverse=True):
+        if key in name:
+            return base_lr * custom_keys[key].get("lr_mult", 1.0), base_wd * custom_keys[key].get("decay_mult", 1.0)
+    if module_is_norm and norm_decay_mult is not None:
+        return base_lr, base_wd * norm_decay_mult
+    return base_lr, base_wd
+
+
+def poly_lr(base_lr, t, end=40000, power=0.9, eta_min=0.0):
+    """mmengine PolyLR closed form (dg_lora_dinov2_ms_masked.py:27-29)."""
+    t = min(t, end)
+    return (base_lr - eta_min) * (1 - t / end) ** power + eta_min
+
+
+def adamw_step(p, g, m, v, step, lr, wd, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.AdamW single-tensor update (decoupled decay), returns new (p, m, v)."""
+    p = p * (1 - lr * wd)
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)) + eps
+    return p - (lr / bc1) * m / denom, m, v
+
+
+# =============================================================================== evaluation
+def confusion_iou(pred, label, num_classes=19, ignore=IGNORE):
+    """mmseg IoUMetric.intersect_and_union + per-class IoU / mIoU (rein/dg_metrics.py:74-102 groups these by dataset)."""
+    valid = label != ignore
+    p, l = pred[valid], label[valid]
+    inter = torch.bincount(p[p == l], minlength=num_classes).double()
+    ap = torch.bincount(p, minlength=num_classes).double()
+    al = torch.bincount(l, minlength=num_classes).double()
+    union = ap + al - inter
+    iou = inter / union
+    return iou, float(np.nanmean(iou.numpy()) * 100.0)

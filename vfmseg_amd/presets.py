@@ -1,0 +1,131 @@
+"""Model presets: the hyper-parameters of the reference configs on the hot path, as plain dicts.
+
+Values (not code) taken from the reference config tree:
+  configs/_base_/models/lora_dinov2_ms_masked.py:1-87   -> dinov2_ms_masked()
+  configs/_base_/models/lora_dinov2_linear.py:1-53      -> dinov2_linear()
+  configs/dg/gta2citys/dg_lora_dinov2_ms_masked.py:10-29 -> optim_cfg()
+They use the reference's registry `type=` names and ctor kwargs so a user's own
+configs/dg/*.py dicts are interchangeable with these.
+"""
+import copy
+
+_PREPROC = dict(
+    type="SegDataPreProcessor",
+    mean=[123.675, 116.28, 103.53],
+    std=[58.395, 57.12, 57.375],
+    bgr_to_rgb=True,
+    pad_val=0,
+    seg_pad_val=255,
+)
+
+_CE = dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=1.0)
+
+
+def dinov2_backbone(depth=24, embed_dim=1024, num_heads=16, img_size=512):
+    return dict(
+        type="DinoVisionTransformer",
+        patch_size=16,
+        embed_dim=embed_dim,
+        depth=depth,
+        num_heads=num_heads,
+        mlp_ratio=4,
+        img_size=img_size,
+        ffn_layer="mlp",
+        init_values=1e-05,
+        block_chunks=0,
+        qkv_bias=True,
+        proj_bias=True,
+        ffn_bias=True,
+    )
+
+
+def lora_cfg(r=32, alpha=32, targets=("qkv",), dropout=0.1):
+    return dict(r=r, lora_alpha=alpha, target_modules=list(targets), lora_dropout=dropout)
+
+
+def linear_head(embed_dim=1024, channels=256, num_classes=19):
+    return dict(
+        type="LinearHead",
+        in_channels=[embed_dim] * 4,
+        in_index=[0, 1, 2, 3],
+        channels=channels,
+        dropout_ratio=0.1,
+        num_classes=num_classes,
+        norm_cfg=dict(type="GN", num_groups=32),
+        align_corners=False,
+        loss_decode=copy.deepcopy(_CE),
+    )
+
+
+def vfm_head(embed_dim=1024, channels=256, num_classes=19, depth=3, mask_ratio=0.2):
+    return dict(
+        type="VFMHead",
+        transformer=dict(
+            type="MaskTransformerDecoder",
+            query_dim=channels,
+            n_heads=8,
+            d_head=64,
+            depth=depth,
+            dropout=0.1,
+            mask_ratio=mask_ratio,
+        ),
+        in_channels=[embed_dim] * 4,
+        in_index=[0, 1, 2, 3],
+        channels=channels,
+        dropout_ratio=0.1,
+        num_classes=num_classes,
+        norm_cfg=dict(type="GN", num_groups=32),
+        align_corners=False,
+        loss_decode=copy.deepcopy(_CE),
+    )
+
+
+def dinov2_ms_masked(depth=24, embed_dim=1024, num_heads=16, checkpoint=None, work_dir="work_dirs/tmp"):
+    """The `MsVFMEncoderDecoder` model of BASELINE config 2/3."""
+    return dict(
+        type="MsVFMEncoderDecoder",
+        data_preprocessor=dict(_PREPROC, size=(1024, 1024)),
+        backbone=dict(
+            type="LoRABackbone",
+            backbone=dinov2_backbone(depth, embed_dim, num_heads),
+            checkpoint=checkpoint,
+            Lora_config=lora_cfg(),
+        ),
+        decode_head=linear_head(embed_dim),
+        aux_head=vfm_head(embed_dim),
+        detail_loss=1.0,
+        scales=[1, 0.5],
+        hr_crop_size=(512, 512),
+        feature_scale=0.5,
+        crop_coord_divisible=32,
+        train_cfg=dict(work_dir=work_dir, log_config=dict(interval=50, img_interval=500)),
+        test_cfg=dict(
+            mode="ms_slide_inference",
+            threadshod=0.968,
+            conf=0.8,
+            lr_img_size=(512, 1024),
+            stride=[320, 320],
+            crop_size=[512, 512],
+        ),
+    )
+
+
+def optim_cfg():
+    embed_multi = dict(lr_mult=1.0, decay_mult=0.0)
+    return dict(
+        optim_wrapper=dict(
+            constructor="PEFTOptimWrapperConstructor",
+            optimizer=dict(type="AdamW", lr=0.0001, weight_decay=0.05, eps=1e-8, betas=(0.9, 0.999)),
+            paramwise_cfg=dict(
+                custom_keys={
+                    "norm": dict(decay_mult=0.0),
+                    "query_embed": embed_multi,
+                    "level_embed": embed_multi,
+                    "learnable_tokens": embed_multi,
+                    "reins.scale": embed_multi,
+                },
+                norm_decay_mult=0.0,
+            ),
+        ),
+        param_scheduler=[dict(type="PolyLR", eta_min=0, power=0.9, begin=0, end=40000, by_epoch=False)],
+    )
