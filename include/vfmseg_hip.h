@@ -1,0 +1,203 @@
+/* libvfmseg_hip - C ABI of the MI355X (gfx950) kernels behind the VFM-segmentation hot path.
+ *
+ * The reference (tpy001/VFMSeg) has no FFI of its own: its extension boundary is the mmengine
+ * registry + nn.Module method signatures.  This library sits *below* that surface;
+ * every entry point replaces one family of third-party CUDA kernels the reference launches through
+ * torch / xformers / peft, cited per function as reference file:line.
+ *
+ * Conventions
+ *  - every pointer is a caller-owned DEVICE pointer (e.g. torch.Tensor.data_ptr()); no ownership transfer
+ *  - kernels are asynchronous on `stream` (a hipStream_t passed as void*), never synchronise, never allocate
+ *  - return 0 on success, negative VFM_E_* otherwise; vfm_last_error() gives a thread-local message
+ *  - matrices are row-major with explicit leading dimensions in ELEMENTS
+ *  - dtypes: VFM_F32 / VFM_BF16 activations and weights, fp32 accumulation and statistics, int64 labels
+ *  - token-major ("NHWC") activations: a feature map [B,H,W,C] is the matrix [B*H*W, C]
+ */
+#ifndef VFMSEG_HIP_H
+#define VFMSEG_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { VFM_F32 = 0, VFM_BF16 = 1, VFM_U8 = 2, VFM_I64 = 3 };
+enum { VFM_OK = 0, VFM_E_INVAL = -1, VFM_E_SHAPE = -2, VFM_E_ALIGN = -3, VFM_E_HIP = -4, VFM_E_UNSUPPORTED = -5 };
+/* GEMM epilogue modes */
+enum { VFM_EP_NONE = 0, VFM_EP_GELU = 1, VFM_EP_RELU = 2, VFM_EP_MUL_GELU_GRAD = 3, VFM_EP_MUL = 4 };
+/* activation fused into norm kernels */
+enum { VFM_ACT_NONE = 0, VFM_ACT_GELU = 1, VFM_ACT_RELU = 2 };
+
+const char* vfm_last_error(void);
+int vfm_abi_version(void);
+
+/* ---- elementwise / layout ------------------------------------------------------------------ */
+/* dst[r,c] = src[r,c] * (colscale ? colscale[c] : 1)          (casts; LayerScale prologue for dgrad) */
+int vfm_cast(const void* src, int src_dt, long ld_src, void* dst, int dst_dt, long ld_dst, long rows, long cols,
+             const float* colscale, void* stream);
+/* dst[c, r] = src[r, c] for r<rows, c<cols; dst has ld_dst >= rows, columns rows..pad_rows-1 are zero-filled.
+ * Used to feed weight-gradient GEMMs (reduction over tokens) to the NT GEMM. */
+int vfm_transpose(const void* src, int src_dt, long ld_src, void* dst, int dst_dt, long ld_dst, long rows, long cols,
+                  long pad_rows, void* stream);
+/* generic 4-D strided gather/scatter + cast over the index space [n0,n1,n2,n3] (weight packing / un-packing):
+ * dst[i0*d0+i1*d1+i2*d2+i3*d3] = src[i0*s0+i1*s1+i2*s2+i3*s3]; accumulate=1 adds into an fp32 dst */
+int vfm_strided_copy(const void* src, int src_dt, void* dst, int dst_dt, long n0, long n1, long n2, long n3, long s0,
+                     long s1, long s2, long s3, long d0, long d1, long d2, long d3, int accumulate, void* stream);
+/* y = a*x + b*y elementwise over n fp32 values (gradient accumulation, residual adds) */
+int vfm_axpby(const float* x, float a, float* y, float b, long n, void* stream);
+/* y[i] *= *scalar (device scalar; keeps the loss-scale multiply on the GPU) */
+int vfm_scale_by_device_scalar(float* y, const float* scalar, long n, void* stream);
+/* out[c] (+)= sum_r x[r,c]  (bias gradients); deterministic two-stage reduction, ws >= 64*cols floats */
+int vfm_colsum(const void* x, int dt, long ld, long rows, long cols, float* out, int accumulate, float* ws, void* stream);
+/* Bernoulli keep-mask multipliers: out[i] = (u_i >= p) ? 1/(1-p) : 0, counter-based hash RNG (seed, offset) */
+int vfm_dropout_mask(void* out, int dt, long n, float p, uint64_t seed, uint64_t offset, void* stream);
+/* dst[r,c] = src[r,c] * mask[(r / rows_per_group) * mask_ld + c]   (Dropout2d: one multiplier per (image, channel));
+ * rows_per_group == 1 gives plain elementwise dropout */
+int vfm_mul_mask(const void* src, int src_dt, long ld_src, const void* mask, int mask_dt, long mask_ld,
+                 long rows_per_group, void* dst, int dst_dt, long ld_dst, long rows, long cols, void* stream);
+/* GEGLU (Transformer.py:52-59): out[r, c] = h[r, c] * gelu(h[r, C + c]),  h is [rows, 2C] */
+int vfm_geglu_fwd(const void* h, int h_dt, long ld_h, void* out, int out_dt, long ld_out, long rows, long C, void* stream);
+int vfm_geglu_bwd(const void* h, int h_dt, long ld_h, const void* dout, int do_dt, long ld_do, void* dh, int dh_dt,
+                  long ld_dh, long rows, long C, void* stream);
+/* query masking (Transformer.py:263-268): out[r,:] = keep[r] ? x[r,:] : token[:] ; bwd splits the gradient */
+int vfm_mask_token_fwd(const float* x, const uint8_t* keep, const float* token, float* out, long rows, long C, void* stream);
+int vfm_mask_token_bwd(const float* dout, const uint8_t* keep, float* dx, float* dtoken, long rows, long C, void* stream);
+
+/* ---- normalisation --------------------------------------------------------------------------- */
+/* LayerNorm over the last dim (block.py:63,75; Transformer.py:167-169). x fp32 [rows, C]; y in out_dt; optional second
+ * output y2 = y * mask2 (LoRA input dropout, peft lora.Linear) ; stats = (mean, rstd) fp32 [rows,2] */
+int vfm_layernorm_fwd(const float* x, long ld_x, const float* w, const float* b, float eps, void* y, int y_dt, long ld_y,
+                      float* stats, long rows, long C, void* stream);
+/* dx (+)= LN backward; dw/db accumulate into fp32 [C] when non-null (two-stage, ws >= 2*128*C floats) */
+int vfm_layernorm_bwd(const void* dy, int dy_dt, long ld_dy, const float* x, long ld_x, const float* w,
+                      const float* stats, float* dx, long ld_dx, int accumulate_dx, float* dw, float* db, float* ws,
+                      long rows, long C, void* stream);
+/* GroupNorm on token-major maps [B, P, C] (P pixels): groups of C/G channels, statistics over (P, C/G).
+ * (linear_head.py:36-40 ConvModule GN; VFMHead.py:28-49; Transformer.py:91-92 eps 1e-6). Fused activation.
+ * stats fp32 [B, G, 2]. y in y_dt; */
+int vfm_groupnorm_fwd(const float* x, const float* w, const float* b, float eps, int G, int act, void* y, int y_dt,
+                      float* stats, float* ws, long B, long P, long C, void* stream);
+/* ws for both: >= B*G*2 + B*64*2*C floats */
+int vfm_groupnorm_bwd(const void* dy, int dy_dt, const float* x, const float* w, const float* b, const float* stats,
+                      int G, int act, float* dx, float* dw, float* db, float* ws, long B, long P, long C, void* stream);
+/* BatchNorm (nn.SyncBatchNorm, linear_head.py:44) on [rows, C]: partial moments -> (sum, sumsq) fp32 [2,C] */
+int vfm_bn_moments(const float* x, long rows, long C, float* sums, float* ws, void* stream);
+/* (sum, sumsq) over `count` rows (after the DP all-reduce of the sums, if any) -> mean_var fp32 [2,C] (biased var);
+ * updates running stats like nn.SyncBatchNorm (momentum, unbiased var) when non-null */
+int vfm_bn_finalize(const float* sums, float count, float* mean_var, float* running_mean, float* running_var,
+                    float momentum, long C, void* stream);
+/* y = act((x-mean)*rstd*w+b); mean_var fp32 [2,C] (biased var) */
+int vfm_bn_apply(const float* x, const float* mean_var, const float* w, const float* b, float eps, int act, void* y,
+                 int y_dt, long rows, long C, void* stream);
+/* sums_dy fp32 [2,C] = (sum dz, sum dz*xhat) where dz = dy*act'(.)  (the quantities SyncBN all-reduces in backward) */
+int vfm_bn_bwd_reduce(const void* dy, int dy_dt, const float* x, const float* mean_var, const float* w, const float* b,
+                      float eps, int act, float* sums_dy, float* ws, long rows, long C, void* stream);
+/* dx from the (possibly all-reduced) sums; total_rows = global row count */
+int vfm_bn_bwd_apply(const void* dy, int dy_dt, const float* x, const float* mean_var, const float* w, const float* b,
+                     float eps, int act, const float* sums_dy, float total_rows, float* dx, long rows, long C,
+                     void* stream);
+
+/* ---- GEMM ------------------------------------------------------------------------------------- */
+/* C[M,N] = epilogue( alpha * sum_k A[m,k] * B[n,k] )       (torch.nn.Linear / 1x1 conv / ConvT2x2 / dgrad / wgrad)
+ *   in_dt VFM_BF16: MFMA bf16 path, A/B bf16 row-major with K contiguous, K % 64 == 0 (pad with zeros)
+ *   in_dt VFM_F32 : exact-fp32 MFMA path, arbitrary element strides (sa_m,sa_k),(sb_n,sb_k), any K
+ * epilogue order:  v = alpha*acc + bias[n % bias_mod];  if C2: C2 = v (pre-activation, saved for backward)
+ *                  ep_mode: GELU/RELU -> v = act(v);  MUL_GELU_GRAD -> v *= gelu'(aux[m,n]);  MUL -> v *= aux[m,n]
+ *                  v *= colscale[n];  v += residual[m,n];  C = v   (residual may alias C: in-place accumulate)
+ * batch: z in [0,batch): operand offsets z*stride (elements).  (attention.py:51-53,58,80; mlp.py:34-40; linear_head.py:36-48)
+ */
+typedef struct vfm_gemm_desc {
+  const void* A; const void* B; void* C;
+  int in_dt; int c_dt;
+  long M, N, K;
+  long sa_m, sa_k, sb_n, sb_k, ldc;
+  float alpha;
+  const float* bias; long bias_mod;
+  const float* colscale;
+  const void* residual; int r_dt; long ldr;
+  int ep_mode; const void* aux; int aux_dt; long ld_aux;
+  void* C2; int c2_dt; long ldc2;
+  long batch, stride_a, stride_b, stride_c;
+} vfm_gemm_desc;
+int vfm_gemm(const vfm_gemm_desc* d, void* stream);
+
+/* ---- attention -------------------------------------------------------------------------------- */
+/* softmax(q k^T * scale) v per (image, head)  - xformers memory_efficient_attention (attention.py:73-89,
+ * Transformer.py:140-156).  Token rows of image b: sequence index i < n_main -> row b*n_main + i,
+ * else (the [cls] token, stored after all patch tokens) row B*n_main + b.  q/k/v element (row, h*d + j) at
+ * ptr[row*ld + h*d + j].  lse fp32 [B, H, nq] (log-sum-exp of the scaled scores) is saved for backward. */
+typedef struct vfm_attn_desc {
+  const void* q; const void* k; const void* v; void* o;
+  int dt; long ldq, ldk, ldv, ldo;
+  int B, H, d;
+  int nq_main, nq_extra, nk_main, nk_extra;
+  float scale;
+  float* lse;
+  /* backward only */
+  const void* dout; long ld_do;
+  void* dq; void* dk; void* dv; long ld_dq, ld_dk, ld_dv;
+  float* delta; /* workspace fp32 [B,H,nq] */
+} vfm_attn_desc;
+int vfm_attn_fwd(const vfm_attn_desc* d, void* stream);
+int vfm_attn_bwd(const vfm_attn_desc* d, void* stream);
+
+/* ---- ViT input / output ------------------------------------------------------------------------ */
+/* im2col of non-overlapping PxP patches (patch_embed.py:65-77): img fp32 NCHW [B,3,H,W] (crop window y0,x0,
+ * row/plane strides in elements) -> A [B*(h/P)*(w/P), 3*P*P] in out_dt, k = c*P*P + py*P + px (conv weight order) */
+int vfm_patchify(const float* img, long stride_b, long stride_c, long stride_y, int y0, int x0, int h, int w, int P,
+                 void* out, int out_dt, long ld_out, int B, void* stream);
+/* tokens = [patch rows + pos[1+i]] then [cls + pos[0]] rows at the end (dino_v2.py:217-228, cls-last layout) */
+int vfm_assemble_tokens(const float* patch_tok, const float* cls, const float* pos, float* x, int B, int np, int C,
+                        void* stream);
+
+/* ---- resize / loss ------------------------------------------------------------------------------ */
+/* bilinear, align_corners=False (F.interpolate semantics: src=(dst+0.5)*scale-0.5 clamped at 0), fp32.
+ * in: [B,Hi,Wi,C] (in_nchw=0) or [B,C,Hi,Wi] (in_nchw=1). The *virtual* output is Hv x Wv; only the window
+ * (y0,x0,hc,wc) is produced.  out layout: out_mode 0 = NHWC [B,hc,wc,ldc_out] (C valid, rest zero),
+ * 1 = NCHW [B,C,hc,wc], 2 = NHWC with 2-level 2x2 blocked pixel order (b, y/4, x/4, (y/2)%2, (x/2)%2, y%2, x%2, C)
+ * so that stride-2 2x2 convolutions become GEMMs on views (VFMHead.py:38-45).  (Ms_VFM_encoder_decoder.py:129-133,
+ * 160-167; VFMHead.py:63-67; linear_head.py:76-80) */
+int vfm_resize_bilinear(const void* in, int in_dt, int in_nchw, int B, int Hi, int Wi, int C, long in_ld_c, void* out,
+                        int out_dt, int out_mode, long out_ld_c, int Hv, int Wv, int y0, int x0, int hc, int wc,
+                        void* stream);
+/* nearest (F.interpolate mode='nearest': src=floor(dst*scale)) + crop for int64 label maps (get_lr_seg/get_hr_seg,
+ * Ms_VFM_encoder_decoder.py:148-158). in [B,Hi,Wi] -> out [B,hc,wc] of the virtual Hv x Wv map */
+int vfm_label_resize(const int64_t* in, int B, int Hi, int Wi, int64_t* out, int Hv, int Wv, int y0, int x0, int hc,
+                     int wc, void* stream);
+/* blocked <-> raster pixel order for small maps: x [B, H*W (blocked, levels), C] -> y [B,H,W,C] (inverse when inv=1) */
+int vfm_unblock(const float* x, float* y, int B, int H, int W, int C, int levels, int inverse, void* stream);
+/* fused bilinear-upsample + softmax cross-entropy (ignore_index) + top-1 accuracy + d(logits_low)
+ * (mmseg CrossEntropyLoss(avg_non_ignore=False) + accuracy via linear_head.py:72-113 / VFMHead.py:91-133):
+ *   logits_low fp32 NHWC [B,h,w,C] ; label int64 [B,H,W] ; loss = sum_valid(-log p[label]) / (B*H*W)
+ *   out: loss_parts fp32 [B*h*w] (summed by caller-visible vfm_reduce_sum), counts int32 [2] = (hits, valid),
+ *   dlogits fp32 [B,h,w,C] = d loss / d logits_low (may be null for inference).  The full-resolution logits never
+ *   touch HBM. */
+int vfm_upsample_ce(const float* logits_low, const int64_t* label, int B, int h, int w, int C, int H, int W,
+                    int ignore_index, float* loss_parts, int32_t* counts, float* dlogits, void* stream);
+/* deterministic sum of n floats -> out[0] (out[0] *= scale) */
+int vfm_reduce_sum(const float* x, long n, float scale, float* out, void* stream);
+
+/* ---- inference helpers --------------------------------------------------------------------------- */
+/* confidence gate (Ms_VFM_encoder_decoder.py:446-448): frac[0] = mean_pixels( max softmax(logits) > thr ) over the
+ * window of an NCHW map [B,C,H,W]; counts int32 [1] zeroed by the caller */
+int vfm_conf_gate(const float* logits, int B, int C, int H, int W, int y0, int x0, int hc, int wc, float thr,
+                  int32_t* count, void* stream);
+/* preds[:, :, y0:y0+hc, x0:x0+wc] += bilinear_resize(crop_logits NHWC [B,h,w,C] or NCHW) ; count += 1
+ * (slide accumulate, Ms_VFM_encoder_decoder.py:453-459) */
+int vfm_slide_accumulate(const float* crop, int crop_nchw, int B, int h, int w, int C, float* preds, float* count,
+                         int H, int W, int y0, int x0, int hc, int wc, void* stream);
+/* seg = preds / count ; pred = argmax_c  (NCHW) */
+int vfm_slide_finalize(float* preds, const float* count, uint8_t* argmax, int B, int C, int H, int W, void* stream);
+
+/* ---- optimiser ------------------------------------------------------------------------------------- */
+/* fused multi-tensor AdamW over one flat fp32 buffer (torch.optim.AdamW semantics; groups from
+ * peft_optimizer_constructor.py:25-147): segment s covers [seg_start[s], seg_start[s+1]) with lr*seg_lr_mult[s],
+ * seg_wd[s]. lr and step are passed by value each iteration (PolyLR on the host). */
+int vfm_adamw(float* p, const float* g, float* m, float* v, long n, const long* seg_start, const float* seg_lr_mult,
+              const float* seg_wd, int n_seg, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+              void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

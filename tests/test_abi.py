@@ -1,0 +1,50 @@
+"""CPU-side checks of the C-ABI boundary: the library builds/loads and exports every symbol the header declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "vfmseg_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(vfm_\w+)\s*\(", txt)))
+
+
+def test_header_declares_entry_points():
+    names = _declared()
+    assert "vfm_gemm" in names and "vfm_attn_fwd" in names and "vfm_upsample_ce" in names and len(names) >= 35
+
+
+def test_library_exports_every_declared_symbol():
+    from vfmseg_amd.csrc import build
+    lib_path = build.LIB if os.path.exists(build.LIB) else build.build(verbose=False)
+    lib = ctypes.CDLL(lib_path)
+    missing = [n for n in _declared() if not hasattr(lib, n)]
+    assert not missing, missing
+    lib.vfm_abi_version.restype = ctypes.c_int
+    assert lib.vfm_abi_version() >= 1
+
+
+def test_python_binding_matches_header():
+    from vfmseg_amd import lib as L
+    declared = set(_declared()) - {"vfm_last_error", "vfm_abi_version"}
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    # argument counts agree with the header prototypes
+    txt = open(os.path.join(ROOT, "include", "vfmseg_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    for name, args in L.SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", txt, flags=re.S)
+        assert m, name
+        n = len([a for a in m.group(1).split(",") if a.strip()])
+        assert n == len(args), (name, n, len(args))
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from vfmseg_amd import lib as L, ops
+    with pytest.raises(L.HipError):
+        ops.cast(torch.zeros(4, 4), torch.zeros(4, 4))

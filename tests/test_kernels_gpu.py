@@ -1,0 +1,388 @@
+"""Per-kernel numerics on a real MI355X: every C-ABI entry point against a plain PyTorch fp32 CPU reference."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from vfmseg_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def test_cast_transpose_strided():
+    x = rnd(37, 70, seed=1)
+    cs = rnd(70, seed=2)
+    y = torch.empty(37, 70, dtype=torch.bfloat16, device=DEV)
+    ops.cast(x.to(DEV), y, cs.to(DEV))
+    assert relerr(y.float(), (x * cs).bfloat16().float()) < 1e-6
+    # column-slice destination
+    big = torch.zeros(37, 128, dtype=torch.float32, device=DEV)
+    ops.cast(x.to(DEV), big[:, 16:86])
+    assert torch.equal(big[:, 16:86].cpu(), x) and big[:, :16].abs().sum() == 0
+    t = torch.full((70, 64), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.transpose(x.to(DEV), t, pad_rows=64)
+    assert torch.equal(t[:, :37].float().cpu(), x.t().bfloat16().float()) and t[:, 37:].abs().sum() == 0
+    w = rnd(6, 5, 2, 2, seed=3)
+    out = torch.empty(2, 2, 5, 6, dtype=torch.float32, device=DEV)
+    ops.permute_copy(w.to(DEV), (2, 3, 1, 0), out)
+    assert torch.equal(out.cpu(), w.permute(2, 3, 1, 0).contiguous())
+
+
+def test_colsum_axpby_masks():
+    x = rnd(1000, 130, seed=4)
+    out = torch.ones(130, device=DEV)
+    ops.colsum(x.to(DEV), out, accumulate=True)
+    assert relerr(out, x.sum(0) + 1) < 1e-5
+    y = rnd(999, seed=5).to(DEV)
+    x2 = rnd(999, seed=6).to(DEV)
+    ref = 2.0 * x2 + 0.5 * y
+    ops.axpby(x2, 2.0, y, 0.5)
+    assert relerr(y, ref) < 1e-6
+    m = torch.empty(1 << 20, dtype=torch.float32, device=DEV)
+    ops.dropout_mask(m, 0.1, seed=123)
+    keep = (m > 0).float().mean().item()
+    assert abs(keep - 0.9) < 3e-3 and abs(m.max().item() - 1 / 0.9) < 1e-6
+    m2 = torch.empty(1 << 20, dtype=torch.float32, device=DEV)
+    ops.dropout_mask(m2, 0.1, seed=123)
+    assert torch.equal(m, m2)  # counter-based: reproducible
+    src = rnd(64, 48, seed=7)
+    msk = (rnd(4, 48, seed=8) > 0).float() * 2
+    dst = torch.empty(64, 48, dtype=torch.float32, device=DEV)
+    ops.mul_mask(src.to(DEV), msk.to(DEV), dst, rows_per_group=16)
+    assert relerr(dst, src * msk.repeat_interleave(16, 0)) < 1e-6
+
+
+def test_geglu_masktoken():
+    h = rnd(50, 96, seed=9)
+    out = torch.empty(50, 48, device=DEV)
+    ops.geglu_fwd(h.to(DEV), out)
+    a, g = h.chunk(2, -1)
+    assert relerr(out, a * F.gelu(g)) < 1e-5
+    hh = h.clone().requires_grad_(True)
+    a, g = hh.chunk(2, -1)
+    do = rnd(50, 48, seed=10)
+    (a * F.gelu(g)).backward(do)
+    dh = torch.empty(50, 96, device=DEV)
+    ops.geglu_bwd(h.to(DEV), do.to(DEV), dh)
+    assert relerr(dh, hh.grad) < 1e-5
+    x = rnd(40, 64, seed=11)
+    keep = (rnd(40, seed=12) > -0.5)
+    tok = rnd(64, seed=13)
+    o = torch.empty(40, 64, device=DEV)
+    ops.mask_token_fwd(x.to(DEV), keep.to(torch.uint8).to(DEV), tok.to(DEV), o)
+    assert torch.equal(o.cpu(), torch.where(keep[:, None], x, tok[None]))
+    dx = torch.empty(40, 64, device=DEV)
+    dt = torch.empty(64, device=DEV)
+    ops.mask_token_bwd(x.to(DEV), keep.to(torch.uint8).to(DEV), dx, dt)
+    assert relerr(dx, x * keep[:, None]) < 1e-6 and relerr(dt, (x * (~keep)[:, None]).sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("C", [256, 1024])
+def test_layernorm(C):
+    rows = 77
+    x = rnd(rows, C, seed=14, scale=2.0) + 0.5
+    w, b = rnd(C, seed=15) * 0.1 + 1, rnd(C, seed=16) * 0.1
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), wr, br, 1e-6)
+    dy = rnd(rows, C, seed=17)
+    ref.backward(dy)
+    y = torch.empty(rows, C, device=DEV)
+    stats = torch.empty(rows, 2, device=DEV)
+    ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, y, stats)
+    assert relerr(y, ref) < 1e-5
+    yb = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+    ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6, yb, None)
+    assert relerr(yb.float(), ref) < 1e-2
+    dx = torch.ones(rows, C, device=DEV)
+    dw, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), stats, dx, accumulate_dx=True, dw=dw, db=db)
+    assert relerr(dx - 1, xr.grad) < 2e-5
+    assert relerr(dw, wr.grad) < 2e-5 and relerr(db, br.grad) < 2e-5
+
+
+@pytest.mark.parametrize("C,G,act", [(1024, 32, 2), (256, 32, 1), (64, 32, 1), (128, 32, 0)])
+def test_groupnorm(C, G, act):
+    B, P = 2, 32 * 32
+    x = rnd(B, P, C, seed=18, scale=1.5) + 0.3
+    w, b = rnd(C, seed=19) * 0.1 + 1, rnd(C, seed=20) * 0.1
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.group_norm(xr.permute(0, 2, 1), G, wr, br, 1e-5).permute(0, 2, 1)
+    ref = F.gelu(ref) if act == 1 else (F.relu(ref) if act == 2 else ref)
+    dy = rnd(B, P, C, seed=21)
+    ref.backward(dy)
+    y = torch.empty(B * P, C, device=DEV)
+    stats = torch.empty(B, G, 2, device=DEV)
+    xd = x.reshape(B * P, C).to(DEV)
+    ops.groupnorm_fwd(xd, w.to(DEV), b.to(DEV), 1e-5, G, act, y, stats, B, P)
+    assert relerr(y, ref.reshape(B * P, C)) < 2e-5
+    dx = torch.empty(B * P, C, device=DEV)
+    dw, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.groupnorm_bwd(dy.reshape(B * P, C).to(DEV), xd, w.to(DEV), b.to(DEV), stats, G, act, dx, dw, db, B, P)
+    assert relerr(dx, xr.grad.reshape(B * P, C)) < 5e-5
+    assert relerr(dw, wr.grad) < 5e-5 and relerr(db, br.grad) < 5e-5
+
+
+def test_batchnorm():
+    rows, C = 4096, 512
+    x = rnd(rows, C, seed=22, scale=1.3) + 0.2
+    w, b = rnd(C, seed=23) * 0.1 + 1, rnd(C, seed=24) * 0.1
+    rm, rv = rnd(C, seed=25) * 0.1, rnd(C, seed=26).abs() * 0.1 + 1
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.gelu(F.batch_norm(xr, rm_ref, rv_ref, wr, br, True, 0.1, 1e-5))
+    dy = rnd(rows, C, seed=27)
+    ref.backward(dy)
+    xd = x.to(DEV)
+    sums = torch.empty(2, C, device=DEV)
+    mv = torch.empty(2, C, device=DEV)
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    ops.bn_moments(xd, sums)
+    ops.bn_finalize(sums, rows, mv, rmd, rvd, 0.1)
+    y = torch.empty(rows, C, device=DEV)
+    ops.bn_apply(xd, mv, w.to(DEV), b.to(DEV), 1e-5, 1, y)
+    assert relerr(y, ref) < 2e-5
+    assert relerr(rmd, rm_ref) < 1e-5 and relerr(rvd, rv_ref) < 1e-5
+    sd = torch.empty(2, C, device=DEV)
+    ops.bn_bwd_reduce(dy.to(DEV), xd, mv, w.to(DEV), b.to(DEV), 1e-5, 1, sd)
+    assert relerr(sd[0], br.grad) < 5e-5 and relerr(sd[1], wr.grad) < 5e-5
+    dx = torch.empty(rows, C, device=DEV)
+    ops.bn_bwd_apply(dy.to(DEV), xd, mv, w.to(DEV), b.to(DEV), 1e-5, 1, sd, rows, dx)
+    assert relerr(dx, xr.grad) < 5e-5
+
+
+def _gemm_ref(a, b, bias=None, colscale=None, residual=None, ep=0, aux=None, alpha=1.0):
+    v = alpha * (a.double() @ b.double().t())
+    if bias is not None:
+        v = v + bias.double()
+    pre = v.clone()
+    if ep == 1:
+        v = F.gelu(v)
+    elif ep == 2:
+        v = F.relu(v)
+    elif ep == 3:
+        ad = aux.double().requires_grad_(True)
+        F.gelu(ad).sum().backward()
+        v = v * ad.grad
+    elif ep == 4:
+        v = v * aux.double()
+    if colscale is not None:
+        v = v * colscale.double()
+    if residual is not None:
+        v = v + residual.double()
+    return v, pre
+
+
+@pytest.mark.parametrize("M,N,K", [(100, 70, 50), (257, 130, 64), (64, 19, 256)])
+def test_gemm_f32(M, N, K):
+    a, b = rnd(M, K, seed=28), rnd(N, K, seed=29)
+    bias, cs, res, aux = rnd(N, seed=30), rnd(N, seed=31), rnd(M, N, seed=32), rnd(M, N, seed=33)
+    for ep in (0, 1, 2, 3, 4):
+        c = torch.empty(M, N, device=DEV)
+        c2 = torch.empty(M, N, device=DEV)
+        ops.gemm(a.to(DEV), b.to(DEV), c, alpha=0.5, bias=bias.to(DEV), colscale=cs.to(DEV), residual=res.to(DEV), ep_mode=ep,
+                 aux=aux.to(DEV), c2=c2)
+        ref, pre = _gemm_ref(a, b, bias, cs, res, ep, aux, 0.5)
+        assert relerr(c, ref) < 1e-5, ep
+        assert relerr(c2, pre) < 1e-5
+    # transposed operands via strides + in-place accumulate
+    c = res.clone().to(DEV)
+    ops.gemm(a.t().contiguous().to(DEV), b.t().contiguous().to(DEV), c, residual=c, trans_a=True, trans_b=True)
+    assert relerr(c, a.double() @ b.double().t() + res.double()) < 1e-5
+    # batched
+    ab, bb = rnd(3, M, K, seed=34), rnd(3, N, K, seed=35)
+    cb = torch.empty(3, M, N, device=DEV)
+    ops.gemm(ab.to(DEV), bb.to(DEV), cb)
+    assert relerr(cb, ab.double() @ bb.double().transpose(1, 2)) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (4100, 1024, 1024), (2048, 19, 256), (513, 64, 1088)])
+def test_gemm_bf16(M, N, K):
+    a, b = rnd(M, K, seed=36).bfloat16(), rnd(N, K, seed=37).bfloat16()
+    bias, cs, res, aux = rnd(N, seed=38), rnd(N, seed=39), rnd(M, N, seed=40), rnd(M, N, seed=41).bfloat16()
+    for ep in (0, 1, 3):
+        c = torch.empty(M, N, device=DEV)
+        c2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(a.to(DEV), b.to(DEV), c, bias=bias.to(DEV), colscale=cs.to(DEV), residual=res.to(DEV), ep_mode=ep,
+                 aux=aux.to(DEV), c2=c2)
+        ref, pre = _gemm_ref(a.float(), b.float(), bias, cs, res, ep, aux.float())
+        assert relerr(c, ref) < 2e-5, (ep, relerr(c, ref))  # bf16 inputs are exact in fp32; only accumulation order differs
+        assert relerr(c2.float(), pre) < 1e-2
+    cb = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(a.to(DEV), b.to(DEV), cb)
+    assert relerr(cb.float(), (a.double() @ b.double().t())) < 1e-2
+    # strided (column-slice) operands: A view inside a wider buffer, C into a column slice
+    wide = torch.zeros(M, K + 64, dtype=torch.bfloat16, device=DEV)
+    wide[:, :K] = a.to(DEV)
+    cw = torch.zeros(M, N + 8, device=DEV)
+    ops.gemm(wide[:, :K], b.to(DEV), cw[:, :N])
+    assert relerr(cw[:, :N], a.double() @ b.double().t()) < 2e-5 and cw[:, N:].abs().sum() == 0
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nq_extra,nk_extra,nq,nk", [(1, 1, 200, 200), (0, 0, 256, 256), (0, 0, 130, 70)])
+def test_attention(dt, nq_extra, nk_extra, nq, nk):
+    B, H, d = 2, 3, 64
+    hd = H * d
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    # token-major buffers: main tokens first, then the per-image extra (cls) rows
+    q = rnd(B * nq + B * nq_extra, hd, seed=42).to(dt)
+    k = rnd(B * nk + B * nk_extra, hd, seed=43).to(dt)
+    v = rnd(B * nk + B * nk_extra, hd, seed=44).to(dt)
+    do = rnd(B * nq + B * nq_extra, hd, seed=45).to(dt)
+
+    def gather(t, n, ne):  # -> [B, H, n+ne, d] float
+        main = t[: B * n].reshape(B, n, H, d)
+        if ne:
+            main = torch.cat([main, t[B * n:].reshape(B, 1, H, d)], 1)
+        return main.permute(0, 2, 1, 3).float()
+
+    qq, kk, vv = (gather(q, nq, nq_extra).requires_grad_(True), gather(k, nk, nk_extra).requires_grad_(True),
+                  gather(v, nk, nk_extra).requires_grad_(True))
+    scale = d ** -0.5
+    ref = ((qq @ kk.transpose(-1, -2)) * scale).softmax(-1) @ vv
+    ref.backward(gather(do, nq, nq_extra))
+
+    def scatter(g, n, ne):  # [B,H,n+ne,d] -> token-major
+        g = g.permute(0, 2, 1, 3)
+        main = g[:, :n].reshape(B * n, hd)
+        return torch.cat([main, g[:, n:].reshape(B * ne, hd)], 0) if ne else main
+
+    o = torch.empty(q.shape, dtype=dt, device=DEV)
+    lse = torch.empty(B, H, nq + nq_extra, device=DEV)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    ops.attn_fwd(qd, kd, vd, o, lse, B, H, d, nq, nq_extra, nk, nk_extra, scale)
+    assert relerr(o.float(), scatter(ref, nq, nq_extra)) < tol
+    dq, dk, dv = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    ops.attn_bwd(qd, kd, vd, o, lse, do.to(DEV), dq, dk, dv, B, H, d, nq, nq_extra, nk, nk_extra, scale)
+    assert relerr(dq.float(), scatter(qq.grad, nq, nq_extra)) < tol * 2
+    assert relerr(dk.float(), scatter(kk.grad, nk, nk_extra)) < tol * 2
+    assert relerr(dv.float(), scatter(vv.grad, nk, nk_extra)) < tol * 2
+
+
+def test_patchify_tokens():
+    B, P = 2, 16
+    img = rnd(B, 3, 96, 128, seed=46)
+    w = rnd(32, 3, P, P, seed=47)
+    ref = F.conv2d(img[:, :, 32:96, 16:112], w, stride=P).flatten(2).transpose(1, 2)  # [B, 24, 32]
+    a = torch.empty(B * 4 * 6, 3 * P * P, device=DEV)
+    ops.patchify(img.to(DEV), a, box=(32, 96, 16, 112))
+    got = a.cpu() @ w.reshape(32, -1).t()
+    assert relerr(got, ref.reshape(B * 24, 32)) < 1e-5
+    ptok, cls, pos = rnd(B * 24, 32, seed=48), rnd(32, seed=49), rnd(25, 32, seed=50)
+    x = torch.empty(B * 24 + B, 32, device=DEV)
+    ops.assemble_tokens(ptok.to(DEV), cls.to(DEV), pos.to(DEV), x, B, 24, 32)
+    exp_main = ptok.reshape(B, 24, 32) + pos[1:][None]
+    assert relerr(x[: B * 24], exp_main.reshape(B * 24, 32)) < 1e-6
+    assert relerr(x[B * 24:], (cls + pos[0])[None].expand(B, -1)) < 1e-6
+
+
+def test_resize_and_labels():
+    B, C = 2, 19
+    x = rnd(B, C, 32, 48, seed=51)
+    ref = F.interpolate(x, size=(128, 192), mode="bilinear", align_corners=False)
+    out = torch.empty(B, C, 128, 192, device=DEV)
+    ops.resize_bilinear(x.to(DEV), True, B, 32, 48, C, out, 1, (128, 192))
+    assert relerr(out, ref) < 1e-6
+    # NHWC in, cropped NHWC out
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    o2 = torch.empty(B, 40, 64, C, device=DEV)
+    ops.resize_bilinear(xn.to(DEV), False, B, 32, 48, C, o2, 0, (128, 192), window=(8, 16, 40, 64))
+    assert relerr(o2.permute(0, 3, 1, 2), ref[:, :, 8:48, 16:80]) < 1e-6
+    # down-scaling by 0.5 (no antialias) and blocked output
+    d = F.interpolate(ref, scale_factor=0.5, mode="bilinear", align_corners=False)  # [B,C,64,96]
+    o3 = torch.zeros(B * 32 * 48, 128, device=DEV)
+    ops.resize_bilinear(ref.to(DEV), True, B, 128, 192, C, o3, 2, (64, 96), out_ld=128)
+    # rows ordered (b, y/4, x/4, (y/2)%2, (x/2)%2); inside a row k = ((y%2)*2 + x%2)*C + c
+    exp = d.reshape(B, C, 16, 2, 2, 24, 2, 2).permute(0, 2, 5, 3, 6, 4, 7, 1).reshape(B * 16 * 24 * 4, 4 * C)
+    assert relerr(o3[:, : 4 * C], exp) < 1e-6 and o3[:, 4 * C:].abs().sum() == 0
+    lab = torch.randint(0, 19, (B, 64, 64), generator=torch.Generator().manual_seed(52))
+    lr = F.interpolate(lab[:, None].float(), scale_factor=0.5, mode="nearest").long()[:, 0]
+    o4 = torch.empty(B, 32, 32, dtype=torch.int64, device=DEV)
+    ops.label_resize(lab.to(DEV), o4, (32, 32))
+    assert torch.equal(o4.cpu(), lr)
+    o5 = torch.empty(B, 16, 24, dtype=torch.int64, device=DEV)
+    ops.label_resize(lab.to(DEV), o5, (64, 64), window=(8, 4, 16, 24))
+    assert torch.equal(o5.cpu(), lab[:, 8:24, 4:28])
+    # unblock round trip
+    z = rnd(B, 16 * 16, 5, seed=53)
+    u = torch.empty(B, 16, 16, 5, device=DEV)
+    ops.unblock(z.to(DEV), u, B, 16, 16, 5, 2)
+    zb = torch.empty(B, 256, 5, device=DEV)
+    ops.unblock(u, zb, B, 16, 16, 5, 2, inverse=True)
+    assert torch.equal(zb.cpu(), z)
+    e = z.reshape(B, 4, 4, 2, 2, 2, 2, 5).permute(0, 1, 3, 5, 2, 4, 6, 7).reshape(B, 16, 16, 5)
+    assert torch.equal(u.cpu(), e)
+
+
+@pytest.mark.parametrize("h,H", [(32, 128), (8, 128), (16, 16)])
+def test_upsample_ce(h, H):
+    B, C = 2, 19
+    lg = rnd(B, h, h, C, seed=54, scale=2.0)
+    lab = torch.randint(0, C, (B, H, H), generator=torch.Generator().manual_seed(55))
+    lab[:, 5:9] = 255
+    lr = lg.clone().requires_grad_(True)
+    up = F.interpolate(lr.permute(0, 3, 1, 2), size=(H, H), mode="bilinear", align_corners=False)
+    loss_ref = F.cross_entropy(up, lab, reduction="none", ignore_index=255).mean()
+    loss_ref.backward()
+    valid = lab != 255
+    hits_ref = ((up.argmax(1) == lab) & valid).sum().item()
+    loss, counts, dl = ops.upsample_ce(lg.to(DEV), lab.to(DEV))
+    assert abs(loss.item() - loss_ref.item()) < 1e-5 * max(1, abs(loss_ref.item()))
+    assert counts.tolist() == [hits_ref, int(valid.sum())]
+    assert relerr(dl, lr.grad) < 2e-5
+
+
+def test_inference_helpers():
+    B, C, H, W = 1, 19, 96, 128
+    lg = rnd(B, C, H, W, seed=56, scale=2.0)
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.conf_gate_count(lg.to(DEV), (16, 32, 64, 64), 0.3, cnt)
+    ref = (lg[:, :, 16:80, 32:96].softmax(1).max(1)[0] > 0.3).sum().item()
+    assert cnt.item() == ref
+    preds = torch.zeros(B, C, H, W, device=DEV)
+    count = torch.zeros(B, 1, H, W, device=DEV)
+    crop = rnd(B, 8, 8, C, seed=57)
+    pr, cr = torch.zeros(B, C, H, W), torch.zeros(B, 1, H, W)
+    for (y0, x0) in ((0, 0), (32, 64), (16, 32)):
+        ops.slide_accumulate(crop.to(DEV), False, B, 8, 8, C, preds, count, (y0, x0, 64, 64))
+        pr[:, :, y0:y0 + 64, x0:x0 + 64] += F.interpolate(crop.permute(0, 3, 1, 2), size=(64, 64), mode="bilinear", align_corners=False)
+        cr[:, :, y0:y0 + 64, x0:x0 + 64] += 1
+    cr = cr.clamp_min(1)
+    count.clamp_(min=1)
+    am = torch.empty(B, H, W, dtype=torch.uint8, device=DEV)
+    ops.slide_finalize(preds, count, am)
+    assert relerr(preds, pr / cr) < 1e-6
+    assert torch.equal(am.cpu().long(), (pr / cr).argmax(1))
+
+
+def test_adamw():
+    n = 10000
+    p, g = rnd(n, seed=58), rnd(n, seed=59)
+    q = p.clone().requires_grad_(True)
+    q2 = p[6000:].clone().requires_grad_(True)
+    opt = torch.optim.AdamW([dict(params=[q], weight_decay=0.05)], lr=1e-3)
+    pd, m, v = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    seg = torch.tensor([0, 6000], dtype=torch.int64, device=DEV)
+    lrm = torch.tensor([1.0, 1.0], device=DEV)
+    wd = torch.tensor([0.05, 0.05], device=DEV)
+    for step in (1, 2, 3):
+        q.grad = g.clone() * step
+        opt.step()
+        ops.adamw(pd, (g * step).to(DEV), m, v, seg, lrm, wd, 1e-3, (0.9, 0.999), 1e-8, step)
+    assert relerr(pd, q.detach()) < 1e-5

@@ -1,0 +1,63 @@
+"""Builds libvfmseg_hip.so (gfx950) in-tree with hipcc.  `python -m vfmseg_amd.csrc.build [--force]`."""
+import glob
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+LIB = os.path.join(HERE, "libvfmseg_hip.so")
+OBJ = os.path.join(HERE, "build")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wno-unused-result",
+         "-I" + os.path.join(ROOT, "include")]
+
+
+def _hipcc():
+    for c in ("/opt/rocm/bin/hipcc", "hipcc"):
+        if os.path.exists(c) or c == "hipcc":
+            return c
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    srcs = sorted(glob.glob(os.path.join(HERE, "*.hip")))
+    hdrs = sorted(glob.glob(os.path.join(HERE, "*.h"))) + [os.path.join(ROOT, "include", "vfmseg_hip.h")]
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = []
+    objs = []
+    for s in srcs:
+        o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            jobs.append((s, o))
+
+    def cc(job):
+        s, o = job
+        cmd = [_hipcc()] + FLAGS + ["-c", s, "-o", o]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s" % (s, r.stderr[-6000:]))
+        if verbose and r.stderr.strip():
+            sys.stderr.write(r.stderr[-2000:])
+        return o
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            list(ex.map(cc, jobs))
+    if jobs or force or _stale(LIB, objs):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

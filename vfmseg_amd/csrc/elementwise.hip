@@ -1,0 +1,327 @@
+// Elementwise / layout kernels (HBM-bound): casts, transposes, masks, GEGLU, mask-token, reductions.
+#include "common.h"
+
+thread_local char g_vfm_err[512] = {0};
+
+extern "C" const char* vfm_last_error(void) { return g_vfm_err; }
+extern "C" int vfm_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------------ cast
+template <typename TI, typename TO>
+__global__ void k_cast(const TI* __restrict__ src, long ld_src, TO* __restrict__ dst, long ld_dst, long rows, long cols,
+                       const float* __restrict__ colscale) {
+  const long cols4 = cols >> 2;
+  const long total = rows * cols4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols4, c = (i - r * cols4) << 2;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = ld_f32(src + r * ld_src + c + j);
+    if (colscale) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] *= colscale[c + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st_f32(dst + r * ld_dst + c + j, v[j]);
+  }
+  // tail columns (cols % 4)
+  const long tail0 = cols4 << 2;
+  const long ntail = cols - tail0;
+  if (ntail) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < rows * ntail; i += (long)gridDim.x * blockDim.x) {
+      const long r = i / ntail, c = tail0 + (i - r * ntail);
+      float v = ld_f32(src + r * ld_src + c);
+      if (colscale) v *= colscale[c];
+      st_f32(dst + r * ld_dst + c, v);
+    }
+  }
+}
+
+extern "C" int vfm_cast(const void* src, int src_dt, long ld_src, void* dst, int dst_dt, long ld_dst, long rows, long cols,
+                        const float* colscale, void* stream) {
+  VFM_CHECK(rows >= 0 && cols >= 0 && ld_src >= cols && ld_dst >= cols, VFM_E_SHAPE, "vfm_cast: bad shape");
+  if (rows == 0 || cols == 0) return VFM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const long total = rows * ((cols + 3) / 4);
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+#define L(TI, TO) hipLaunchKernelGGL((k_cast<TI, TO>), dim3(grid), dim3(256), 0, s, (const TI*)src, ld_src, (TO*)dst, ld_dst, rows, cols, colscale)
+  if (src_dt == VFM_F32 && dst_dt == VFM_F32) L(float, float);
+  else if (src_dt == VFM_F32 && dst_dt == VFM_BF16) L(float, bf16_t);
+  else if (src_dt == VFM_BF16 && dst_dt == VFM_F32) L(bf16_t, float);
+  else if (src_dt == VFM_BF16 && dst_dt == VFM_BF16) L(bf16_t, bf16_t);
+  else VFM_FAIL(VFM_E_INVAL, "vfm_cast: dtype");
+#undef L
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ transpose
+// 64x64 tiles through LDS (+1 pad): coalesced reads along cols, coalesced writes along rows.
+template <typename TI, typename TO>
+__global__ void k_transpose(const TI* __restrict__ src, long ld_src, TO* __restrict__ dst, long ld_dst, long rows, long cols,
+                            long pad_rows) {
+  __shared__ float tile[64][65];
+  const long r0 = (long)blockIdx.y * 64, c0 = (long)blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 256 threads: 4 row-groups
+  for (int i = ty; i < 64; i += 4) {
+    const long r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? ld_f32(src + r * ld_src + c) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const long c = c0 + i, r = r0 + tx;  // dst[c, r]
+    if (c < cols && r < pad_rows) st_f32(dst + c * ld_dst + r, tile[tx][i]);
+  }
+}
+
+extern "C" int vfm_transpose(const void* src, int src_dt, long ld_src, void* dst, int dst_dt, long ld_dst, long rows, long cols,
+                             long pad_rows, void* stream) {
+  VFM_CHECK(pad_rows >= rows && ld_dst >= pad_rows && ld_src >= cols, VFM_E_SHAPE, "vfm_transpose: bad shape");
+  if (cols == 0 || pad_rows == 0) return VFM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(cols, 64), cdiv(pad_rows, 64));
+#define L(TI, TO) hipLaunchKernelGGL((k_transpose<TI, TO>), grid, dim3(256), 0, s, (const TI*)src, ld_src, (TO*)dst, ld_dst, rows, cols, pad_rows)
+  if (src_dt == VFM_F32 && dst_dt == VFM_F32) L(float, float);
+  else if (src_dt == VFM_F32 && dst_dt == VFM_BF16) L(float, bf16_t);
+  else if (src_dt == VFM_BF16 && dst_dt == VFM_F32) L(bf16_t, float);
+  else if (src_dt == VFM_BF16 && dst_dt == VFM_BF16) L(bf16_t, bf16_t);
+  else VFM_FAIL(VFM_E_INVAL, "vfm_transpose: dtype");
+#undef L
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ strided copy
+template <typename TI, typename TO>
+__global__ void k_strided_copy(const TI* __restrict__ src, TO* __restrict__ dst, long n0, long n1, long n2, long n3, long s0,
+                               long s1, long s2, long s3, long d0, long d1, long d2, long d3, int accumulate) {
+  const long total = n0 * n1 * n2 * n3;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long t = i;
+    const long i3 = t % n3; t /= n3;
+    const long i2 = t % n2; t /= n2;
+    const long i1 = t % n1; t /= n1;
+    const float v = ld_f32(src + t * s0 + i1 * s1 + i2 * s2 + i3 * s3);
+    TO* q = dst + t * d0 + i1 * d1 + i2 * d2 + i3 * d3;
+    st_f32(q, accumulate ? ld_f32(q) + v : v);
+  }
+}
+
+extern "C" int vfm_strided_copy(const void* src, int src_dt, void* dst, int dst_dt, long n0, long n1, long n2, long n3,
+                                long s0, long s1, long s2, long s3, long d0, long d1, long d2, long d3, int accumulate,
+                                void* stream) {
+  const long total = n0 * n1 * n2 * n3;
+  if (total == 0) return VFM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+#define L(TI, TO) hipLaunchKernelGGL((k_strided_copy<TI, TO>), dim3(grid), dim3(256), 0, s, (const TI*)src, (TO*)dst, n0, n1, n2, n3, s0, s1, s2, s3, d0, d1, d2, d3, accumulate)
+  if (src_dt == VFM_F32 && dst_dt == VFM_F32) L(float, float);
+  else if (src_dt == VFM_F32 && dst_dt == VFM_BF16) L(float, bf16_t);
+  else if (src_dt == VFM_BF16 && dst_dt == VFM_F32) L(bf16_t, float);
+  else if (src_dt == VFM_BF16 && dst_dt == VFM_BF16) L(bf16_t, bf16_t);
+  else VFM_FAIL(VFM_E_INVAL, "vfm_strided_copy: dtype");
+#undef L
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ axpby / scale
+__global__ void k_axpby(const float* __restrict__ x, float a, float* __restrict__ y, float b, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = (b == 0.f) ? a * x[i] : a * x[i] + b * y[i];
+}
+extern "C" int vfm_axpby(const float* x, float a, float* y, float b, long n, void* stream) {
+  if (n == 0) return VFM_OK;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(k_axpby, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, a, y, b, n);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+__global__ void k_scale_dev(float* __restrict__ y, const float* __restrict__ sc, long n) {
+  const float s = *sc;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] *= s;
+}
+extern "C" int vfm_scale_by_device_scalar(float* y, const float* scalar, long n, void* stream) {
+  if (n == 0) return VFM_OK;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(k_scale_dev, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, scalar, n);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ column sums
+// stage 1: grid (cdiv(cols,64), 64): block (64 cols x 4 row-lanes) sums a strided row slice -> ws[by, c]
+template <typename T>
+__global__ void k_colsum1(const T* __restrict__ x, long ld, long rows, long cols, float* __restrict__ ws) {
+  __shared__ float sh[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long c = (long)blockIdx.x * 64 + tx;
+  float acc = 0.f;
+  if (c < cols)
+    for (long r = (long)blockIdx.y * 4 + ty; r < rows; r += (long)gridDim.y * 4) acc += ld_f32(x + r * ld + c);
+  sh[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && c < cols) ws[(long)blockIdx.y * cols + c] = sh[0][tx] + sh[1][tx] + sh[2][tx] + sh[3][tx];
+}
+__global__ void k_colsum2(const float* __restrict__ ws, long cols, int parts, float* __restrict__ out, int accumulate) {
+  const long c = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float a = 0.f;
+  for (int p = 0; p < parts; ++p) a += ws[(long)p * cols + c];
+  out[c] = accumulate ? out[c] + a : a;
+}
+extern "C" int vfm_colsum(const void* x, int dt, long ld, long rows, long cols, float* out, int accumulate, float* ws,
+                          void* stream) {
+  VFM_CHECK(ld >= cols && ws, VFM_E_SHAPE, "vfm_colsum: bad args");
+  if (cols == 0) return VFM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int parts = 64;
+  dim3 grid(cdiv(cols, 64), parts);
+  if (dt == VFM_F32) hipLaunchKernelGGL(k_colsum1<float>, grid, dim3(256), 0, s, (const float*)x, ld, rows, cols, ws);
+  else if (dt == VFM_BF16) hipLaunchKernelGGL(k_colsum1<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, rows, cols, ws);
+  else VFM_FAIL(VFM_E_INVAL, "vfm_colsum: dtype");
+  hipLaunchKernelGGL(k_colsum2, dim3(cdiv(cols, 256)), dim3(256), 0, s, ws, cols, parts, out, accumulate);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ dropout
+template <typename T>
+__global__ void k_dropout_mask(T* __restrict__ out, long n, float p, float keep_scale, uint64_t seed, uint64_t offset) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float u = (hash_u32(seed, offset + (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
+    st_f32(out + i, u >= p ? keep_scale : 0.f);
+  }
+}
+extern "C" int vfm_dropout_mask(void* out, int dt, long n, float p, uint64_t seed, uint64_t offset, void* stream) {
+  VFM_CHECK(p >= 0.f && p < 1.f, VFM_E_INVAL, "vfm_dropout_mask: p");
+  if (n == 0) return VFM_OK;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  const float ks = 1.0f / (1.0f - p);
+  if (dt == VFM_F32) hipLaunchKernelGGL(k_dropout_mask<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (float*)out, n, p, ks, seed, offset);
+  else if (dt == VFM_BF16) hipLaunchKernelGGL(k_dropout_mask<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (bf16_t*)out, n, p, ks, seed, offset);
+  else VFM_FAIL(VFM_E_INVAL, "vfm_dropout_mask: dtype");
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+__global__ void k_mul_mask(const void* __restrict__ src, int src_dt, long ld_src, const void* __restrict__ mask, int mask_dt,
+                           long mask_ld, long rpg, void* __restrict__ dst, int dst_dt, long ld_dst, long rows, long cols) {
+  const long total = rows * cols;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols, c = i - r * cols;
+    const float m = ld_any(mask, (r / rpg) * mask_ld + c, mask_dt);
+    st_any(dst, r * ld_dst + c, dst_dt, ld_any(src, r * ld_src + c, src_dt) * m);
+  }
+}
+extern "C" int vfm_mul_mask(const void* src, int src_dt, long ld_src, const void* mask, int mask_dt, long mask_ld,
+                            long rows_per_group, void* dst, int dst_dt, long ld_dst, long rows, long cols, void* stream) {
+  VFM_CHECK(rows_per_group >= 1, VFM_E_INVAL, "vfm_mul_mask: rows_per_group");
+  const long total = rows * cols;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_mul_mask, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, src_dt, ld_src, mask, mask_dt, mask_ld,
+                     rows_per_group, dst, dst_dt, ld_dst, rows, cols);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ GEGLU
+__global__ void k_geglu_fwd(const void* __restrict__ h, int h_dt, long ld_h, void* __restrict__ out, int out_dt, long ld_out,
+                            long rows, long C) {
+  const long total = rows * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C, c = i - r * C;
+    const float a = ld_any(h, r * ld_h + c, h_dt), g = ld_any(h, r * ld_h + C + c, h_dt);
+    st_any(out, r * ld_out + c, out_dt, a * gelu_f(g));
+  }
+}
+__global__ void k_geglu_bwd(const void* __restrict__ h, int h_dt, long ld_h, const void* __restrict__ dout, int do_dt,
+                            long ld_do, void* __restrict__ dh, int dh_dt, long ld_dh, long rows, long C) {
+  const long total = rows * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C, c = i - r * C;
+    const float a = ld_any(h, r * ld_h + c, h_dt), g = ld_any(h, r * ld_h + C + c, h_dt);
+    const float d = ld_any(dout, r * ld_do + c, do_dt);
+    st_any(dh, r * ld_dh + c, dh_dt, d * gelu_f(g));
+    st_any(dh, r * ld_dh + C + c, dh_dt, d * a * gelu_grad_f(g));
+  }
+}
+extern "C" int vfm_geglu_fwd(const void* h, int h_dt, long ld_h, void* out, int out_dt, long ld_out, long rows, long C,
+                             void* stream) {
+  const long total = rows * C;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_geglu_fwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, h_dt, ld_h, out, out_dt, ld_out, rows, C);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+extern "C" int vfm_geglu_bwd(const void* h, int h_dt, long ld_h, const void* dout, int do_dt, long ld_do, void* dh, int dh_dt,
+                             long ld_dh, long rows, long C, void* stream) {
+  const long total = rows * C;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_geglu_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, h_dt, ld_h, dout, do_dt, ld_do, dh, dh_dt,
+                     ld_dh, rows, C);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ mask token
+__global__ void k_mask_token_fwd(const float* __restrict__ x, const uint8_t* __restrict__ keep, const float* __restrict__ tok,
+                                 float* __restrict__ out, long rows, long C) {
+  const long total = rows * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C, c = i - r * C;
+    out[i] = keep[r] ? x[i] : tok[c];
+  }
+}
+// dx = keep ? dout : 0 ; dtoken[c] = sum over masked rows of dout[r,c]   (one block per 64 columns, deterministic)
+__global__ void k_mask_token_bwd(const float* __restrict__ dout, const uint8_t* __restrict__ keep, float* __restrict__ dx,
+                                 float* __restrict__ dtok, long rows, long C) {
+  __shared__ float sh[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long c = (long)blockIdx.x * 64 + tx;
+  float acc = 0.f;
+  if (c < C) {
+    for (long r = ty; r < rows; r += 4) {
+      const float d = dout[r * C + c];
+      const bool k = keep[r] != 0;
+      dx[r * C + c] = k ? d : 0.f;
+      if (!k) acc += d;
+    }
+  }
+  sh[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && c < C) dtok[c] = sh[0][tx] + sh[1][tx] + sh[2][tx] + sh[3][tx];
+}
+extern "C" int vfm_mask_token_fwd(const float* x, const uint8_t* keep, const float* token, float* out, long rows, long C,
+                                  void* stream) {
+  const long total = rows * C;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_mask_token_fwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, keep, token, out, rows, C);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+extern "C" int vfm_mask_token_bwd(const float* dout, const uint8_t* keep, float* dx, float* dtoken, long rows, long C,
+                                  void* stream) {
+  if (rows * C == 0) return VFM_OK;
+  hipLaunchKernelGGL(k_mask_token_bwd, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, dout, keep, dx, dtoken, rows, C);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ reduce_sum
+__global__ void k_reduce_sum(const float* __restrict__ x, long n, float scale, float* __restrict__ out) {
+  __shared__ float sh[16];
+  float a = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) a += x[i];
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0) out[0] = a * scale;
+}
+extern "C" int vfm_reduce_sum(const float* x, long n, float scale, float* out, void* stream) {
+  hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, scale, out);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}

@@ -1,0 +1,42 @@
+// Shared GEMM epilogue (see vfm_gemm in include/vfmseg_hip.h for the order of operations).
+#pragma once
+#include "common.h"
+
+struct EpiParams {
+  void* C; int c_dt; long ldc;
+  float alpha;
+  const float* bias; long bias_mod;
+  const float* colscale;
+  const void* residual; int r_dt; long ldr;
+  int ep_mode; const void* aux; int aux_dt; long ld_aux;
+  void* C2; int c2_dt; long ldc2;
+};
+
+static inline EpiParams make_epi(const vfm_gemm_desc* d) {
+  EpiParams e;
+  e.C = d->C; e.c_dt = d->c_dt; e.ldc = d->ldc;
+  e.alpha = d->alpha;
+  e.bias = d->bias; e.bias_mod = d->bias_mod > 0 ? d->bias_mod : d->N;
+  e.colscale = d->colscale;
+  e.residual = d->residual; e.r_dt = d->r_dt; e.ldr = d->ldr;
+  e.ep_mode = d->ep_mode; e.aux = d->aux; e.aux_dt = d->aux_dt; e.ld_aux = d->ld_aux;
+  e.C2 = d->C2; e.c2_dt = d->c2_dt; e.ldc2 = d->ldc2;
+  return e;
+}
+
+// one output element; zoff = batch offset into C (elements)
+__device__ __forceinline__ void epi_store(const EpiParams& e, long zoff, long m, long n, float acc) {
+  float v = e.alpha * acc;
+  if (e.bias) v += e.bias[n % e.bias_mod];
+  if (e.C2) st_any(e.C2, zoff + m * e.ldc2 + n, e.c2_dt, v);
+  switch (e.ep_mode) {
+    case VFM_EP_GELU: v = gelu_f(v); break;
+    case VFM_EP_RELU: v = fmaxf(v, 0.f); break;
+    case VFM_EP_MUL_GELU_GRAD: v *= gelu_grad_f(ld_any(e.aux, m * e.ld_aux + n, e.aux_dt)); break;
+    case VFM_EP_MUL: v *= ld_any(e.aux, m * e.ld_aux + n, e.aux_dt); break;
+    default: break;
+  }
+  if (e.colscale) v *= e.colscale[n];
+  if (e.residual) v += ld_any(e.residual, zoff + m * e.ldr + n, e.r_dt);
+  st_any(e.C, zoff + m * e.ldc + n, e.c_dt, v);
+}

@@ -1,0 +1,456 @@
+// LayerNorm / GroupNorm / BatchNorm, forward and backward, on token-major fp32 maps. HBM-bound.
+#include "common.h"
+
+__device__ __forceinline__ float act_f(float v, int act) {
+  return act == VFM_ACT_GELU ? gelu_f(v) : (act == VFM_ACT_RELU ? fmaxf(v, 0.f) : v);
+}
+__device__ __forceinline__ float act_grad_f(float v, int act) {
+  return act == VFM_ACT_GELU ? gelu_grad_f(v) : (act == VFM_ACT_RELU ? (v > 0.f ? 1.f : 0.f) : 1.f);
+}
+
+// =============================================================================================== LayerNorm
+// one wave per row; C <= 64*32; two-pass statistics in registers (matches torch's accuracy class)
+template <typename TO, int MAXPL>
+__global__ void k_ln_fwd(const float* __restrict__ x, long ld_x, const float* __restrict__ w, const float* __restrict__ b,
+                         float eps, TO* __restrict__ y, long ld_y, float* __restrict__ stats, long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ld_x;
+  float v[MAXPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) {
+    const int c = i * 64 + lane;
+    v[i] = c < C ? xr[c] : 0.f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) {
+    const int c = i * 64 + lane;
+    const float d = c < C ? v[i] - mean : 0.f;
+    q += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+  if (stats && lane == 0) {
+    stats[row * 2] = mean;
+    stats[row * 2 + 1] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) {
+    const int c = i * 64 + lane;
+    if (c < C) st_f32(y + row * ld_y + c, (v[i] - mean) * rstd * w[c] + b[c]);
+  }
+}
+
+extern "C" int vfm_layernorm_fwd(const float* x, long ld_x, const float* w, const float* b, float eps, void* y, int y_dt,
+                                 long ld_y, float* stats, long rows, long C, void* stream) {
+  VFM_CHECK(C > 0 && C <= 2048 && ld_x >= C && ld_y >= C, VFM_E_SHAPE, "vfm_layernorm_fwd: C=%ld unsupported", C);
+  if (rows == 0) return VFM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(rows, 4)), blk(256);
+#define L(TO, PL) hipLaunchKernelGGL((k_ln_fwd<TO, PL>), grid, blk, 0, s, x, ld_x, w, b, eps, (TO*)y, ld_y, stats, rows, (int)C)
+  const int pl = (int)((C + 63) / 64);
+  if (y_dt == VFM_BF16) { if (pl <= 4) L(bf16_t, 4); else if (pl <= 16) L(bf16_t, 16); else L(bf16_t, 32); }
+  else if (y_dt == VFM_F32) { if (pl <= 4) L(float, 4); else if (pl <= 16) L(float, 16); else L(float, 32); }
+  else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_fwd: dtype");
+#undef L
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// backward: one wave per row for dx; per-block partial dw/db in LDS -> ws[block][2][C]
+template <typename TD, int MAXPL>
+__global__ void k_ln_bwd(const TD* __restrict__ dy, long ld_dy, const float* __restrict__ x, long ld_x,
+                         const float* __restrict__ w, const float* __restrict__ stats, float* __restrict__ dx, long ld_dx,
+                         int accumulate_dx, float* __restrict__ ws, long rows, int C) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  float pdw[MAXPL], pdb[MAXPL];
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) pdw[i] = pdb[i] = 0.f;
+  for (long row = (long)blockIdx.x * nw + wv; row < rows; row += (long)gridDim.x * nw) {
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    float g[MAXPL], xh[MAXPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) {
+      const int c = i * 64 + lane;
+      if (c < C) {
+        const float d = ld_f32(dy + row * ld_dy + c);
+        xh[i] = (x[row * ld_x + c] - mean) * rstd;
+        g[i] = d * w[c];
+        s1 += g[i];
+        s2 += g[i] * xh[i];
+        pdw[i] += d * xh[i];
+        pdb[i] += d;
+      } else {
+        g[i] = xh[i] = 0.f;
+      }
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) {
+      const int c = i * 64 + lane;
+      if (c < C) {
+        const float v = rstd * (g[i] - s1 - xh[i] * s2);
+        float* p = dx + row * ld_dx + c;
+        *p = accumulate_dx ? *p + v : v;
+      }
+    }
+  }
+  if (ws) {
+    extern __shared__ float sh[];  // [nw][2][C]
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i) {
+      const int c = i * 64 + lane;
+      if (c < C) {
+        sh[(wv * 2 + 0) * C + c] = pdw[i];
+        sh[(wv * 2 + 1) * C + c] = pdb[i];
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) {
+      const int which = c / C, cc = c - which * C;
+      float a = 0.f;
+      for (int k = 0; k < nw; ++k) a += sh[(k * 2 + which) * C + cc];
+      ws[((long)blockIdx.x * 2 + which) * C + cc] = a;
+    }
+  }
+}
+__global__ void k_ln_bwd_fin(const float* __restrict__ ws, int parts, int C, float* __restrict__ dw, float* __restrict__ db) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int p = 0; p < parts; ++p) {
+    a += ws[((long)p * 2 + 0) * C + c];
+    b += ws[((long)p * 2 + 1) * C + c];
+  }
+  if (dw) dw[c] += a;
+  if (db) db[c] += b;
+}
+
+extern "C" int vfm_layernorm_bwd(const void* dy, int dy_dt, long ld_dy, const float* x, long ld_x, const float* w,
+                                 const float* stats, float* dx, long ld_dx, int accumulate_dx, float* dw, float* db,
+                                 float* ws, long rows, long C, void* stream) {
+  VFM_CHECK(C > 0 && C <= 1024, VFM_E_SHAPE, "vfm_layernorm_bwd: C=%ld unsupported", C);
+  VFM_CHECK(!(dw || db) || ws, VFM_E_INVAL, "vfm_layernorm_bwd: ws required for dw/db");
+  if (rows == 0) return VFM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const bool need_w = (dw || db);
+  const int parts = need_w ? 128 : cdiv(rows, 4);
+  const size_t shm = need_w ? (size_t)4 * 2 * C * sizeof(float) : 0;
+  float* wsp = need_w ? ws : nullptr;
+#define L(TD, PL) hipLaunchKernelGGL((k_ln_bwd<TD, PL>), dim3(parts), dim3(256), shm, s, (const TD*)dy, ld_dy, x, ld_x, w, stats, dx, ld_dx, accumulate_dx, wsp, rows, (int)C)
+  const int pl = (int)((C + 63) / 64);
+  if (dy_dt == VFM_BF16) { if (pl <= 4) L(bf16_t, 4); else L(bf16_t, 16); }
+  else if (dy_dt == VFM_F32) { if (pl <= 4) L(float, 4); else L(float, 16); }
+  else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_bwd: dtype");
+#undef L
+  if (need_w) hipLaunchKernelGGL(k_ln_bwd_fin, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, parts, (int)C, dw, db);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// =============================================================================================== per-channel partial moments
+// Shared by GroupNorm and BatchNorm.  x viewed as [B][P][C]; block (bx: 64-channel strip, by: row chunk, bz: image)
+// writes ws[(b*nchunk + chunk)][2][C] = (sum_rows v1, sum_rows v2).
+// MODE 0: v1 = x, v2 = x*x.  MODE 1 (backward): v1 = dz, v2 = dz*xhat, where dz = dy*act'(xhat*w+b) and
+// (mean,rstd) come per (b, group) [GN: stats[b][g][2]] or per channel [BN: stats[2][C] = (mean, var), G==0].
+template <int MODE, typename TD>
+__global__ void k_chan_moments(const float* __restrict__ x, const TD* __restrict__ dy, const float* __restrict__ w,
+                               const float* __restrict__ bb, const float* __restrict__ stats, int G, float eps, int act,
+                               float* __restrict__ ws, long P, int C, int rows_per_chunk) {
+  __shared__ float sh[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const long b = blockIdx.z;
+  const long r0 = (long)blockIdx.y * rows_per_chunk;
+  long r1 = r0 + rows_per_chunk;
+  if (r1 > P) r1 = P;
+  float a1 = 0.f, a2 = 0.f;
+  if (c < C) {
+    float mean = 0.f, rstd = 1.f, wc = 1.f, bc = 0.f;
+    if (MODE == 1) {
+      if (G > 0) {
+        const int g = c / (C / G);
+        mean = stats[(b * G + g) * 2];
+        rstd = stats[(b * G + g) * 2 + 1];
+      } else {
+        mean = stats[c];
+        rstd = rsqrtf(stats[C + c] + eps);
+      }
+      wc = w[c];
+      bc = bb[c];
+    }
+    const float* xp = x + (b * P) * C + c;
+    for (long r = r0 + ty; r < r1; r += 4) {
+      const float xv = xp[r * C];
+      if (MODE == 0) {
+        a1 += xv;
+        a2 += xv * xv;
+      } else {
+        const float xh = (xv - mean) * rstd;
+        float d = ld_f32(dy + (b * P + r) * C + c);
+        if (act != VFM_ACT_NONE) d *= act_grad_f(xh * wc + bc, act);
+        a1 += d;
+        a2 += d * xh;
+      }
+    }
+  }
+  sh[0][ty][tx] = a1;
+  sh[1][ty][tx] = a2;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    const long slot = b * gridDim.y + blockIdx.y;
+    ws[(slot * 2 + 0) * C + c] = sh[0][0][tx] + sh[0][1][tx] + sh[0][2][tx] + sh[0][3][tx];
+    ws[(slot * 2 + 1) * C + c] = sh[1][0][tx] + sh[1][1][tx] + sh[1][2][tx] + sh[1][3][tx];
+  }
+}
+
+static inline int pick_chunks(long P) {
+  int n = (int)((P + 63) / 64);
+  if (n > 64) n = 64;
+  if (n < 1) n = 1;
+  return n;
+}
+
+// =============================================================================================== GroupNorm
+// finalize forward: one thread per (b,g): combine channel partials in double
+__global__ void k_gn_fin_fwd(const float* __restrict__ ws, int nchunk, int C, int G, long P, float eps,
+                             float* __restrict__ stats, int BG) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BG) return;
+  const int b = i / G, g = i - b * G, cg = C / G;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < nchunk; ++k) {
+    const long slot = (long)b * nchunk + k;
+    for (int j = 0; j < cg; ++j) {
+      s += ws[(slot * 2 + 0) * C + g * cg + j];
+      q += ws[(slot * 2 + 1) * C + g * cg + j];
+    }
+  }
+  const double n = (double)P * cg;
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0) var = 0;
+  stats[i * 2] = (float)mean;
+  stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+template <typename TO>
+__global__ void k_gn_apply(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                           const float* __restrict__ stats, int G, int act, TO* __restrict__ y, long B, long P, int C) {
+  const long total = B * P * C;
+  const int cg = C / G;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long bi = i / ((long)P * C);
+    const int g = c / cg;
+    const float mean = stats[(bi * G + g) * 2], rstd = stats[(bi * G + g) * 2 + 1];
+    st_f32(y + i, act_f((x[i] - mean) * rstd * w[c] + b[c], act));
+  }
+}
+extern "C" int vfm_groupnorm_fwd(const float* x, const float* w, const float* b, float eps, int G, int act, void* y, int y_dt,
+                                 float* stats, float* ws_in, long B, long P, long C, void* stream) {
+  VFM_CHECK(G > 0 && C % G == 0 && ws_in, VFM_E_SHAPE, "vfm_groupnorm_fwd: C %% G / ws");
+  if (B * P * C == 0) return VFM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int nchunk = pick_chunks(P);
+  const int rpc = (int)((P + nchunk - 1) / nchunk);
+  float* ws = ws_in + B * G * 2;
+  hipLaunchKernelGGL((k_chan_moments<0, float>), dim3(cdiv(C, 64), nchunk, (unsigned)B), dim3(256), 0, s, x, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0.f, 0, ws, P, (int)C, rpc);
+  hipLaunchKernelGGL(k_gn_fin_fwd, dim3(cdiv(B * G, 64)), dim3(64), 0, s, ws, nchunk, (int)C, G, P, eps, stats, (int)(B * G));
+  const long total = B * P * C;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  if (y_dt == VFM_BF16) hipLaunchKernelGGL(k_gn_apply<bf16_t>, dim3(grid), dim3(256), 0, s, x, w, b, stats, G, act, (bf16_t*)y, B, P, (int)C);
+  else if (y_dt == VFM_F32) hipLaunchKernelGGL(k_gn_apply<float>, dim3(grid), dim3(256), 0, s, x, w, b, stats, G, act, (float*)y, B, P, (int)C);
+  else VFM_FAIL(VFM_E_INVAL, "vfm_groupnorm_fwd: dtype");
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// backward finalize: per (b,g): s1 = sum_c w*sum dz, s2 = sum_c w*sum dz*xhat -> gs[b][g][2]; and dw/db accumulate
+__global__ void k_gn_fin_bwd(const float* __restrict__ ws, int nchunk, int C, int G, const float* __restrict__ w,
+                             float* __restrict__ gs, int BG) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BG) return;
+  const int b = i / G, g = i - b * G, cg = C / G;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = 0; k < nchunk; ++k) {
+    const long slot = (long)b * nchunk + k;
+    for (int j = 0; j < cg; ++j) {
+      const int c = g * cg + j;
+      s1 += (double)w[c] * ws[(slot * 2 + 0) * C + c];
+      s2 += (double)w[c] * ws[(slot * 2 + 1) * C + c];
+    }
+  }
+  gs[i * 2] = (float)s1;
+  gs[i * 2 + 1] = (float)s2;
+}
+__global__ void k_chan_fin_wb(const float* __restrict__ ws, int slots, int C, float* __restrict__ dw, float* __restrict__ db) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < slots; ++k) {
+    b += ws[((long)k * 2 + 0) * C + c];
+    a += ws[((long)k * 2 + 1) * C + c];
+  }
+  if (dw) dw[c] += a;
+  if (db) db[c] += b;
+}
+template <typename TD>
+__global__ void k_gn_bwd_apply(const TD* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w,
+                               const float* __restrict__ b, const float* __restrict__ stats, const float* __restrict__ gs,
+                               int G, int act, float* __restrict__ dx, long B, long P, int C) {
+  const long total = B * P * C;
+  const int cg = C / G;
+  const float inv_n = 1.0f / ((float)P * cg);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long bi = i / ((long)P * C);
+    const int g = c / cg;
+    const float mean = stats[(bi * G + g) * 2], rstd = stats[(bi * G + g) * 2 + 1];
+    const float xh = (x[i] - mean) * rstd;
+    float d = ld_f32(dy + i);
+    if (act != VFM_ACT_NONE) d *= act_grad_f(xh * w[c] + b[c], act);
+    dx[i] = rstd * (d * w[c] - (gs[(bi * G + g) * 2] + xh * gs[(bi * G + g) * 2 + 1]) * inv_n);
+  }
+}
+extern "C" int vfm_groupnorm_bwd(const void* dy, int dy_dt, const float* x, const float* w, const float* b,
+                                 const float* stats, int G, int act, float* dx, float* dw, float* db, float* ws, long B,
+                                 long P, long C, void* stream) {
+  VFM_CHECK(G > 0 && C % G == 0 && ws, VFM_E_SHAPE, "vfm_groupnorm_bwd: args");
+  if (B * P * C == 0) return VFM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int nchunk = pick_chunks(P);
+  const int rpc = (int)((P + nchunk - 1) / nchunk);
+  float* gs = ws;                 // [B,G,2]
+  float* part = ws + B * G * 2;   // [B*nchunk][2][C]
+  dim3 grid(cdiv(C, 64), nchunk, (unsigned)B);
+  if (dy_dt == VFM_BF16)
+    hipLaunchKernelGGL((k_chan_moments<1, bf16_t>), grid, dim3(256), 0, s, x, (const bf16_t*)dy, w, b, stats, G, 0.f, act, part, P, (int)C, rpc);
+  else if (dy_dt == VFM_F32)
+    hipLaunchKernelGGL((k_chan_moments<1, float>), grid, dim3(256), 0, s, x, (const float*)dy, w, b, stats, G, 0.f, act, part, P, (int)C, rpc);
+  else VFM_FAIL(VFM_E_INVAL, "vfm_groupnorm_bwd: dtype");
+  hipLaunchKernelGGL(k_gn_fin_bwd, dim3(cdiv(B * G, 64)), dim3(64), 0, s, part, nchunk, (int)C, G, w, gs, (int)(B * G));
+  if (dw || db) hipLaunchKernelGGL(k_chan_fin_wb, dim3(cdiv(C, 256)), dim3(256), 0, s, part, (int)(B * nchunk), (int)C, dw, db);
+  const long total = B * P * C;
+  const int g2 = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  if (dy_dt == VFM_BF16) hipLaunchKernelGGL(k_gn_bwd_apply<bf16_t>, dim3(g2), dim3(256), 0, s, (const bf16_t*)dy, x, w, b, stats, gs, G, act, dx, B, P, (int)C);
+  else hipLaunchKernelGGL(k_gn_bwd_apply<float>, dim3(g2), dim3(256), 0, s, (const float*)dy, x, w, b, stats, gs, G, act, dx, B, P, (int)C);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// =============================================================================================== BatchNorm
+__global__ void k_bn_fin_sums(const float* __restrict__ ws, int slots, int C, float* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int k = 0; k < slots; ++k) {
+    a += ws[((long)k * 2 + 0) * C + c];
+    b += ws[((long)k * 2 + 1) * C + c];
+  }
+  sums[c] = (float)a;
+  sums[C + c] = (float)b;
+}
+extern "C" int vfm_bn_moments(const float* x, long rows, long C, float* sums, float* ws, void* stream) {
+  VFM_CHECK(ws && sums, VFM_E_INVAL, "vfm_bn_moments: args");
+  hipStream_t s = (hipStream_t)stream;
+  const int nchunk = pick_chunks(rows);
+  const int rpc = (int)((rows + nchunk - 1) / nchunk);
+  hipLaunchKernelGGL((k_chan_moments<0, float>), dim3(cdiv(C, 64), nchunk, 1), dim3(256), 0, s, x, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0.f, 0, ws, rows, (int)C, rpc);
+  hipLaunchKernelGGL(k_bn_fin_sums, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, nchunk, (int)C, sums);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+// (sum, sumsq, count) -> mean_var (biased) and running-stat update (momentum, unbiased var) as nn.SyncBatchNorm does
+__global__ void k_bn_finalize(const float* __restrict__ sums, float count, float* __restrict__ mean_var,
+                              float* __restrict__ rmean, float* __restrict__ rvar, float momentum, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = (double)sums[c] / count;
+  double var = (double)sums[C + c] / count - mean * mean;
+  if (var < 0) var = 0;
+  mean_var[c] = (float)mean;
+  mean_var[C + c] = (float)var;
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+  if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(var * (count / fmaxf(count - 1.f, 1.f)));
+}
+extern "C" int vfm_bn_finalize(const float* sums, float count, float* mean_var, float* running_mean, float* running_var,
+                               float momentum, long C, void* stream) {
+  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, count, mean_var, running_mean,
+                     running_var, momentum, (int)C);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+template <typename TO>
+__global__ void k_bn_apply(const float* __restrict__ x, const float* __restrict__ mv, const float* __restrict__ w,
+                           const float* __restrict__ b, float eps, int act, TO* __restrict__ y, long rows, int C) {
+  const long total = rows * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    st_f32(y + i, act_f((x[i] - mv[c]) * rsqrtf(mv[C + c] + eps) * w[c] + b[c], act));
+  }
+}
+extern "C" int vfm_bn_apply(const float* x, const float* mean_var, const float* w, const float* b, float eps, int act, void* y,
+                            int y_dt, long rows, long C, void* stream) {
+  const long total = rows * C;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (y_dt == VFM_BF16) hipLaunchKernelGGL(k_bn_apply<bf16_t>, dim3(grid), dim3(256), 0, s, x, mean_var, w, b, eps, act, (bf16_t*)y, rows, (int)C);
+  else if (y_dt == VFM_F32) hipLaunchKernelGGL(k_bn_apply<float>, dim3(grid), dim3(256), 0, s, x, mean_var, w, b, eps, act, (float*)y, rows, (int)C);
+  else VFM_FAIL(VFM_E_INVAL, "vfm_bn_apply: dtype");
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+extern "C" int vfm_bn_bwd_reduce(const void* dy, int dy_dt, const float* x, const float* mean_var, const float* w,
+                                 const float* b, float eps, int act, float* sums_dy, float* ws, long rows, long C,
+                                 void* stream) {
+  VFM_CHECK(ws && sums_dy, VFM_E_INVAL, "vfm_bn_bwd_reduce: args");
+  hipStream_t s = (hipStream_t)stream;
+  const int nchunk = pick_chunks(rows);
+  const int rpc = (int)((rows + nchunk - 1) / nchunk);
+  dim3 grid(cdiv(C, 64), nchunk, 1);
+  if (dy_dt == VFM_BF16)
+    hipLaunchKernelGGL((k_chan_moments<1, bf16_t>), grid, dim3(256), 0, s, x, (const bf16_t*)dy, w, b, mean_var, 0, eps, act, ws, rows, (int)C, rpc);
+  else if (dy_dt == VFM_F32)
+    hipLaunchKernelGGL((k_chan_moments<1, float>), grid, dim3(256), 0, s, x, (const float*)dy, w, b, mean_var, 0, eps, act, ws, rows, (int)C, rpc);
+  else VFM_FAIL(VFM_E_INVAL, "vfm_bn_bwd_reduce: dtype");
+  hipLaunchKernelGGL(k_bn_fin_sums, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, nchunk, (int)C, sums_dy);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+template <typename TD>
+__global__ void k_bn_bwd_apply(const TD* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mv,
+                               const float* __restrict__ w, const float* __restrict__ b, float eps, int act,
+                               const float* __restrict__ sums, float inv_n, float* __restrict__ dx, long rows, int C) {
+  const long total = rows * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const float rstd = rsqrtf(mv[C + c] + eps);
+    const float xh = (x[i] - mv[c]) * rstd;
+    float d = ld_f32(dy + i);
+    if (act != VFM_ACT_NONE) d *= act_grad_f(xh * w[c] + b[c], act);
+    dx[i] = rstd * w[c] * (d - (sums[c] + xh * sums[C + c]) * inv_n);
+  }
+}
+extern "C" int vfm_bn_bwd_apply(const void* dy, int dy_dt, const float* x, const float* mean_var, const float* w,
+                                const float* b, float eps, int act, const float* sums_dy, float total_rows, float* dx,
+                                long rows, long C, void* stream) {
+  const long total = rows * C;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  const float inv_n = 1.0f / total_rows;
+  if (dy_dt == VFM_BF16) hipLaunchKernelGGL(k_bn_bwd_apply<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, x, mean_var, w, b, eps, act, sums_dy, inv_n, dx, rows, (int)C);
+  else if (dy_dt == VFM_F32) hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, x, mean_var, w, b, eps, act, sums_dy, inv_n, dx, rows, (int)C);
+  else VFM_FAIL(VFM_E_INVAL, "vfm_bn_bwd_apply: dtype");
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}

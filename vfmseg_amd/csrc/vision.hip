@@ -1,0 +1,455 @@
+// Image-side kernels: patchify, token assembly, bilinear/nearest resize, fused upsample+CE, sliding-window
+// inference helpers, fused AdamW.  All HBM-bound; fp32 arithmetic follows ATen's formulas so results match the
+// reference's F.interpolate / F.cross_entropy to rounding.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------------- patchify
+template <typename TO>
+__global__ void k_patchify(const float* __restrict__ img, long sb, long sc, long sy, int y0, int x0, int nh, int nw, int P,
+                           TO* __restrict__ out, long ld_out, int B) {
+  const long K = 3L * P * P;
+  const long total = (long)B * nh * nw * K;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / K;
+    const int k = (int)(i - row * K);
+    const int c = k / (P * P), r = k - c * P * P, iy = r / P, ix = r - iy * P;
+    const int px = (int)(row % nw);
+    const long t = row / nw;
+    const int py = (int)(t % nh);
+    const long b = t / nh;
+    st_f32(out + row * ld_out + k, img[b * sb + c * sc + (long)(y0 + py * P + iy) * sy + (x0 + px * P + ix)]);
+  }
+}
+extern "C" int vfm_patchify(const float* img, long stride_b, long stride_c, long stride_y, int y0, int x0, int h, int w, int P,
+                            void* out, int out_dt, long ld_out, int B, void* stream) {
+  VFM_CHECK(P > 0 && h % P == 0 && w % P == 0, VFM_E_SHAPE, "vfm_patchify: %dx%d not a multiple of patch %d", h, w, P);
+  VFM_CHECK(ld_out >= 3L * P * P, VFM_E_SHAPE, "vfm_patchify: ld_out");
+  const int nh = h / P, nw = w / P;
+  const long total = (long)B * nh * nw * 3 * P * P;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (out_dt == VFM_BF16) hipLaunchKernelGGL(k_patchify<bf16_t>, dim3(grid), dim3(256), 0, s, img, stride_b, stride_c, stride_y, y0, x0, nh, nw, P, (bf16_t*)out, ld_out, B);
+  else if (out_dt == VFM_F32) hipLaunchKernelGGL(k_patchify<float>, dim3(grid), dim3(256), 0, s, img, stride_b, stride_c, stride_y, y0, x0, nh, nw, P, (float*)out, ld_out, B);
+  else VFM_FAIL(VFM_E_INVAL, "vfm_patchify: dtype");
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- tokens
+__global__ void k_assemble_tokens(const float* __restrict__ ptok, const float* __restrict__ cls, const float* __restrict__ pos,
+                                  float* __restrict__ x, int B, int np, int C) {
+  const long total = ((long)B * np + B) * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / C;
+    const int c = (int)(i - row * C);
+    if (row < (long)B * np) {
+      const int t = (int)(row % np);
+      x[i] = ptok[i] + pos[(long)(1 + t) * C + c];
+    } else {
+      x[i] = cls[c] + pos[c];
+    }
+  }
+}
+extern "C" int vfm_assemble_tokens(const float* patch_tok, const float* cls, const float* pos, float* x, int B, int np, int C,
+                                   void* stream) {
+  const long total = ((long)B * np + B) * C;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_assemble_tokens, dim3(grid), dim3(256), 0, (hipStream_t)stream, patch_tok, cls, pos, x, B, np, C);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- bilinear
+struct Lerp {
+  int i0, i1;
+  float l0, l1;
+};
+// ATen area_pixel_compute_source_index (align_corners=False, cubic=false) + guard
+__device__ __forceinline__ Lerp lerp_idx(int dst, float scale, int in_size) {
+  float src = scale * (dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  Lerp r;
+  r.i0 = (int)src;
+  if (r.i0 > in_size - 1) r.i0 = in_size - 1;
+  r.i1 = r.i0 + (r.i0 < in_size - 1 ? 1 : 0);
+  r.l1 = src - r.i0;
+  r.l0 = 1.f - r.l1;
+  return r;
+}
+__device__ __forceinline__ int blocked2(int y, int x, int wc) {
+  // 2-level 2x2 blocked pixel order: (y/4, x/4, (y/2)%2, (x/2)%2, y%2, x%2)
+  return ((((y >> 2) * (wc >> 2) + (x >> 2)) * 2 + ((y >> 1) & 1)) * 2 + ((x >> 1) & 1)) * 4 + ((y & 1) << 1) + (x & 1);
+}
+
+__global__ void k_resize_bilinear(const void* __restrict__ in, int in_dt, int in_nchw, int B, int Hi, int Wi, int C,
+                                  long in_ld, void* __restrict__ out, int out_dt, int out_mode, long out_ld, float sy,
+                                  float sx, int y0, int x0, int hc, int wc) {
+  const long total = (long)B * hc * wc * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    int c, x, y;
+    long b;
+    if (out_mode == 1) {  // NCHW: x fastest
+      x = (int)(i % wc);
+      long t = i / wc;
+      y = (int)(t % hc);
+      t /= hc;
+      c = (int)(t % C);
+      b = t / C;
+    } else {  // NHWC: c fastest
+      c = (int)(i % C);
+      long t = i / C;
+      x = (int)(t % wc);
+      t /= wc;
+      y = (int)(t % hc);
+      b = t / hc;
+    }
+    const Lerp ly = lerp_idx(y + y0, sy, Hi), lx = lerp_idx(x + x0, sx, Wi);
+    float v00, v01, v10, v11;
+    if (in_nchw) {
+      const long base = (b * C + c) * (long)Hi * Wi;
+      v00 = ld_any(in, base + (long)ly.i0 * Wi + lx.i0, in_dt);
+      v01 = ld_any(in, base + (long)ly.i0 * Wi + lx.i1, in_dt);
+      v10 = ld_any(in, base + (long)ly.i1 * Wi + lx.i0, in_dt);
+      v11 = ld_any(in, base + (long)ly.i1 * Wi + lx.i1, in_dt);
+    } else {
+      const long base = b * (long)Hi * Wi;
+      v00 = ld_any(in, (base + (long)ly.i0 * Wi + lx.i0) * in_ld + c, in_dt);
+      v01 = ld_any(in, (base + (long)ly.i0 * Wi + lx.i1) * in_ld + c, in_dt);
+      v10 = ld_any(in, (base + (long)ly.i1 * Wi + lx.i0) * in_ld + c, in_dt);
+      v11 = ld_any(in, (base + (long)ly.i1 * Wi + lx.i1) * in_ld + c, in_dt);
+    }
+    const float v = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+    long o;
+    if (out_mode == 1) o = i;
+    else if (out_mode == 0) o = ((b * hc + y) * wc + x) * out_ld + c;
+    else {
+      const int p = blocked2(y, x, wc);
+      o = (b * ((long)hc * wc / 4) + (p >> 2)) * out_ld + (long)(p & 3) * C + c;
+    }
+    st_any(out, o, out_dt, v);
+  }
+}
+extern "C" int vfm_resize_bilinear(const void* in, int in_dt, int in_nchw, int B, int Hi, int Wi, int C, long in_ld_c,
+                                   void* out, int out_dt, int out_mode, long out_ld_c, int Hv, int Wv, int y0, int x0, int hc,
+                                   int wc, void* stream) {
+  VFM_CHECK(Hv > 0 && Wv > 0 && y0 >= 0 && x0 >= 0 && y0 + hc <= Hv && x0 + wc <= Wv, VFM_E_SHAPE, "vfm_resize_bilinear: window");
+  VFM_CHECK(out_mode != 2 || (hc % 4 == 0 && wc % 4 == 0 && out_ld_c >= 4L * C), VFM_E_SHAPE, "vfm_resize_bilinear: blocked mode needs hc,wc %% 4");
+  const long total = (long)B * hc * wc * C;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_resize_bilinear, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, in_dt, in_nchw, B, Hi, Wi, C, in_ld_c,
+                     out, out_dt, out_mode, out_ld_c, (float)Hi / (float)Hv, (float)Wi / (float)Wv, y0, x0, hc, wc);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- labels
+__global__ void k_label_resize(const int64_t* __restrict__ in, int B, int Hi, int Wi, int64_t* __restrict__ out, float sy,
+                               float sx, int y0, int x0, int hc, int wc) {
+  const long total = (long)B * hc * wc;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % wc);
+    long t = i / wc;
+    const int y = (int)(t % hc);
+    const long b = t / hc;
+    int iy = (int)floorf((y + y0) * sy), ix = (int)floorf((x + x0) * sx);  // nearest_neighbor_compute_source_index
+    if (iy > Hi - 1) iy = Hi - 1;
+    if (ix > Wi - 1) ix = Wi - 1;
+    out[i] = in[(b * Hi + iy) * (long)Wi + ix];
+  }
+}
+extern "C" int vfm_label_resize(const int64_t* in, int B, int Hi, int Wi, int64_t* out, int Hv, int Wv, int y0, int x0, int hc,
+                                int wc, void* stream) {
+  VFM_CHECK(y0 >= 0 && x0 >= 0 && y0 + hc <= Hv && x0 + wc <= Wv, VFM_E_SHAPE, "vfm_label_resize: window");
+  const long total = (long)B * hc * wc;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_label_resize, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, B, Hi, Wi, out, (float)Hi / (float)Hv,
+                     (float)Wi / (float)Wv, y0, x0, hc, wc);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- unblock
+__device__ __forceinline__ long blocked_index(int y, int x, int H, int W, int levels) {
+  // levels of 2x2 blocking; coarsest cell is (y >> levels, x >> levels) in raster order
+  long p = (long)(y >> levels) * (W >> levels) + (x >> levels);
+  for (int l = levels - 1; l >= 0; --l) p = (p * 2 + ((y >> l) & 1)) * 2 + ((x >> l) & 1);
+  return p;
+}
+__global__ void k_unblock(const float* __restrict__ xin, float* __restrict__ yout, int B, int H, int W, int C, int levels,
+                          int inverse) {
+  const long total = (long)B * H * W * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int x = (int)(t % W);
+    t /= W;
+    const int y = (int)(t % H);
+    const long b = t / H;
+    const long pb = (b * (long)H * W + blocked_index(y, x, H, W, levels)) * C + c;
+    if (inverse) yout[pb] = xin[i];
+    else yout[i] = xin[pb];
+  }
+}
+extern "C" int vfm_unblock(const float* x, float* y, int B, int H, int W, int C, int levels, int inverse, void* stream) {
+  VFM_CHECK(levels >= 0 && H % (1 << levels) == 0 && W % (1 << levels) == 0, VFM_E_SHAPE, "vfm_unblock: H,W vs levels");
+  const long total = (long)B * H * W * C;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_unblock, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C, levels, inverse);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- upsample + CE
+// One wave per LOW-resolution pixel. It visits every high-resolution pixel whose bilinear footprint touches it,
+// recomputes that pixel's interpolated logits / softmax in registers, and gathers its own share of the gradient
+// (no atomics on floats, bitwise reproducible).  The owner (y0==y && x0==x) also accounts loss / accuracy.
+#define CE_CMAX 32
+__global__ void __launch_bounds__(256) k_upsample_ce(const float* __restrict__ lg, const int64_t* __restrict__ label, int B, int h,
+                                                      int w, int C, int H, int W, int ignore, float sy, float sx,
+                                                      float inv_total, float* __restrict__ loss_parts,
+                                                      int32_t* __restrict__ counts, float* __restrict__ dlogits) {
+  const int lane = threadIdx.x & 63;
+  const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= (long)B * h * w) return;
+  const int x = (int)(pix % w);
+  const long t = pix / w;
+  const int y = (int)(t % h);
+  const long b = t / h;
+  // conservative candidate window in the high-res grid
+  int hy0 = (int)floorf((y - 1 + 0.5f) / sy - 0.5f) - 1, hy1 = (int)ceilf((y + 1 + 0.5f) / sy - 0.5f) + 1;
+  int hx0 = (int)floorf((x - 1 + 0.5f) / sx - 0.5f) - 1, hx1 = (int)ceilf((x + 1 + 0.5f) / sx - 0.5f) + 1;
+  if (y == 0) hy0 = 0;  // clamped sources
+  if (x == 0) hx0 = 0;
+  hy0 = max(hy0, 0), hx0 = max(hx0, 0), hy1 = min(hy1, H - 1), hx1 = min(hx1, W - 1);
+  const int nx = hx1 - hx0 + 1, ny = hy1 - hy0 + 1;
+  float acc[CE_CMAX];
+#pragma unroll
+  for (int c = 0; c < CE_CMAX; ++c) acc[c] = 0.f;
+  float loss = 0.f;
+  int hits = 0, valid = 0;
+  const float* lb = lg + b * (long)h * w * C;
+  for (int i = lane; i < nx * ny; i += 64) {
+    const int hy = hy0 + i / nx, hx = hx0 + i % nx;
+    const Lerp ly = lerp_idx(hy, sy, h), lx = lerp_idx(hx, sx, w);
+    const float wy = (ly.i0 == y ? ly.l0 : 0.f) + (ly.i1 == y ? ly.l1 : 0.f);
+    const float wx = (lx.i0 == x ? lx.l0 : 0.f) + (lx.i1 == x ? lx.l1 : 0.f);
+    const bool member = (ly.i0 == y || ly.i1 == y) && (lx.i0 == x || lx.i1 == x);
+    if (!member) continue;
+    const int64_t lab = label[(b * H + hy) * (long)W + hx];
+    const bool is_valid = lab != ignore;
+    const bool owner = (ly.i0 == y) && (lx.i0 == x);
+    if (!is_valid && !owner) continue;
+    const float* p00 = lb + ((long)ly.i0 * w + lx.i0) * C;
+    const float* p01 = lb + ((long)ly.i0 * w + lx.i1) * C;
+    const float* p10 = lb + ((long)ly.i1 * w + lx.i0) * C;
+    const float* p11 = lb + ((long)ly.i1 * w + lx.i1) * C;
+    float v[CE_CMAX];
+    float m = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int c = 0; c < CE_CMAX; ++c) {
+      if (c < C) {
+        v[c] = ly.l0 * (lx.l0 * p00[c] + lx.l1 * p01[c]) + ly.l1 * (lx.l0 * p10[c] + lx.l1 * p11[c]);
+        if (v[c] > m) {
+          m = v[c];
+          am = c;
+        }
+      } else {
+        v[c] = -INFINITY;
+      }
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < CE_CMAX; ++c)
+      if (c < C) se += __expf(v[c] - m);
+    const float lse = m + __logf(se);
+    if (is_valid) {
+      const float g = wy * wx * inv_total;
+      const float inv_se = 1.f / se;
+#pragma unroll
+      for (int c = 0; c < CE_CMAX; ++c)
+        if (c < C) acc[c] += g * (__expf(v[c] - m) * inv_se - (c == (int)lab ? 1.f : 0.f));
+      if (owner) {
+        float vl = 0.f;
+#pragma unroll
+        for (int c = 0; c < CE_CMAX; ++c)
+          if (c == (int)lab) vl = v[c];
+        loss += lse - vl;
+        valid += 1;
+        hits += (am == (int)lab) ? 1 : 0;
+      }
+    }
+  }
+  if (dlogits) {
+#pragma unroll
+    for (int c = 0; c < CE_CMAX; ++c) {
+      if (c < C) {
+        const float s = wave_sum(acc[c]);
+        if (lane == 0) dlogits[pix * C + c] = s;
+      }
+    }
+  }
+  loss = wave_sum(loss);
+  for (int o = 32; o > 0; o >>= 1) {
+    hits += __shfl_xor(hits, o, 64);
+    valid += __shfl_xor(valid, o, 64);
+  }
+  if (lane == 0) {
+    loss_parts[pix] = loss;
+    if (valid) {
+      atomicAdd(&counts[0], hits);
+      atomicAdd(&counts[1], valid);
+    }
+  }
+}
+extern "C" int vfm_upsample_ce(const float* logits_low, const int64_t* label, int B, int h, int w, int C, int H, int W,
+                               int ignore_index, float* loss_parts, int32_t* counts, float* dlogits, void* stream) {
+  VFM_CHECK(C > 0 && C <= CE_CMAX, VFM_E_SHAPE, "vfm_upsample_ce: C=%d > %d", C, CE_CMAX);
+  VFM_CHECK(H >= h && W >= w, VFM_E_SHAPE, "vfm_upsample_ce: only up-sampling is supported");
+  const long npix = (long)B * h * w;
+  if (npix == 0) return VFM_OK;
+  hipLaunchKernelGGL(k_upsample_ce, dim3(cdiv(npix, 4)), dim3(256), 0, (hipStream_t)stream, logits_low, label, B, h, w, C, H, W,
+                     ignore_index, (float)h / (float)H, (float)w / (float)W, 1.0f / ((float)B * H * W), loss_parts, counts,
+                     dlogits);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- inference helpers
+__global__ void k_conf_gate(const float* __restrict__ lg, int B, int C, int H, int W, int y0, int x0, int hc, int wc, float thr,
+                            int32_t* __restrict__ count) {
+  const long total = (long)B * hc * wc;
+  int local = 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % wc);
+    long t = i / wc;
+    const int y = (int)(t % hc);
+    const long b = t / hc;
+    const float* p = lg + (b * C) * (long)H * W + (long)(y + y0) * W + (x + x0);
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, p[(long)c * H * W]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(p[(long)c * H * W] - m);
+    local += (1.0f / se > thr) ? 1 : 0;  // max softmax = exp(0)/se
+  }
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
+}
+extern "C" int vfm_conf_gate(const float* logits, int B, int C, int H, int W, int y0, int x0, int hc, int wc, float thr,
+                             int32_t* count, void* stream) {
+  VFM_CHECK(y0 >= 0 && x0 >= 0 && y0 + hc <= H && x0 + wc <= W, VFM_E_SHAPE, "vfm_conf_gate: window");
+  const long total = (long)B * hc * wc;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_conf_gate, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, B, C, H, W, y0, x0, hc, wc, thr, count);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+__global__ void k_slide_acc(const float* __restrict__ crop, int crop_nchw, int B, int h, int w, int C, float* __restrict__ preds,
+                            float* __restrict__ count, int H, int W, int y0, int x0, int hc, int wc, float sy, float sx) {
+  const long total = (long)B * C * hc * wc;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % wc);
+    long t = i / wc;
+    const int y = (int)(t % hc);
+    t /= hc;
+    const int c = (int)(t % C);
+    const long b = t / C;
+    const Lerp ly = lerp_idx(y, sy, h), lx = lerp_idx(x, sx, w);
+    float v00, v01, v10, v11;
+    if (crop_nchw) {
+      const float* p = crop + (b * C + c) * (long)h * w;
+      v00 = p[ly.i0 * w + lx.i0], v01 = p[ly.i0 * w + lx.i1], v10 = p[ly.i1 * w + lx.i0], v11 = p[ly.i1 * w + lx.i1];
+    } else {
+      const float* p = crop + b * (long)h * w * C + c;
+      v00 = p[((long)ly.i0 * w + lx.i0) * C], v01 = p[((long)ly.i0 * w + lx.i1) * C];
+      v10 = p[((long)ly.i1 * w + lx.i0) * C], v11 = p[((long)ly.i1 * w + lx.i1) * C];
+    }
+    const float v = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+    preds[((b * C + c) * (long)H + (y + y0)) * W + (x + x0)] += v;
+    if (c == 0) count[(b * (long)H + (y + y0)) * W + (x + x0)] += 1.f;
+  }
+}
+extern "C" int vfm_slide_accumulate(const float* crop, int crop_nchw, int B, int h, int w, int C, float* preds, float* count,
+                                    int H, int W, int y0, int x0, int hc, int wc, void* stream) {
+  VFM_CHECK(y0 >= 0 && x0 >= 0 && y0 + hc <= H && x0 + wc <= W, VFM_E_SHAPE, "vfm_slide_accumulate: window");
+  const long total = (long)B * C * hc * wc;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_slide_acc, dim3(grid), dim3(256), 0, (hipStream_t)stream, crop, crop_nchw, B, h, w, C, preds, count, H, W,
+                     y0, x0, hc, wc, (float)h / (float)hc, (float)w / (float)wc);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+__global__ void k_slide_fin(float* __restrict__ preds, const float* __restrict__ count, uint8_t* __restrict__ am, int B, int C,
+                            int H, int W) {
+  const long total = (long)B * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / ((long)H * W), p = i - b * (long)H * W;
+    const float cnt = count ? count[i] : 1.f;
+    float best = -INFINITY;
+    int bi = 0;
+    for (int c = 0; c < C; ++c) {
+      float* q = preds + (b * C + c) * (long)H * W + p;
+      const float v = count ? *q / cnt : *q;
+      if (count) *q = v;
+      if (v > best) {
+        best = v;
+        bi = c;
+      }
+    }
+    if (am) am[i] = (uint8_t)bi;
+  }
+}
+extern "C" int vfm_slide_finalize(float* preds, const float* count, uint8_t* argmax, int B, int C, int H, int W, void* stream) {
+  const long total = (long)B * H * W;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_slide_fin, dim3(grid), dim3(256), 0, (hipStream_t)stream, preds, count, argmax, B, C, H, W);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- AdamW
+__global__ void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                        const long* __restrict__ seg_start, const float* __restrict__ seg_lr, const float* __restrict__ seg_wd,
+                        int n_seg, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n_seg - 1;  // largest s with seg_start[s] <= i
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (seg_start[mid] <= i) lo = mid;
+      else hi = mid - 1;
+    }
+    const float lr_i = lr * seg_lr[lo], wd = seg_wd[lo];
+    const float gi = g[i] * gscale;
+    float pi = p[i] * (1.f - lr_i * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr_i / bc1) * (mi / denom);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+extern "C" int vfm_adamw(float* p, const float* g, float* m, float* v, long n, const long* seg_start, const float* seg_lr_mult,
+                         const float* seg_wd, int n_seg, float lr, float beta1, float beta2, float eps, int step,
+                         float grad_scale, void* stream) {
+  VFM_CHECK(n_seg >= 1 && step >= 1, VFM_E_INVAL, "vfm_adamw: n_seg/step");
+  if (n == 0) return VFM_OK;
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  const int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  hipLaunchKernelGGL(k_adamw, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, seg_start, seg_lr_mult, seg_wd, n_seg,
+                     lr, beta1, beta2, eps, bc1, bc2s, grad_scale);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}

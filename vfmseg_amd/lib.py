@@ -1,0 +1,148 @@
+"""ctypes binding of libvfmseg_hip.so (include/vfmseg_hip.h).  The product path has NO fallback: if the
+library is missing or a tensor is not on the GPU, the ops raise."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvfmseg_hip.so")
+
+F32, BF16, U8, I64 = 0, 1, 2, 3
+EP_NONE, EP_GELU, EP_RELU, EP_MUL_GELU_GRAD, EP_MUL = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+
+vp, ci, cl, cf, u64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", vp), ("B", vp), ("C", vp),
+        ("in_dt", ci), ("c_dt", ci),
+        ("M", cl), ("N", cl), ("K", cl),
+        ("sa_m", cl), ("sa_k", cl), ("sb_n", cl), ("sb_k", cl), ("ldc", cl),
+        ("alpha", cf),
+        ("bias", vp), ("bias_mod", cl),
+        ("colscale", vp),
+        ("residual", vp), ("r_dt", ci), ("ldr", cl),
+        ("ep_mode", ci), ("aux", vp), ("aux_dt", ci), ("ld_aux", cl),
+        ("C2", vp), ("c2_dt", ci), ("ldc2", cl),
+        ("batch", cl), ("stride_a", cl), ("stride_b", cl), ("stride_c", cl),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("q", vp), ("k", vp), ("v", vp), ("o", vp),
+        ("dt", ci), ("ldq", cl), ("ldk", cl), ("ldv", cl), ("ldo", cl),
+        ("B", ci), ("H", ci), ("d", ci),
+        ("nq_main", ci), ("nq_extra", ci), ("nk_main", ci), ("nk_extra", ci),
+        ("scale", cf),
+        ("lse", vp),
+        ("dout", vp), ("ld_do", cl),
+        ("dq", vp), ("dk", vp), ("dv", vp), ("ld_dq", cl), ("ld_dk", cl), ("ld_dv", cl),
+        ("delta", vp),
+    ]
+
+
+# name -> argtypes (return type is always int); mirrors include/vfmseg_hip.h
+SIGNATURES = {
+    "vfm_cast": [vp, ci, cl, vp, ci, cl, cl, cl, vp, vp],
+    "vfm_transpose": [vp, ci, cl, vp, ci, cl, cl, cl, cl, vp],
+    "vfm_strided_copy": [vp, ci, vp, ci] + [cl] * 12 + [ci, vp],
+    "vfm_axpby": [vp, cf, vp, cf, cl, vp],
+    "vfm_scale_by_device_scalar": [vp, vp, cl, vp],
+    "vfm_colsum": [vp, ci, cl, cl, cl, vp, ci, vp, vp],
+    "vfm_dropout_mask": [vp, ci, cl, cf, u64, u64, vp],
+    "vfm_mul_mask": [vp, ci, cl, vp, ci, cl, cl, vp, ci, cl, cl, cl, vp],
+    "vfm_geglu_fwd": [vp, ci, cl, vp, ci, cl, cl, cl, vp],
+    "vfm_geglu_bwd": [vp, ci, cl, vp, ci, cl, vp, ci, cl, cl, cl, vp],
+    "vfm_mask_token_fwd": [vp, vp, vp, vp, cl, cl, vp],
+    "vfm_mask_token_bwd": [vp, vp, vp, vp, cl, cl, vp],
+    "vfm_layernorm_fwd": [vp, cl, vp, vp, cf, vp, ci, cl, vp, cl, cl, vp],
+    "vfm_layernorm_bwd": [vp, ci, cl, vp, cl, vp, vp, vp, cl, ci, vp, vp, vp, cl, cl, vp],
+    "vfm_groupnorm_fwd": [vp, vp, vp, cf, ci, ci, vp, ci, vp, vp, cl, cl, cl, vp],
+    "vfm_groupnorm_bwd": [vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, cl, cl, cl, vp],
+    "vfm_bn_moments": [vp, cl, cl, vp, vp, vp],
+    "vfm_bn_finalize": [vp, cf, vp, vp, vp, cf, cl, vp],
+    "vfm_bn_apply": [vp, vp, vp, vp, cf, ci, vp, ci, cl, cl, vp],
+    "vfm_bn_bwd_reduce": [vp, ci, vp, vp, vp, vp, cf, ci, vp, vp, cl, cl, vp],
+    "vfm_bn_bwd_apply": [vp, ci, vp, vp, vp, vp, cf, ci, vp, cf, vp, cl, cl, vp],
+    "vfm_gemm": [C.POINTER(GemmDesc), vp],
+    "vfm_attn_fwd": [C.POINTER(AttnDesc), vp],
+    "vfm_attn_bwd": [C.POINTER(AttnDesc), vp],
+    "vfm_patchify": [vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, ci, cl, ci, vp],
+    "vfm_assemble_tokens": [vp, vp, vp, vp, ci, ci, ci, vp],
+    "vfm_resize_bilinear": [vp, ci, ci, ci, ci, ci, ci, cl, vp, ci, ci, cl, ci, ci, ci, ci, ci, ci, vp],
+    "vfm_label_resize": [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, vp],
+    "vfm_unblock": [vp, vp, ci, ci, ci, ci, ci, ci, vp],
+    "vfm_upsample_ce": [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp],
+    "vfm_reduce_sum": [vp, cl, cf, vp, vp],
+    "vfm_conf_gate": [vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, vp],
+    "vfm_slide_accumulate": [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp],
+    "vfm_slide_finalize": [vp, vp, vp, ci, ci, ci, ci, vp],
+    "vfm_adamw": [vp, vp, vp, vp, cl, vp, vp, vp, ci, cf, cf, cf, cf, ci, cf, vp],
+}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once). Raises HipLibraryMissing - there is no CPU fallback in the product path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -m vfmseg_amd.csrc.build` (hipcc --offload-arch=gfx950)")
+    lib = C.CDLL(LIB_PATH)
+    lib.vfm_last_error.restype = C.c_char_p
+    lib.vfm_abi_version.restype = ci
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = ci
+    _lib = lib
+    return lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc, name):
+    if rc != 0:
+        raise HipError(f"{name} failed ({rc}): {load().vfm_last_error().decode()}")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt_of(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.uint8 or t.dtype == torch.bool:
+        return U8
+    if t.dtype == torch.int64:
+        return I64
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def torch_dt(code):
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL). Refuses CPU tensors: the HIP path must be the one that runs."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipError("vfmseg_amd ops need GPU tensors (no CPU fallback in the product path)")
+    return t.data_ptr()

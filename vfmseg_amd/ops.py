@@ -1,0 +1,384 @@
+"""Tensor-level wrappers over the C ABI (one Python function per entry point, no autograd here).
+
+All tensors must live on the GPU; every call is asynchronous on torch's current HIP stream.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, EP_GELU, EP_MUL, EP_MUL_GELU_GRAD, EP_NONE, EP_RELU, F32  # noqa: F401
+
+_ws_cache = {}
+
+
+def workspace(nfloats, device, tag="default"):
+    """Grow-only fp32 scratch per (device, tag); kernels never allocate."""
+    key = (str(device), tag)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nfloats:
+        t = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)
+        _ws_cache[key] = t
+    return t
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D view"
+    return t.stride(0)
+
+
+def cast(src, dst, colscale=None):
+    """dst[r,c] = src[r,c] * colscale[c]; src/dst 2-D row-major views (may be column slices)."""
+    lib = L.load()
+    L.check(lib.vfm_cast(L.ptr(src), L.dt_of(src), _ld(src), L.ptr(dst), L.dt_of(dst), _ld(dst), src.shape[0], src.shape[1],
+                         L.ptr(colscale), L.stream()), "vfm_cast")
+    return dst
+
+
+def transpose(src, dst, pad_rows=None):
+    """dst[c, r] = src[r, c]; dst [cols, >=pad_rows]; columns rows..pad_rows-1 zero-filled."""
+    lib = L.load()
+    rows, cols = src.shape
+    pad_rows = rows if pad_rows is None else pad_rows
+    L.check(lib.vfm_transpose(L.ptr(src), L.dt_of(src), _ld(src), L.ptr(dst), L.dt_of(dst), _ld(dst), rows, cols, pad_rows,
+                              L.stream()), "vfm_transpose")
+    return dst
+
+
+def strided_copy(src, dst, shape, sstr, dstr, accumulate=False):
+    lib = L.load()
+    n = list(shape) + [1] * (4 - len(shape))
+    s = list(sstr) + [0] * (4 - len(sstr))
+    d = list(dstr) + [0] * (4 - len(dstr))
+    # leading singleton padding must be at the FRONT so that the fastest index stays last
+    k = 4 - len(shape)
+    n = [1] * k + list(shape)
+    s = [0] * k + list(sstr)
+    d = [0] * k + list(dstr)
+    L.check(lib.vfm_strided_copy(L.ptr(src), L.dt_of(src), L.ptr(dst), L.dt_of(dst), *n, *s, *d, int(accumulate), L.stream()),
+            "vfm_strided_copy")
+    return dst
+
+
+def permute_copy(src, perm, dst):
+    """dst (contiguous, any dtype) = src.permute(perm) ; src may be any strided <=4-D tensor."""
+    v = src.permute(*perm)
+    strided_copy(src, dst, list(v.shape), list(v.stride()), list(torch.empty(v.shape, device="meta").stride()))
+    return dst
+
+
+def axpby(x, a, y, b):
+    lib = L.load()
+    assert x.is_contiguous() and y.is_contiguous() and x.dtype == y.dtype == torch.float32 and x.numel() == y.numel()
+    L.check(lib.vfm_axpby(L.ptr(x), float(a), L.ptr(y), float(b), x.numel(), L.stream()), "vfm_axpby")
+    return y
+
+
+def scale_by_device_scalar(y, scalar):
+    lib = L.load()
+    assert y.is_contiguous() and y.dtype == torch.float32
+    L.check(lib.vfm_scale_by_device_scalar(L.ptr(y), L.ptr(scalar), y.numel(), L.stream()), "vfm_scale_by_device_scalar")
+    return y
+
+
+def colsum(x, out, accumulate=False):
+    lib = L.load()
+    rows, cols = x.shape
+    ws = workspace(64 * cols, x.device)
+    L.check(lib.vfm_colsum(L.ptr(x), L.dt_of(x), _ld(x), rows, cols, L.ptr(out), int(accumulate), L.ptr(ws), L.stream()),
+            "vfm_colsum")
+    return out
+
+
+def dropout_mask(out, p, seed, offset=0):
+    lib = L.load()
+    assert out.is_contiguous()
+    L.check(lib.vfm_dropout_mask(L.ptr(out), L.dt_of(out), out.numel(), float(p), int(seed), int(offset), L.stream()),
+            "vfm_dropout_mask")
+    return out
+
+
+def mul_mask(src, mask, dst, rows_per_group=1):
+    lib = L.load()
+    L.check(lib.vfm_mul_mask(L.ptr(src), L.dt_of(src), _ld(src), L.ptr(mask), L.dt_of(mask), _ld(mask), rows_per_group,
+                             L.ptr(dst), L.dt_of(dst), _ld(dst), src.shape[0], src.shape[1], L.stream()), "vfm_mul_mask")
+    return dst
+
+
+def geglu_fwd(h, out):
+    lib = L.load()
+    rows, c2 = h.shape
+    L.check(lib.vfm_geglu_fwd(L.ptr(h), L.dt_of(h), _ld(h), L.ptr(out), L.dt_of(out), _ld(out), rows, c2 // 2, L.stream()),
+            "vfm_geglu_fwd")
+    return out
+
+
+def geglu_bwd(h, dout, dh):
+    lib = L.load()
+    rows, c2 = h.shape
+    L.check(lib.vfm_geglu_bwd(L.ptr(h), L.dt_of(h), _ld(h), L.ptr(dout), L.dt_of(dout), _ld(dout), L.ptr(dh), L.dt_of(dh),
+                              _ld(dh), rows, c2 // 2, L.stream()), "vfm_geglu_bwd")
+    return dh
+
+
+def mask_token_fwd(x, keep, token, out):
+    lib = L.load()
+    L.check(lib.vfm_mask_token_fwd(L.ptr(x), L.ptr(keep), L.ptr(token), L.ptr(out), x.shape[0], x.shape[1], L.stream()),
+            "vfm_mask_token_fwd")
+    return out
+
+
+def mask_token_bwd(dout, keep, dx, dtoken):
+    lib = L.load()
+    L.check(lib.vfm_mask_token_bwd(L.ptr(dout), L.ptr(keep), L.ptr(dx), L.ptr(dtoken), dout.shape[0], dout.shape[1],
+                                   L.stream()), "vfm_mask_token_bwd")
+
+
+def layernorm_fwd(x, w, b, eps, y, stats=None):
+    lib = L.load()
+    rows, c = x.shape
+    L.check(lib.vfm_layernorm_fwd(L.ptr(x), _ld(x), L.ptr(w), L.ptr(b), float(eps), L.ptr(y), L.dt_of(y), _ld(y),
+                                  L.ptr(stats), rows, c, L.stream()), "vfm_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(dy, x, w, stats, dx, accumulate_dx=False, dw=None, db=None):
+    lib = L.load()
+    rows, c = x.shape
+    ws = workspace(2 * 128 * c, x.device) if (dw is not None or db is not None) else None
+    L.check(lib.vfm_layernorm_bwd(L.ptr(dy), L.dt_of(dy), _ld(dy), L.ptr(x), _ld(x), L.ptr(w), L.ptr(stats), L.ptr(dx),
+                                  _ld(dx), int(accumulate_dx), L.ptr(dw), L.ptr(db), L.ptr(ws), rows, c, L.stream()),
+            "vfm_layernorm_bwd")
+    return dx
+
+
+def groupnorm_fwd(x, w, b, eps, groups, act, y, stats, B, P):
+    """x fp32 [B*P, C] contiguous; stats fp32 [B, G, 2]."""
+    lib = L.load()
+    c = x.shape[1]
+    ws = workspace(B * groups * 2 + B * 64 * 2 * c, x.device)
+    L.check(lib.vfm_groupnorm_fwd(L.ptr(x), L.ptr(w), L.ptr(b), float(eps), groups, act, L.ptr(y), L.dt_of(y), L.ptr(stats),
+                                  L.ptr(ws), B, P, c, L.stream()), "vfm_groupnorm_fwd")
+    return y
+
+
+def groupnorm_bwd(dy, x, w, b, stats, groups, act, dx, dw, db, B, P):
+    lib = L.load()
+    c = x.shape[1]
+    ws = workspace(B * groups * 2 + B * 64 * 2 * c, x.device)
+    L.check(lib.vfm_groupnorm_bwd(L.ptr(dy), L.dt_of(dy), L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(stats), groups, act, L.ptr(dx),
+                                  L.ptr(dw), L.ptr(db), L.ptr(ws), B, P, c, L.stream()), "vfm_groupnorm_bwd")
+    return dx
+
+
+def bn_moments(x, sums):
+    lib = L.load()
+    rows, c = x.shape
+    ws = workspace(64 * 2 * c, x.device)
+    L.check(lib.vfm_bn_moments(L.ptr(x), rows, c, L.ptr(sums), L.ptr(ws), L.stream()), "vfm_bn_moments")
+    return sums
+
+
+def bn_finalize(sums, count, mean_var, running_mean=None, running_var=None, momentum=0.1):
+    lib = L.load()
+    L.check(lib.vfm_bn_finalize(L.ptr(sums), float(count), L.ptr(mean_var), L.ptr(running_mean), L.ptr(running_var),
+                                float(momentum), sums.shape[1], L.stream()), "vfm_bn_finalize")
+    return mean_var
+
+
+def bn_apply(x, mean_var, w, b, eps, act, y):
+    lib = L.load()
+    rows, c = x.shape
+    L.check(lib.vfm_bn_apply(L.ptr(x), L.ptr(mean_var), L.ptr(w), L.ptr(b), float(eps), act, L.ptr(y), L.dt_of(y), rows, c,
+                             L.stream()), "vfm_bn_apply")
+    return y
+
+
+def bn_bwd_reduce(dy, x, mean_var, w, b, eps, act, sums_dy):
+    lib = L.load()
+    rows, c = x.shape
+    ws = workspace(64 * 2 * c, x.device)
+    L.check(lib.vfm_bn_bwd_reduce(L.ptr(dy), L.dt_of(dy), L.ptr(x), L.ptr(mean_var), L.ptr(w), L.ptr(b), float(eps), act,
+                                  L.ptr(sums_dy), L.ptr(ws), rows, c, L.stream()), "vfm_bn_bwd_reduce")
+    return sums_dy
+
+
+def bn_bwd_apply(dy, x, mean_var, w, b, eps, act, sums_dy, total_rows, dx):
+    lib = L.load()
+    rows, c = x.shape
+    L.check(lib.vfm_bn_bwd_apply(L.ptr(dy), L.dt_of(dy), L.ptr(x), L.ptr(mean_var), L.ptr(w), L.ptr(b), float(eps), act,
+                                 L.ptr(sums_dy), float(total_rows), L.ptr(dx), rows, c, L.stream()), "vfm_bn_bwd_apply")
+    return dx
+
+
+def gemm(a, b, c, *, alpha=1.0, bias=None, bias_mod=0, colscale=None, residual=None, ep_mode=EP_NONE, aux=None, c2=None,
+         trans_a=False, trans_b=False):
+    """c[M,N] = epilogue(alpha * A @ B^T).  a: [M,K] (or [K,M] if trans_a), b: [N,K] (or [K,N] if trans_b); 2-D views
+    (or 3-D batched with equal batch).  bf16 inputs require K-contiguous operands with K % 64 == 0."""
+    lib = L.load()
+    d = L.GemmDesc()
+    batched = a.dim() == 3
+    a2 = a[0] if batched else a
+    b2 = b[0] if batched else b
+    c2d = c[0] if batched else c
+    if trans_a:
+        K, M = a2.shape
+        d.sa_m, d.sa_k = a2.stride(1), a2.stride(0)
+    else:
+        M, K = a2.shape
+        d.sa_m, d.sa_k = a2.stride(0), a2.stride(1)
+    if trans_b:
+        Kb, N = b2.shape
+        d.sb_n, d.sb_k = b2.stride(1), b2.stride(0)
+    else:
+        N, Kb = b2.shape
+        d.sb_n, d.sb_k = b2.stride(0), b2.stride(1)
+    assert K == Kb, f"gemm K mismatch {K} vs {Kb}"
+    assert a.dtype == b.dtype
+    assert c2d.shape[0] == M and c2d.shape[1] == N and c2d.stride(1) == 1
+    d.A, d.B, d.C = L.ptr(a), L.ptr(b), L.ptr(c)
+    d.in_dt, d.c_dt = L.dt_of(a), L.dt_of(c)
+    d.M, d.N, d.K = M, N, K
+    d.ldc = c2d.stride(0)
+    d.alpha = float(alpha)
+    d.bias, d.bias_mod = L.ptr(bias), int(bias_mod)
+    d.colscale = L.ptr(colscale)
+    if residual is not None:
+        r2 = residual[0] if batched else residual
+        d.residual, d.r_dt, d.ldr = L.ptr(residual), L.dt_of(residual), r2.stride(0)
+    d.ep_mode = ep_mode
+    if aux is not None:
+        d.aux, d.aux_dt, d.ld_aux = L.ptr(aux), L.dt_of(aux), aux.stride(0)
+    if c2 is not None:
+        d.C2, d.c2_dt, d.ldc2 = L.ptr(c2), L.dt_of(c2), c2.stride(0)
+    if batched:
+        d.batch, d.stride_a, d.stride_b, d.stride_c = a.shape[0], a.stride(0), b.stride(0), c.stride(0)
+    else:
+        d.batch = 1
+    L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
+    return c
+
+
+def _attn_desc(q, k, v, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, lse):
+    a = L.AttnDesc()
+    a.q, a.k, a.v, a.o = L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o)
+    a.dt = L.dt_of(q)
+    a.ldq, a.ldk, a.ldv, a.ldo = q.stride(0), k.stride(0), v.stride(0), o.stride(0)
+    a.B, a.H, a.d = B, H, d
+    a.nq_main, a.nq_extra, a.nk_main, a.nk_extra = nq_main, nq_extra, nk_main, nk_extra
+    a.scale = float(scale)
+    a.lse = L.ptr(lse)
+    return a
+
+
+def attn_fwd(q, k, v, o, lse, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale):
+    """q,k,v,o: 2-D row-major views [rows, >=H*d] (column slices of a packed qkv buffer are fine)."""
+    lib = L.load()
+    a = _attn_desc(q, k, v, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, lse)
+    L.check(lib.vfm_attn_fwd(C.byref(a), L.stream()), "vfm_attn_fwd")
+    return o
+
+
+def attn_bwd(q, k, v, o, lse, dout, dq, dk, dv, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale):
+    lib = L.load()
+    a = _attn_desc(q, k, v, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, lse)
+    a.dout, a.ld_do = L.ptr(dout), dout.stride(0)
+    a.dq, a.dk, a.dv = L.ptr(dq), L.ptr(dk), L.ptr(dv)
+    a.ld_dq, a.ld_dk, a.ld_dv = dq.stride(0), dk.stride(0), dv.stride(0)
+    delta = workspace(B * H * (nq_main + nq_extra), q.device, "attn_delta")
+    a.delta = L.ptr(delta)
+    L.check(lib.vfm_attn_bwd(C.byref(a), L.stream()), "vfm_attn_bwd")
+
+
+def patchify(img, out, box=None, patch=16):
+    """img fp32 [B,3,H,W] (any strides with unit x-stride); box=(y0,y1,x0,x1) crop; out [B*nh*nw, >=3*P*P]."""
+    lib = L.load()
+    B, _, H, W = img.shape
+    y0, y1, x0, x1 = box if box is not None else (0, H, 0, W)
+    assert img.stride(3) == 1 and img.dtype == torch.float32
+    L.check(lib.vfm_patchify(L.ptr(img), img.stride(0), img.stride(1), img.stride(2), y0, x0, y1 - y0, x1 - x0, patch,
+                             L.ptr(out), L.dt_of(out), _ld(out), B, L.stream()), "vfm_patchify")
+    return out
+
+
+def assemble_tokens(patch_tok, cls, pos, x, B, np_, C_):
+    lib = L.load()
+    L.check(lib.vfm_assemble_tokens(L.ptr(patch_tok), L.ptr(cls), L.ptr(pos), L.ptr(x), B, np_, C_, L.stream()),
+            "vfm_assemble_tokens")
+    return x
+
+
+def resize_bilinear(inp, in_nchw, B, Hi, Wi, Cc, out, out_mode, virt, window=None, in_ld=None, out_ld=None):
+    """virt=(Hv,Wv) virtual output size; window=(y0,x0,hc,wc) (default: whole). out_mode 0 NHWC, 1 NCHW, 2 blocked."""
+    lib = L.load()
+    Hv, Wv = virt
+    y0, x0, hc, wc = window if window is not None else (0, 0, Hv, Wv)
+    in_ld = Cc if in_ld is None else in_ld
+    out_ld = Cc if out_ld is None else out_ld
+    L.check(lib.vfm_resize_bilinear(L.ptr(inp), L.dt_of(inp), int(in_nchw), B, Hi, Wi, Cc, in_ld, L.ptr(out), L.dt_of(out),
+                                    out_mode, out_ld, Hv, Wv, y0, x0, hc, wc, L.stream()), "vfm_resize_bilinear")
+    return out
+
+
+def label_resize(lab, out, virt, window=None):
+    lib = L.load()
+    B, Hi, Wi = lab.shape
+    Hv, Wv = virt
+    y0, x0, hc, wc = window if window is not None else (0, 0, Hv, Wv)
+    assert lab.dtype == torch.int64 and lab.is_contiguous() and out.is_contiguous()
+    L.check(lib.vfm_label_resize(L.ptr(lab), B, Hi, Wi, L.ptr(out), Hv, Wv, y0, x0, hc, wc, L.stream()), "vfm_label_resize")
+    return out
+
+
+def unblock(x, y, B, H, W, Cc, levels, inverse=False):
+    lib = L.load()
+    L.check(lib.vfm_unblock(L.ptr(x), L.ptr(y), B, H, W, Cc, levels, int(inverse), L.stream()), "vfm_unblock")
+    return y
+
+
+def upsample_ce(logits_low, label, ignore_index=255, need_grad=True):
+    """logits_low fp32 [B,h,w,C] NHWC; label int64 [B,H,W]. Returns (loss[1], counts int32[2], dlogits or None)."""
+    lib = L.load()
+    B, h, w, Cc = logits_low.shape
+    _, H, W = label.shape
+    dev = logits_low.device
+    parts = torch.empty(B * h * w, dtype=torch.float32, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    dl = torch.empty_like(logits_low) if need_grad else None
+    assert logits_low.is_contiguous() and label.is_contiguous() and label.dtype == torch.int64
+    L.check(lib.vfm_upsample_ce(L.ptr(logits_low), L.ptr(label), B, h, w, Cc, H, W, ignore_index, L.ptr(parts), L.ptr(counts),
+                                L.ptr(dl), L.stream()), "vfm_upsample_ce")
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    L.check(lib.vfm_reduce_sum(L.ptr(parts), parts.numel(), 1.0 / (B * H * W), L.ptr(loss), L.stream()), "vfm_reduce_sum")
+    return loss, counts, dl
+
+
+def conf_gate_count(logits_nchw, window, thr, count):
+    lib = L.load()
+    B, Cc, H, W = logits_nchw.shape
+    y0, x0, hc, wc = window
+    L.check(lib.vfm_conf_gate(L.ptr(logits_nchw), B, Cc, H, W, y0, x0, hc, wc, float(thr), L.ptr(count), L.stream()),
+            "vfm_conf_gate")
+    return count
+
+
+def slide_accumulate(crop, crop_nchw, B, h, w, Cc, preds, count, window):
+    lib = L.load()
+    _, _, H, W = preds.shape
+    y0, x0, hc, wc = window
+    L.check(lib.vfm_slide_accumulate(L.ptr(crop), int(crop_nchw), B, h, w, Cc, L.ptr(preds), L.ptr(count), H, W, y0, x0, hc, wc,
+                                     L.stream()), "vfm_slide_accumulate")
+
+
+def slide_finalize(preds, count, argmax=None):
+    lib = L.load()
+    B, Cc, H, W = preds.shape
+    L.check(lib.vfm_slide_finalize(L.ptr(preds), L.ptr(count), L.ptr(argmax), B, Cc, H, W, L.stream()), "vfm_slide_finalize")
+    return preds
+
+
+def adamw(p, g, m, v, seg_start, seg_lr_mult, seg_wd, lr, betas, eps, step, grad_scale=1.0):
+    lib = L.load()
+    L.check(lib.vfm_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(seg_start), L.ptr(seg_lr_mult),
+                          L.ptr(seg_wd), seg_start.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), int(step),
+                          float(grad_scale), L.stream()), "vfm_adamw")
