@@ -1,0 +1,74 @@
+"""DINOv2 + LoRA backbone on the HIP path vs the CPU oracle: taps and LoRA gradients (f32 parity mode and bf16)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import torch_ref as R  # noqa: E402
+from tests.helpers import full_state_dict, rel_err  # noqa: E402
+from vfmseg_amd import presets  # noqa: E402
+from vfmseg_amd.precision import set_compute_dtype  # noqa: E402
+from vfmseg_amd.registry import MODELS  # noqa: E402
+from vfmseg_amd.synth import synth_image  # noqa: E402
+import vfmseg_amd.backbones  # noqa: E402,F401
+
+DEPTH, OUT = 4, (0, 1, 2, 3)
+
+
+def _build(sd):
+    cfg = dict(type="LoRABackbone", backbone=dict(presets.dinov2_backbone(depth=DEPTH), out_indices=list(OUT)),
+               Lora_config=presets.lora_cfg(dropout=0.0))
+    m = MODELS.build(cfg)
+    bsd = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
+    missing, unexpected = m.load_state_dict(bsd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)
+    return m.cuda()
+
+
+@pytest.mark.parametrize("mode,tol,gtol", [("f32", 2e-4, 2e-3), ("bf16", 3e-2, 8e-2)])
+def test_backbone_taps_and_lora_grads(mode, tol, gtol):
+    set_compute_dtype(mode)
+    try:
+        sd = full_state_dict(depth=DEPTH)
+        m = _build(sd)
+        img = synth_image(2, 512, seed=21)
+        # oracle (CPU fp32) with autograd on the LoRA factors
+        sdo = dict(sd)
+        tk = [k for k in sd if "lora_" in k]
+        for k in tk:
+            sdo[k] = sd[k].clone().requires_grad_(True)
+        taps = R.dinov2_forward(sdo, img, depth=DEPTH, out_indices=OUT)
+        gen = torch.Generator().manual_seed(5)
+        dts = [torch.randn(t.shape, generator=gen) for t in taps]
+        loss = sum((t * d).sum() for t, d in zip(taps, dts))
+        og = dict(zip(tk, torch.autograd.grad(loss, [sdo[k] for k in tk])))
+        # HIP
+        xcat, (hp, wp) = m.forward_tokens([(img.cuda(), None)])
+        assert (hp, wp) == (32, 32) and xcat.shape == (2 * 1024, 4 * 1024)
+        v = xcat.float().view(2, 32, 32, 4, 1024)
+        for i, t in enumerate(taps):
+            got = v[:, :, :, i].permute(0, 3, 1, 2).cpu()
+            assert rel_err(got, t.detach()) < tol, (i, rel_err(got, t.detach()))
+        dx = torch.stack([d.permute(0, 2, 3, 1) for d in dts], dim=3).reshape(2 * 1024, 4 * 1024).to(xcat.dtype).cuda()
+        xcat.backward(dx)
+        for n, p in m.named_parameters():
+            if "lora_" in n:
+                e = rel_err(p.grad.cpu(), og["backbone." + n])
+                assert e < gtol, (n, e)
+    finally:
+        set_compute_dtype("bf16")
+
+
+def test_api_views_match_reference_layout():
+    set_compute_dtype("f32")
+    try:
+        sd = full_state_dict(depth=DEPTH)
+        m = _build(sd).eval()
+        img = synth_image(1, 512, seed=22)
+        with torch.no_grad():
+            feats = m(img.cuda())
+            ref = R.dinov2_forward(sd, img, depth=DEPTH, out_indices=OUT)
+        assert len(feats) == 4 and tuple(feats[0].shape) == (1, 1024, 32, 32)
+        assert rel_err(feats[3].cpu(), ref[3]) < 2e-4
+    finally:
+        set_compute_dtype("bf16")

@@ -1,0 +1,502 @@
+"""ViT backbones + LoRA wrapper on the HIP kernels (reference: rein/models/backbones/{dino_v2,lora_backbone}.py).
+
+The nn.Modules below are *parameter containers* that reproduce the reference's state_dict key scheme
+ and registry names; the arithmetic lives in `DinoEngine`, which drives the C-ABI kernels:
+
+  token layout  : rows [0, n*Np) = patch tokens (image-major), rows [n*Np, n*Np+n) = the [cls] tokens.  GEMM row
+                  tiles therefore never straddle an odd 1025-token boundary and feature taps are plain row slices.
+  residual      : fp32 [M, D]; GEMM operands in the compute dtype (bf16 | f32), fp32 accumulation.
+  LoRA          : fused into the QKV projection by K-concatenation: [LN(x) | s*drop(LN(x)) A^T] @ [W | B]^T, so
+                  the rank-32 path costs no extra pass over the activations (peft lora.Linear semantics,
+                  lora_backbone.py:16-23; scaling alpha/r).
+  backward      : hand-written (frozen base => only activation gradients + LoRA A/B weight gradients).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .precision import compute_dtype
+from .registry import MODELS
+
+R_PAD = 64  # LoRA rank padded to one MFMA K-block
+
+
+# ------------------------------------------------------------------------------------------ parameter containers
+class _Lin(nn.Module):
+    def __init__(self, i, o, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = i, o
+        self.weight = nn.Parameter(torch.empty(o, i))
+        self.bias = nn.Parameter(torch.zeros(o)) if bias else None
+        nn.init.trunc_normal_(self.weight, std=0.02)
+
+
+class LoraLinear(nn.Module):
+    """peft 0.10 lora.Linear key layout: base_layer.{weight,bias}, lora_A.default.weight, lora_B.default.weight."""
+
+    def __init__(self, base, r, alpha, dropout):
+        super().__init__()
+        self.base_layer = base
+        self.r, self.scaling, self.p = r, alpha / r, dropout
+        a, b = _Lin(base.in_features, r, False), _Lin(r, base.out_features, False)
+        nn.init.kaiming_uniform_(a.weight, a=math.sqrt(5))
+        nn.init.zeros_(b.weight)
+        self.lora_A = nn.ModuleDict({"default": a})
+        self.lora_B = nn.ModuleDict({"default": b})
+
+
+class _Attn(nn.Module):
+    def __init__(self, dim, heads, qkv_bias, proj_bias):
+        super().__init__()
+        self.num_heads = heads
+        self.qkv = _Lin(dim, dim * 3, qkv_bias)
+        self.proj = _Lin(dim, dim, proj_bias)
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden, bias):
+        super().__init__()
+        self.fc1 = _Lin(dim, hidden, bias)
+        self.fc2 = _Lin(hidden, dim, bias)
+
+
+class _LayerScale(nn.Module):
+    def __init__(self, dim, init):
+        super().__init__()
+        self.gamma = nn.Parameter(init * torch.ones(dim))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, heads, mlp_ratio, qkv_bias, proj_bias, ffn_bias, init_values):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attn(dim, heads, qkv_bias, proj_bias)
+        self.ls1 = _LayerScale(dim, init_values if init_values else 1.0)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio), ffn_bias)
+        self.ls2 = _LayerScale(dim, init_values if init_values else 1.0)
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, patch, in_chans, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, dim, patch, patch)
+
+
+@MODELS.register_module()
+class DinoVisionTransformer(nn.Module):
+    """Same ctor kwargs / state_dict keys as rein/models/backbones/dino_v2.py:55-182 (ffn_layer='mlp' only)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0,
+                 qkv_bias=True, ffn_bias=True, proj_bias=True, drop_path_rate=0.0, drop_path_uniform=False,
+                 init_values=None, ffn_layer="mlp", block_chunks=1, out_indices=(7, 11, 15, 23), init_cfg=None,
+                 resize_feat=False, **kw):
+        super().__init__()
+        if ffn_layer != "mlp":
+            raise NotImplementedError("only ffn_layer='mlp' (the reference's LoRA configs) is on the HIP path")
+        if block_chunks not in (0, None):
+            raise NotImplementedError("block_chunks must be 0 (all reference LoRA configs, lora_dinov2_ms_masked.py:27)")
+        self.embed_dim = self.num_features = embed_dim
+        self.patch_size, self.num_heads, self.n_blocks = patch_size, num_heads, depth
+        self.out_indices = list(out_indices)
+        self.img_size = img_size if isinstance(img_size, int) else img_size[0]
+        self.patch_embed = _PatchEmbed(patch_size, in_chans, embed_dim)
+        n = (self.img_size // patch_size) ** 2
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, n + 1, embed_dim))
+        self.blocks = nn.ModuleList(
+            [_Block(embed_dim, num_heads, mlp_ratio, qkv_bias, proj_bias, ffn_bias, init_values) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)  # present in checkpoints, NOT applied to the taps (dino_v2.py:252-268)
+        self.mask_token = nn.Parameter(torch.zeros(1, embed_dim))
+        self._engine = None
+        self.register_load_state_dict_post_hook(lambda m, keys: m.engine().invalidate())
+
+    def engine(self):
+        if self._engine is None:
+            self._engine = DinoEngine(self)
+        return self._engine
+
+    def forward_tokens(self, jobs, training=False, seed=0):
+        """jobs: list of (img [B,3,H,W] fp32 cuda, box or None) that share one token grid. Returns Xcat
+        [sum(B)*Np, 4*D] (compute dtype) - the four taps side by side, token-major - and (hp, wp)."""
+        return _BackboneFn.apply(self, jobs, training, seed, *self.engine().trainable())
+
+    def forward(self, x):
+        xcat, (hp, wp) = self.forward_tokens([(x, None)], training=self.training and self.engine().lora_on())
+        b, d = x.shape[0], self.embed_dim
+        v = xcat.view(b, hp, wp, len(self.out_indices), d)
+        return tuple(v[:, :, :, i].permute(0, 3, 1, 2) for i in range(len(self.out_indices)))  # NCHW-shaped views
+
+
+class _Holder(nn.Module):
+    def __init__(self, m):
+        super().__init__()
+        self.model = m
+
+
+class _PeftModel(nn.Module):
+    def __init__(self, m):
+        super().__init__()
+        self.base_model = _Holder(m)
+
+
+@MODELS.register_module()
+class LoRABackbone(nn.Module):
+    """rein/models/backbones/lora_backbone.py:10-44.  `checkpoint=None` (random init) is accepted - a documented
+    deviation: the reference torch.load()s unconditionally."""
+
+    def __init__(self, backbone, checkpoint=None, Lora_config=None, init_cfg=None, **kw):
+        super().__init__()
+        vit = MODELS.build(backbone)
+        cfg = Lora_config or {}
+        self.lora_targets = list(cfg.get("target_modules", ["qkv"]))
+        if self.lora_targets != ["qkv"]:
+            raise NotImplementedError("HIP path fuses LoRA into the qkv projection (target_modules=['qkv'])")
+        for blk in vit.blocks:
+            blk.attn.qkv = LoraLinear(blk.attn.qkv, cfg.get("r", 32), cfg.get("lora_alpha", 32), cfg.get("lora_dropout", 0.0))
+        self.model = _PeftModel(vit)
+        self._lora_train = False
+        if checkpoint is not None:
+            self.load_pretrained_backbone(checkpoint, self.lora_targets)
+        self.train(True)
+
+    @property
+    def vit(self):
+        return self.model.base_model.model
+
+    def load_pretrained_backbone(self, checkpoint, target_modules):
+        sd = torch.load(checkpoint, map_location="cpu") if isinstance(checkpoint, str) else checkpoint
+        new = {}
+        for name, w in sd.items():
+            for t in target_modules:  # lora_backbone.py:30-34 rename
+                if t in name:
+                    name = name.replace(t, t + ".base_layer")
+            new[name] = w
+        self.vit.load_state_dict(new, strict=False)
+        self.vit.engine().invalidate()
+
+    def train(self, mode=True):
+        """lora_backbone.py:37-41 + utils.py:9-58: only parameters whose name contains 'lora' are trainable and the
+        base model stays in eval (no drop-path / dropout); modules named lora* (lora_dropout) are in train mode."""
+        super().train(False)
+        self._lora_train = bool(mode)
+        for n, p in self.named_parameters():
+            p.requires_grad = ("lora" in n) if mode else p.requires_grad
+        return self
+
+    def forward_tokens(self, jobs, seed=0):
+        return self.vit.forward_tokens(jobs, training=self._lora_train, seed=seed)
+
+    def forward(self, x):
+        xcat, (hp, wp) = self.forward_tokens([(x, None)])
+        b, d, nt = x.shape[0], self.vit.embed_dim, len(self.vit.out_indices)
+        v = xcat.view(b, hp, wp, nt, d)
+        return tuple(v[:, :, :, i].permute(0, 3, 1, 2) for i in range(nt))
+
+
+# ------------------------------------------------------------------------------------------ packed weights
+class Packed:
+    """A frozen [N,K] weight in the compute dtype, plus (bf16 mode) its transpose for the dgrad GEMM."""
+
+    def __init__(self, w_f32, cd, k_pad=None):
+        n, k = w_f32.shape
+        k_pad = k_pad or k
+        self.n, self.k = n, k_pad
+        self.w = torch.zeros(n, k_pad, dtype=cd, device=w_f32.device)
+        ops.cast(w_f32, self.w[:, :k])
+        self.wt = None
+        if cd == torch.bfloat16:
+            self.wt = torch.zeros(k_pad, n, dtype=cd, device=w_f32.device)
+            ops.transpose(w_f32, self.wt[:k], pad_rows=n)
+
+    def fwd(self, a, out, **epi):
+        return ops.gemm(a, self.w, out, **epi)
+
+    def dgrad(self, dy, out, **epi):
+        if self.wt is not None:
+            return ops.gemm(dy, self.wt, out, **epi)
+        return ops.gemm(dy, self.w, out, trans_b=True, **epi)
+
+
+def wgrad(dy, x, grad_out, alpha=1.0, n_rows=None, accumulate=True):
+    """grad_out[N,K] (+)= alpha * dy[:, :N]^T @ x   (reduction over the M tokens).
+    bf16: explicit transposes feed the NT MFMA GEMM (K = tokens, zero-padded to 64); f32: strided operands."""
+    M = dy.shape[0]
+    res = grad_out if accumulate else None
+    if dy.dtype == torch.bfloat16:
+        mp = (M + 63) // 64 * 64
+        dyt = torch.empty(dy.shape[1], mp, dtype=dy.dtype, device=dy.device)
+        xt = torch.empty(x.shape[1], mp, dtype=x.dtype, device=x.device)
+        ops.transpose(dy, dyt, pad_rows=mp)
+        ops.transpose(x, xt, pad_rows=mp)
+        ops.gemm(dyt, xt, grad_out, alpha=alpha, residual=res)
+    else:
+        ops.gemm(dy, x, grad_out, alpha=alpha, residual=res, trans_a=True, trans_b=True)
+    return grad_out
+
+
+# ------------------------------------------------------------------------------------------ engine
+class DinoEngine:
+    def __init__(self, vit):
+        self.vit = vit
+        self._packed = None
+        self._pos_cache = {}
+
+    def invalidate(self):
+        self._packed = None
+        self._pos_cache = {}
+
+    def lora_on(self):
+        return isinstance(self.vit.blocks[0].attn.qkv, LoraLinear)
+
+    def trainable(self):
+        out = []
+        if self.lora_on():
+            for blk in self.vit.blocks:
+                out += [blk.attn.qkv.lora_A["default"].weight, blk.attn.qkv.lora_B["default"].weight]
+        return out
+
+    # ---- frozen weights, packed once per (dtype, device)
+    def packed(self):
+        cd = compute_dtype()
+        dev = self.vit.pos_embed.device
+        if self._packed is not None and self._packed["cd"] == cd and self._packed["dev"] == dev:
+            return self._packed
+        v = self.vit
+        D = v.embed_dim
+        P = dict(cd=cd, dev=dev, layers=[])
+        with torch.no_grad():
+            pw = v.patch_embed.proj.weight.detach().reshape(D, -1)
+            P["pe"] = Packed(pw, cd)
+            P["pe_b"] = v.patch_embed.proj.bias.detach().float().contiguous()
+            P["cls"] = v.cls_token.detach().reshape(D).float().contiguous()
+            for blk in v.blocks:
+                qkv = blk.attn.qkv
+                base = qkv.base_layer if isinstance(qkv, LoraLinear) else qkv
+                kq = D + (R_PAD if isinstance(qkv, LoraLinear) else 0)
+                Lp = dict(
+                    qkv=Packed(base.weight.detach(), cd, k_pad=kq),
+                    qkv_b=base.bias.detach().float().contiguous() if base.bias is not None else None,
+                    proj=Packed(blk.attn.proj.weight.detach(), cd),
+                    proj_b=blk.attn.proj.bias.detach().float().contiguous() if blk.attn.proj.bias is not None else None,
+                    fc1=Packed(blk.mlp.fc1.weight.detach(), cd),
+                    fc1_b=blk.mlp.fc1.bias.detach().float().contiguous() if blk.mlp.fc1.bias is not None else None,
+                    fc2=Packed(blk.mlp.fc2.weight.detach(), cd),
+                    fc2_b=blk.mlp.fc2.bias.detach().float().contiguous() if blk.mlp.fc2.bias is not None else None,
+                    g1=blk.ls1.gamma.detach().float().contiguous(), g2=blk.ls2.gamma.detach().float().contiguous(),
+                    n1w=blk.norm1.weight.detach().float().contiguous(), n1b=blk.norm1.bias.detach().float().contiguous(),
+                    n2w=blk.norm2.weight.detach().float().contiguous(), n2b=blk.norm2.bias.detach().float().contiguous(),
+                )
+                if isinstance(qkv, LoraLinear):
+                    Lp["a"] = torch.zeros(R_PAD, D, dtype=cd, device=dev)       # A padded to 64 rows   [r, in]
+                    Lp["at"] = torch.zeros(D, R_PAD, dtype=cd, device=dev)      # A^T                   [in, r]
+                P["layers"].append(Lp)
+        self._packed = P
+        return P
+
+    def refresh_lora(self, P):
+        """LoRA factors change every optimiser step: re-pack them into the concatenated QKV operand."""
+        D = self.vit.embed_dim
+        with torch.no_grad():
+            for blk, Lp in zip(self.vit.blocks, P["layers"]):
+                q = blk.attn.qkv
+                if not isinstance(q, LoraLinear):
+                    continue
+                A, Bm, r = q.lora_A["default"].weight.detach(), q.lora_B["default"].weight.detach(), q.r
+                ops.cast(A, Lp["a"][:r])
+                _pack_at(A, Lp["at"], r)
+                ops.cast(Bm, Lp["qkv"].w[:, D:D + r])
+                if Lp["qkv"].wt is not None:
+                    ops.transpose(Bm, Lp["qkv"].wt[D:D + r], pad_rows=Bm.shape[0])
+
+    def pos_tokens(self, hp, wp):
+        v = self.vit
+        n = v.pos_embed.shape[1] - 1
+        s = int(math.sqrt(n))
+        if hp == s and wp == s:
+            return v.pos_embed.detach().reshape(n + 1, -1).float().contiguous()
+        raise NotImplementedError("pos-embed bicubic re-interpolation (dino_v2.py:184-215) is not on the HIP path yet")
+
+    # ---- forward
+    def forward(self, jobs, training, seed):
+        v, P = self.vit, self.packed()
+        cd = P["cd"]
+        dev = P["dev"]
+        D, H, ps = v.embed_dim, v.num_heads, v.patch_size
+        lora = self.lora_on()
+        if lora:
+            self.refresh_lora(P)
+        sizes = []
+        for img, box in jobs:
+            y0, y1, x0, x1 = box if box is not None else (0, img.shape[2], 0, img.shape[3])
+            sizes.append(((y1 - y0) // ps, (x1 - x0) // ps))
+        hp, wp = sizes[0]
+        assert all(s == (hp, wp) for s in sizes), "all jobs of one backbone call must share the token grid"
+        Np = hp * wp
+        nimg = sum(j[0].shape[0] for j in jobs)
+        Mp, M = nimg * Np, nimg * Np + nimg
+        kpe = 3 * ps * ps
+        A0 = torch.empty(Mp, kpe, dtype=cd, device=dev)
+        r0 = 0
+        for img, box in jobs:
+            b = img.shape[0]
+            ops.patchify(img, A0[r0 * Np:(r0 + b) * Np], box=box, patch=ps)
+            r0 += b
+        ptok = torch.empty(Mp, D, dtype=torch.float32, device=dev)
+        P["pe"].fwd(A0, ptok, bias=P["pe_b"])
+        x = torch.empty(M, D, dtype=torch.float32, device=dev)
+        ops.assemble_tokens(ptok, P["cls"], self.pos_tokens(hp, wp), x, nimg, Np, D)
+        del ptok, A0
+        nt = len(v.out_indices)
+        xcat = torch.empty(Mp, nt * D, dtype=cd, device=dev)
+        saved = []
+        hd = D // H
+        scale = hd ** -0.5
+        for li, (blk, Lp) in enumerate(zip(v.blocks, P["layers"])):
+            S = {"x_in": x}
+            kq = Lp["qkv"].k
+            a1 = torch.zeros(M, kq, dtype=cd, device=dev) if kq > D else torch.empty(M, D, dtype=cd, device=dev)
+            st1 = torch.empty(M, 2, dtype=torch.float32, device=dev)
+            ops.layernorm_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1)
+            if lora:
+                q = blk.attn.qkv
+                xd, mask = a1[:, :D], None
+                if training and q.p > 0:
+                    mask = torch.empty(M, D, dtype=cd, device=dev)
+                    ops.dropout_mask(mask, q.p, seed, offset=li * M * D)
+                    xd = torch.empty(M, D, dtype=cd, device=dev)
+                    ops.mul_mask(a1[:, :D], mask, xd)
+                ops.gemm(xd, Lp["a"], a1[:, D:D + R_PAD], alpha=q.scaling)  # T = s * drop(xn) A^T
+                S.update(xd=xd if mask is not None else None, mask=mask)
+            qkv = torch.empty(M, 3 * D, dtype=cd, device=dev)
+            Lp["qkv"].fwd(a1, qkv, bias=Lp["qkv_b"])
+            ao = torch.empty(M, D, dtype=cd, device=dev)
+            lse = torch.empty(nimg, H, Np + 1, dtype=torch.float32, device=dev)
+            ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ao, lse, nimg, H, hd, Np, 1, Np, 1, scale)
+            xm = torch.empty(M, D, dtype=torch.float32, device=dev)
+            Lp["proj"].fwd(ao, xm, bias=Lp["proj_b"], colscale=Lp["g1"], residual=x)
+            a2 = torch.empty(M, D, dtype=cd, device=dev)
+            st2 = torch.empty(M, 2, dtype=torch.float32, device=dev)
+            ops.layernorm_fwd(xm, Lp["n2w"], Lp["n2b"], 1e-6, a2, st2)
+            hid = Lp["fc1"].n
+            hpre = torch.empty(M, hid, dtype=cd, device=dev)
+            g = torch.empty(M, hid, dtype=cd, device=dev)
+            Lp["fc1"].fwd(a2, g, bias=Lp["fc1_b"], ep_mode=ops.EP_GELU, c2=hpre)
+            xo = torch.empty(M, D, dtype=torch.float32, device=dev)
+            Lp["fc2"].fwd(g, xo, bias=Lp["fc2_b"], colscale=Lp["g2"], residual=xm)
+            S.update(a1=a1, st1=st1, qkv=qkv, ao=ao, lse=lse, x_mid=xm, a2=a2, st2=st2, hpre=hpre, g=g)
+            saved.append(S)
+            x = xo
+            if li in v.out_indices:
+                i = v.out_indices.index(li)
+                ops.cast(x[:Mp], xcat[:, i * D:(i + 1) * D])
+        ctx = dict(saved=saved, nimg=nimg, Np=Np, M=M, Mp=Mp, P=P, training=training)
+        return xcat, (hp, wp), ctx
+
+    # ---- backward: d(xcat) -> LoRA grads [dA0, dB0, dA1, dB1, ...]
+    def backward(self, ctx, dxcat):
+        v, P = self.vit, ctx["P"]
+        cd, dev = P["cd"], P["dev"]
+        D, H = v.embed_dim, v.num_heads
+        hd = D // H
+        scale = hd ** -0.5
+        M, Mp, nimg, Np = ctx["M"], ctx["Mp"], ctx["nimg"], ctx["Np"]
+        dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
+        grads = [None] * (2 * len(v.blocks))
+        for li in range(len(v.blocks) - 1, -1, -1):
+            blk, Lp, S = v.blocks[li], P["layers"][li], ctx["saved"][li]
+            q = blk.attn.qkv
+            if li in v.out_indices:
+                i = v.out_indices.index(li)
+                src = dxcat[:, i * D:(i + 1) * D]
+                ops.strided_copy(src, dx, (Mp, D), (src.stride(0), 1), (D, 1), accumulate=True)
+            # ---- MLP branch: x_out = x_mid + g2 * fc2(gelu(fc1(LN2(x_mid))))
+            t = torch.empty(M, D, dtype=cd, device=dev)
+            ops.cast(dx, t, Lp["g2"])
+            hid = Lp["fc1"].n
+            dh = torch.empty(M, hid, dtype=cd, device=dev)
+            Lp["fc2"].dgrad(t, dh, ep_mode=ops.EP_MUL_GELU_GRAD, aux=S["hpre"])
+            dn = torch.empty(M, D, dtype=cd, device=dev)
+            Lp["fc1"].dgrad(dh, dn)
+            ops.layernorm_bwd(dn, S["x_mid"], Lp["n2w"], S["st2"], dx, accumulate_dx=True)
+            del dh
+            # ---- attention branch: x_mid = x_in + g1 * proj(attn(qkv(LN1(x_in))))
+            ops.cast(dx, t, Lp["g1"])
+            dao = torch.empty(M, D, dtype=cd, device=dev)
+            Lp["proj"].dgrad(t, dao)
+            dqkv = torch.empty(M, 3 * D, dtype=cd, device=dev)
+            qkv = S["qkv"]
+            ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], S["ao"], S["lse"], dao, dqkv[:, :D], dqkv[:, D:2 * D],
+                         dqkv[:, 2 * D:], nimg, H, hd, Np, 1, Np, 1, scale)
+            kq = Lp["qkv"].k
+            da1 = torch.empty(M, kq, dtype=cd, device=dev)
+            Lp["qkv"].dgrad(dqkv, da1)
+            if isinstance(q, LoraLinear):
+                r = q.r
+                A, Bm = q.lora_A["default"].weight, q.lora_B["default"].weight
+                a1 = S["a1"]
+                xd = S["xd"] if S["xd"] is not None else a1[:, :D]
+                gB = torch.empty_like(Bm, dtype=torch.float32)
+                gA = torch.empty_like(A, dtype=torch.float32)
+                # dB[out, r] = dqkv^T @ T ;  dA[r, in] = s * dT^T @ drop(xn)
+                _wgrad_cols(dqkv, a1[:, D:D + r], gB)
+                _wgrad_cols(da1[:, D:D + r], xd, gA, alpha=q.scaling)
+                grads[2 * li], grads[2 * li + 1] = gA, gB
+                # d LN1(x) = da1[:, :D] + mask * (s * dT @ A)
+                ep = dict(ep_mode=ops.EP_MUL, aux=S["mask"]) if S["mask"] is not None else {}
+                ops.gemm(da1[:, D:D + R_PAD], Lp["at"], da1[:, :D], alpha=q.scaling, residual=da1[:, :D], **ep)
+            ops.layernorm_bwd(da1[:, :D], S["x_in"], Lp["n1w"], S["st1"], dx, accumulate_dx=True)
+            ctx["saved"][li] = None
+        return grads
+
+
+def _pack_at(A, at, r):
+    """at[:, :r] = A^T  (A [r, in])"""
+    ops.strided_copy(A, at, (A.shape[1], r), (1, A.stride(0)), (at.stride(0), 1))
+
+
+def _wgrad_cols(dy, x, grad_out, alpha=1.0):
+    """grad_out[N,K] = alpha * dy^T @ x, where dy / x may be column slices (made contiguous by the transposes)."""
+    if dy.dtype == torch.bfloat16:
+        M = dy.shape[0]
+        mp = (M + 63) // 64 * 64
+        dyt = torch.empty(dy.shape[1], mp, dtype=dy.dtype, device=dy.device)
+        xt = torch.empty(x.shape[1], mp, dtype=x.dtype, device=x.device)
+        ops.transpose(dy, dyt, pad_rows=mp)
+        ops.transpose(x, xt, pad_rows=mp)
+        ops.gemm(dyt, xt, grad_out, alpha=alpha)
+    else:
+        ops.gemm(dy, x, grad_out, alpha=alpha, trans_a=True, trans_b=True)
+
+
+class _BackboneFn(torch.autograd.Function):
+    """One autograd node for the whole ViT: forward saves activations, backward runs the hand-written block backward."""
+
+    @staticmethod
+    def forward(ctx, vit, jobs, training, seed, *lora_params):
+        eng = vit.engine()
+        need_grad = training and any(p.requires_grad for p in lora_params)
+        xcat, grid, c = eng.forward(jobs, training, seed)
+        if need_grad:
+            ctx.eng, ctx.c = eng, c
+        else:
+            c["saved"] = None
+        ctx.nparams = len(lora_params)
+        ctx.mark_non_differentiable()
+        ctx.set_materialize_grads(False)
+        ctx.grid = grid
+        return xcat, _Grid(grid)
+
+    @staticmethod
+    def backward(ctx, dxcat, _):
+        if dxcat is None:
+            return (None, None, None, None) + (None,) * ctx.nparams
+        grads = ctx.eng.backward(ctx.c, dxcat.contiguous())
+        return (None, None, None, None) + tuple(grads)
+
+
+class _Grid(tuple):
+    """(hp, wp) carried through autograd.Function as a non-tensor output."""
+    pass
