@@ -59,6 +59,10 @@ int vfm_mul_mask(const void* src, int src_dt, long ld_src, const void* mask, int
 int vfm_geglu_fwd(const void* h, int h_dt, long ld_h, void* out, int out_dt, long ld_out, long rows, long C, void* stream);
 int vfm_geglu_bwd(const void* h, int h_dt, long ld_h, const void* dout, int do_dt, long ld_do, void* dh, int dh_dt,
                   long ld_dh, long rows, long C, void* stream);
+/* out[r,c] = dy[r,c] * act'(pre[r,c])  (act: VFM_ACT_GELU on the saved pre-activation; VFM_ACT_RELU may be given the
+ * post-activation, the sign test is identical) */
+int vfm_act_grad_mul(const void* dy, int dy_dt, long ld_dy, const void* pre, int pre_dt, long ld_pre, void* out, int out_dt,
+                     long ld_out, long rows, long cols, int act, void* stream);
 /* query masking (Transformer.py:263-268): out[r,:] = keep[r] ? x[r,:] : token[:] ; bwd splits the gradient */
 int vfm_mask_token_fwd(const float* x, const uint8_t* keep, const float* token, float* out, long rows, long C, void* stream);
 int vfm_mask_token_bwd(const float* dout, const uint8_t* keep, float* dx, float* dtoken, long rows, long C, void* stream);

@@ -1,0 +1,126 @@
+"""Heads and the full MsVFMEncoderDecoder train step on the HIP path vs the CPU oracle and the reference goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import vfmseg_amd  # noqa: E402,F401
+from oracle import torch_ref as R  # noqa: E402
+from tests.helpers import cached_full_state_dict, rel_err, sl  # noqa: E402
+from vfmseg_amd import presets  # noqa: E402
+from vfmseg_amd.heads import FeatPack  # noqa: E402
+from vfmseg_amd.precision import set_compute_dtype  # noqa: E402
+from vfmseg_amd.registry import MODELS  # noqa: E402
+from vfmseg_amd.segmentors import SegDataSample  # noqa: E402
+from vfmseg_amd.synth import synth_image, synth_label  # noqa: E402
+
+
+def _feats(b, seed):
+    g = torch.Generator().manual_seed(3000 + seed)
+    return [torch.randn(b, 1024, 32, 32, generator=g) for _ in range(4)]
+
+
+def _pack(feats, dtype):
+    B = feats[0].shape[0]
+    x = torch.cat([f.permute(0, 2, 3, 1).reshape(B * 1024, 1024) for f in feats], 1)
+    return FeatPack(x.to(dtype).cuda().contiguous(), B, 32, 32)
+
+
+def _zero_dropout(m):
+    for mod in m.modules():
+        if hasattr(mod, "dropout_ratio"):
+            mod.dropout_ratio = 0.0
+        if hasattr(mod, "p") and isinstance(getattr(mod, "p"), float):
+            mod.p = 0.0
+
+
+def _build_heads(sd):
+    lin = MODELS.build(presets.linear_head()).cuda()
+    vfm = MODELS.build(presets.vfm_head()).cuda()
+    lin.load_state_dict({k[len("decode_head."):]: v for k, v in sd.items() if k.startswith("decode_head.")})
+    vfm.load_state_dict({k[len("aux_decoder."):]: v for k, v in sd.items() if k.startswith("aux_decoder.")})
+    _zero_dropout(lin), _zero_dropout(vfm)
+    return lin, vfm
+
+
+def test_heads_match_reference_goldens(golden_dir):
+    G = np.load(os.path.join(golden_dir, "heads.npz"))
+    set_compute_dtype("f32")
+    try:
+        sd = cached_full_state_dict()
+        lin, vfm = _build_heads(sd)
+        feats = _feats(2, 1)
+        lab = synth_label(2, 512, seed=5).cuda()
+        fp = _pack(feats, torch.float32)
+        lin.train()
+        losses, logits = lin.loss(fp, lab, return_logits=True)
+        assert rel_err(sl(logits), G["lin_train_logits_slice"]) < 1e-3
+        np.testing.assert_allclose([losses["loss_ce"].item(), losses["acc_seg"].item()], G["lin_train_loss"], rtol=1e-4)
+        lin.load_state_dict({k[len("decode_head."):]: v for k, v in sd.items() if k.startswith("decode_head.")})
+        lin.eval()
+        with torch.no_grad():
+            le = lin.forward(fp)
+        assert rel_err(sl(le), G["lin_eval_logits_slice"]) < 1e-3
+        vfm.train()
+        _zero_dropout(vfm)
+        ctx = torch.randn(2, 19, 256, 256, generator=torch.Generator().manual_seed(77)).cuda()
+        vfm.transformer_decoder.fixed_keep = torch.from_numpy(G["vfm_mask_rand"]) > 0.2
+        losses, hl = vfm.loss(fp, ctx, lab, return_logits=True)
+        assert rel_err(sl(hl), G["vfm_logits_slice"]) < 1e-3
+        np.testing.assert_allclose([losses["loss_ce"].item(), losses["acc_seg"].item()], G["vfm_loss"], rtol=2e-4)
+        vfm.transformer_decoder.mask_enable = False
+        with torch.no_grad():
+            ln = vfm.forward(fp, ctx)
+        assert rel_err(sl(ln), G["vfm_nomask_logits_slice"]) < 1e-3
+    finally:
+        set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("mode,ltol,gtol", [("f32", 2e-4, 5e-3), ("bf16", 3e-2, 1.5e-1)])
+def test_train_step_matches_reference_goldens(golden_dir, mode, ltol, gtol):
+    """Full forward_train + backward (B=2, 1024^2 -> 2x512^2 passes) against tests/golden/train_step.npz, which was
+    produced by the reference's own MsVFMEncoderDecoder."""
+    G = np.load(os.path.join(golden_dir, "train_step.npz"))
+    set_compute_dtype(mode)
+    try:
+        sd = cached_full_state_dict()
+        model = MODELS.build(presets.dinov2_ms_masked()).cuda()
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        model.train()
+        _zero_dropout(model)
+        for blk in model.backbone.vit.blocks:
+            blk.attn.qkv.p = 0.0
+        model.fixed_crop_box = tuple(int(v) for v in G["hr_crop_box"])
+        model.aux_decoder.transformer_decoder.fixed_keep = torch.from_numpy(G["mask_rand"]) > 0.2
+        img, lab = synth_image(2, 1024, seed=3), synth_label(2, 1024, seed=3)
+        samples = [SegDataSample(gt_sem_seg=lab[i]) for i in range(2)]
+        losses = model.loss(img.cuda(), samples)
+        keys = ["decode_lr.loss_ce", "decode_lr.acc_seg", "decode_hr.loss_ce", "decode_hr.acc_seg"]
+        got = np.array([float(losses[k]) for k in keys])
+        np.testing.assert_allclose(got[[0, 2]], G["losses"][[0, 2]], rtol=ltol)
+        np.testing.assert_allclose(got[[1, 3]], G["losses"][[1, 3]], atol=0.05 if mode == "bf16" else 2e-3)
+        total, _ = model.parse_losses(losses)
+        total.backward()
+        named = dict(model.named_parameters())
+        n_train = sum(p.numel() for p in named.values() if p.requires_grad)
+        assert n_train == int(G["n_trainable"][0])
+        norms = [0.0, 0.0, 0.0]
+        for k, p in named.items():
+            if p.grad is None:
+                continue
+            j = 0 if "lora_" in k else (1 if k.startswith("decode_head") else 2)
+            norms[j] += p.grad.double().pow(2).sum().item()
+        np.testing.assert_allclose(np.sqrt(norms), G["grad_norms"], rtol=gtol)
+        for name in G.files:
+            if name.startswith("grad_slice::"):
+                k = name.split("::", 1)[1]
+                g = named[k].grad
+                g2 = g.reshape(g.shape[0], -1) if g.dim() > 1 else g
+                e = rel_err(sl(g2), G[name])
+                assert e < gtol * 2, (k, e)
+    finally:
+        set_compute_dtype("bf16")

@@ -267,6 +267,28 @@ extern "C" int vfm_geglu_bwd(const void* h, int h_dt, long ld_h, const void* dou
   return VFM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ act grad
+__global__ void k_act_grad_mul(const void* __restrict__ dy, int dy_dt, long ld_dy, const void* __restrict__ pre, int pre_dt,
+                               long ld_pre, void* __restrict__ out, int out_dt, long ld_out, long rows, long cols, int act) {
+  const long total = rows * cols;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols, c = i - r * cols;
+    const float p = ld_any(pre, r * ld_pre + c, pre_dt);
+    const float g = act == VFM_ACT_GELU ? gelu_grad_f(p) : (act == VFM_ACT_RELU ? (p > 0.f ? 1.f : 0.f) : 1.f);
+    st_any(out, r * ld_out + c, out_dt, ld_any(dy, r * ld_dy + c, dy_dt) * g);
+  }
+}
+extern "C" int vfm_act_grad_mul(const void* dy, int dy_dt, long ld_dy, const void* pre, int pre_dt, long ld_pre, void* out,
+                                int out_dt, long ld_out, long rows, long cols, int act, void* stream) {
+  const long total = rows * cols;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_act_grad_mul, dim3(grid), dim3(256), 0, (hipStream_t)stream, dy, dy_dt, ld_dy, pre, pre_dt, ld_pre, out,
+                     out_dt, ld_out, rows, cols, act);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ mask token
 __global__ void k_mask_token_fwd(const float* __restrict__ x, const uint8_t* __restrict__ keep, const float* __restrict__ tok,
                                  float* __restrict__ out, long rows, long C) {

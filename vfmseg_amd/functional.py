@@ -1,0 +1,488 @@
+"""Autograd ops of the decoder heads, each a thin torch.autograd.Function over the C-ABI kernels.
+
+Conventions: feature maps are token-major matrices [rows, C]; GEMM operands use the compute dtype (bf16 | f32),
+normalisation inputs / residual streams / losses are fp32.  Every Function returns gradients in the dtype of the
+corresponding forward input, so autograd never inserts a cast of its own.
+"""
+import torch
+
+from . import ops
+from .precision import compute_dtype
+
+_seed_state = {"seed": 0x5EED, "offset": 0}
+
+
+def manual_seed(seed):
+    _seed_state["seed"], _seed_state["offset"] = int(seed), 0
+
+
+def _next_rng(n):
+    off = _seed_state["offset"]
+    _seed_state["offset"] += int(n)
+    return _seed_state["seed"], off
+
+
+def _pad64(n):
+    return (n + 63) // 64 * 64
+
+
+# ------------------------------------------------------------------------------------------------ weight layouts
+# Each trainable weight is packed into the GEMM's B operand [N, K] (K contiguous) and its gradient un-packed.
+#   linear / conv1x1 : param [N, K(,1,1)]                      -> B[n, k]
+#   conv2x2s2        : param [Cout, Cin, 2, 2]                  -> B[co, (ky*2+kx)*Cin + ci]   (im2col order of blocked maps)
+#   convT2x2         : param [Cin, Cout, 2, 2]                  -> B[(ky*2+kx)*Cout + co, ci] (pixel-shuffle-free ConvTranspose)
+def _layout_dims(w, layout):
+    if layout in ("linear", "conv1x1"):
+        return w.shape[0], w[0].numel()
+    if layout == "conv2x2s2":
+        return w.shape[0], 4 * w.shape[1]
+    if layout == "convT2x2":
+        return 4 * w.shape[1], w.shape[0]
+    raise ValueError(layout)
+
+
+def _pack(w, layout, dst):
+    """dst [N, >=K] (any dtype) <- param"""
+    ld = dst.stride(0)
+    if layout in ("linear", "conv1x1"):
+        n, k = _layout_dims(w, layout)
+        ops.strided_copy(w, dst, (n, k), (k, 1), (ld, 1))
+    elif layout == "conv2x2s2":
+        co, ci = w.shape[0], w.shape[1]
+        # index space (co, kk, ci): src w[co, ci, kk] ; dst [co, kk*ci_n + ci]
+        ops.strided_copy(w, dst, (co, 4, ci), (ci * 4, 1, 4), (ld, ci, 1))
+    elif layout == "convT2x2":
+        ci, co = w.shape[0], w.shape[1]
+        # index space (kk, co, ci): src w[ci, co, kk] ; dst [(kk*co_n + co), ci]
+        ops.strided_copy(w, dst, (4, co, ci), (1, 4, co * 4), (co * ld, ld, 1))
+    return dst
+
+
+def _unpack_grad(g2d, layout, w):
+    """fp32 grad in param layout from the [N, >=K] GEMM-layout gradient."""
+    out = torch.empty_like(w, dtype=torch.float32)
+    ld = g2d.stride(0)
+    if layout in ("linear", "conv1x1"):
+        n, k = _layout_dims(w, layout)
+        ops.strided_copy(g2d, out, (n, k), (ld, 1), (k, 1))
+    elif layout == "conv2x2s2":
+        co, ci = w.shape[0], w.shape[1]
+        ops.strided_copy(g2d, out, (co, 4, ci), (ld, ci, 1), (ci * 4, 1, 4))
+    elif layout == "convT2x2":
+        ci, co = w.shape[0], w.shape[1]
+        ops.strided_copy(g2d, out, (4, co, ci), (co * ld, ld, 1), (1, 4, co * 4))
+    return out
+
+
+def _splitk_wgrad(dyt, xt, out, kchunks):
+    """out[N,Kp] = dyt[N,Mp] @ xt[Kp,Mp]^T with the token reduction split into `kchunks` batched slices that are
+    then summed in a fixed order (deterministic split-K)."""
+    n, mp = dyt.shape
+    kp = xt.shape[0]
+    if kchunks <= 1:
+        return ops.gemm(dyt, xt, out)
+    ck = mp // kchunks
+    slabs = torch.empty(kchunks, n, kp, dtype=torch.float32, device=out.device)
+    a = torch.as_strided(dyt, (kchunks, n, ck), (ck, mp, 1))
+    b = torch.as_strided(xt, (kchunks, kp, ck), (ck, mp, 1))
+    ops.gemm(a, b, slabs)
+    ops.colsum(slabs.view(kchunks, n * kp), out.view(n * kp))
+    return out
+
+
+class LinearFn(torch.autograd.Function):
+    """y = [dropout](act(x @ W^T + b)) [+ residual]   with W = concat_N(pack(w_i)).
+
+    x: [M, Kp] compute dtype (columns beyond the weights' K must be zero).  out_dtype: torch dtype of y.
+    act: None | 'gelu' | 'relu'.  residual: fp32/any [M, N] added after the (dropped-out) linear part.
+    """
+
+    @staticmethod
+    def forward(ctx, x, residual, bias, opts, *weights):
+        layouts, act, out_dtype, drop_p, bias_tile = opts["layouts"], opts.get("act"), opts["out_dtype"], opts.get("drop_p", 0.0), opts.get("bias_tile", 1)
+        cd = x.dtype
+        M, Kp = x.shape
+        dims = [_layout_dims(w, l) for w, l in zip(weights, layouts)]
+        N = sum(d[0] for d in dims)
+        K = dims[0][1]
+        assert all(d[1] == K for d in dims) and K <= Kp
+        wp = torch.zeros(N, Kp, dtype=cd, device=x.device) if Kp > K else torch.empty(N, Kp, dtype=cd, device=x.device)
+        r0 = 0
+        for w, l, d in zip(weights, layouts, dims):
+            _pack(w.detach(), l, wp[r0:r0 + d[0]])
+            r0 += d[0]
+        y = torch.empty(M, N, dtype=out_dtype, device=x.device)
+        need_grad = any(ctx.needs_input_grad)
+        pre = None
+        ep, aux = ops.EP_NONE, None
+        if act == "gelu":
+            ep = ops.EP_GELU
+            pre = torch.empty(M, N, dtype=cd, device=x.device) if need_grad else None
+        elif act == "relu":
+            ep = ops.EP_RELU
+        mask = None
+        if drop_p > 0:
+            assert act is None
+            mask = torch.empty(M, N, dtype=cd, device=x.device)
+            seed, off = _next_rng(M * N)
+            ops.dropout_mask(mask, drop_p, seed, off)
+            ep, aux = ops.EP_MUL, mask
+        bias_full = None
+        if bias is not None:
+            bias_full = bias.detach()
+        ops.gemm(x, wp, y, bias=bias_full, bias_mod=(N // bias_tile if bias_tile > 1 else 0), residual=residual, ep_mode=ep,
+                 aux=aux, c2=pre)
+        ctx.save_for_backward(x, wp, pre if pre is not None else (y if act == "relu" else None), mask, *weights)
+        ctx.opts, ctx.dims, ctx.has_res, ctx.has_bias = opts, dims, residual is not None, bias is not None
+        ctx.res_dtype = residual.dtype if residual is not None else None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wp, pre, mask, *weights = ctx.saved_tensors
+        opts, dims = ctx.opts, ctx.dims
+        layouts, act, bias_tile = opts["layouts"], opts.get("act"), opts.get("bias_tile", 1)
+        cd = x.dtype
+        M, Kp = x.shape
+        N = wp.shape[0]
+        dy = dy.contiguous()
+        d_res = None
+        if ctx.has_res and ctx.needs_input_grad[1]:
+            d_res = dy if dy.dtype == ctx.res_dtype else _cast_new(dy, ctx.res_dtype)
+        # effective gradient of the linear part, in the compute dtype, zero-padded to a multiple of 64 columns (bf16)
+        npad = _pad64(N) if cd == torch.bfloat16 else N
+        g = torch.zeros(M, npad, dtype=cd, device=dy.device) if npad > N else torch.empty(M, N, dtype=cd, device=dy.device)
+        gv = g[:, :N]
+        if mask is not None:
+            ops.mul_mask(dy, mask, gv)
+        elif act == "gelu":
+            _mul_act_grad(dy, pre, gv, "gelu")
+        elif act == "relu":
+            _mul_act_grad(dy, pre, gv, "relu")
+        else:
+            ops.cast(dy, gv)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(M, Kp, dtype=cd, device=dy.device)
+            if cd == torch.bfloat16:
+                wt = torch.zeros(Kp, npad, dtype=cd, device=dy.device) if npad > N else torch.empty(Kp, N, dtype=cd, device=dy.device)
+                ops.transpose(wp, wt, pad_rows=N)
+                ops.gemm(g, wt, dx)
+            else:
+                ops.gemm(gv, wp, dx, trans_b=True)
+        dbias = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            full = torch.empty(N, dtype=torch.float32, device=dy.device)
+            ops.colsum(gv, full)
+            if bias_tile > 1:
+                dbias = torch.empty(N // bias_tile, dtype=torch.float32, device=dy.device)
+                ops.colsum(full.view(bias_tile, N // bias_tile), dbias)
+            else:
+                dbias = full
+        dws = [None] * len(weights)
+        if any(ctx.needs_input_grad[4:]):
+            gw = torch.empty(N, Kp, dtype=torch.float32, device=dy.device)
+            if cd == torch.bfloat16:
+                mp = _pad64(M)
+                tiles = ((N + 127) // 128) * ((Kp + 127) // 128)
+                kch = 1
+                while tiles * kch < 256 and (mp // (kch * 2)) % 64 == 0 and mp // (kch * 2) >= 256:
+                    kch *= 2
+                dyt = torch.empty(N, mp, dtype=cd, device=dy.device)
+                xt = torch.empty(Kp, mp, dtype=cd, device=dy.device)
+                ops.transpose(gv, dyt, pad_rows=mp)
+                ops.transpose(x, xt, pad_rows=mp)
+                _splitk_wgrad(dyt, xt, gw, kch)
+            else:
+                ops.gemm(gv, x, gw, trans_a=True, trans_b=True)
+            r0 = 0
+            for i, (w, l, d) in enumerate(zip(weights, layouts, dims)):
+                if ctx.needs_input_grad[4 + i]:
+                    dws[i] = _unpack_grad(gw[r0:r0 + d[0]], l, w)
+                r0 += d[0]
+        return (dx, d_res, dbias, None) + tuple(dws)
+
+
+def _cast_new(t, dtype):
+    out = torch.empty(t.shape, dtype=dtype, device=t.device)
+    ops.cast(t.view(-1, t.shape[-1]), out.view(-1, t.shape[-1]))
+    return out
+
+
+def _mul_act_grad(dy, pre, out, kind):
+    """out = dy * act'(pre)  (relu: `pre` may be the post-activation, the sign test is the same)."""
+    M, N = dy.shape
+    if kind == "gelu":
+        # reuse the GEMM-free path: gelu'(pre) via the norm-free elementwise kernel family
+        ops.act_grad_mul(dy, pre, out, ops.ACT_GELU)
+    else:
+        ops.act_grad_mul(dy, pre, out, ops.ACT_RELU)
+
+
+def linear(x, weights, layouts, bias=None, residual=None, act=None, out_dtype=None, drop_p=0.0, bias_tile=1):
+    if not isinstance(weights, (list, tuple)):
+        weights, layouts = [weights], [layouts]
+    opts = dict(layouts=list(layouts), act=act, out_dtype=out_dtype or x.dtype, drop_p=drop_p, bias_tile=bias_tile)
+    return LinearFn.apply(x, residual, bias, opts, *weights)
+
+
+# ------------------------------------------------------------------------------------------------ norms
+class GroupNormActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, B, P, groups, eps, act, out_dtype):
+        x = x.contiguous()
+        C = x.shape[1]
+        y = torch.empty(B * P, C, dtype=out_dtype, device=x.device)
+        stats = torch.empty(B, groups, 2, dtype=torch.float32, device=x.device)
+        ops.groupnorm_fwd(x, w.detach(), b.detach(), eps, groups, act, y, stats, B, P)
+        ctx.save_for_backward(x, w, b, stats)
+        ctx.cfg = (B, P, groups, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b, stats = ctx.saved_tensors
+        B, P, groups, act = ctx.cfg
+        C = x.shape[1]
+        dx = torch.empty_like(x)
+        dw = torch.zeros(C, dtype=torch.float32, device=x.device)
+        db = torch.zeros(C, dtype=torch.float32, device=x.device)
+        ops.groupnorm_bwd(dy.contiguous(), x, w.detach(), b.detach(), stats, groups, act, dx, dw, db, B, P)
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def group_norm_act(x, w, b, B, P, groups=32, eps=1e-5, act=ops.ACT_NONE, out_dtype=None):
+    return GroupNormActFn.apply(x, w, b, B, P, groups, eps, act, out_dtype or compute_dtype())
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps, out_dtype):
+        x = x.contiguous()
+        M, C = x.shape
+        y = torch.empty(M, C, dtype=out_dtype, device=x.device)
+        stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+        ops.layernorm_fwd(x, w.detach(), b.detach(), eps, y, stats)
+        ctx.save_for_backward(x, w, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, stats = ctx.saved_tensors
+        C = x.shape[1]
+        dx = torch.empty_like(x)
+        dw = torch.zeros(C, dtype=torch.float32, device=x.device)
+        db = torch.zeros(C, dtype=torch.float32, device=x.device)
+        ops.layernorm_bwd(dy.contiguous(), x, w.detach(), stats, dx, False, dw, db)
+        return dx, dw, db, None, None
+
+
+def layer_norm(x, w, b, eps=1e-5, out_dtype=None):
+    return LayerNormFn.apply(x, w, b, eps, out_dtype or compute_dtype())
+
+
+class BatchNormActFn(torch.autograd.Function):
+    """nn.SyncBatchNorm (train mode) + fused activation on [rows, C]; `sync` = callable all-reducing a fp32 tensor in
+    place over the data-parallel group (None on a single GPU), `world_rows` = global row count."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, running_mean, running_var, momentum, eps, act, out_dtype, sync, world):
+        x = x.contiguous()
+        rows, C = x.shape
+        sums = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        ops.bn_moments(x, sums)
+        total = rows * world
+        if sync is not None:
+            sync(sums)
+        mv = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        ops.bn_finalize(sums, total, mv, running_mean, running_var, momentum)
+        y = torch.empty(rows, C, dtype=out_dtype, device=x.device)
+        ops.bn_apply(x, mv, w.detach(), b.detach(), eps, act, y)
+        ctx.save_for_backward(x, w, b, mv)
+        ctx.cfg = (eps, act, sync, total)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, b, mv = ctx.saved_tensors
+        eps, act, sync, total = ctx.cfg
+        rows, C = x.shape
+        dy = dy.contiguous()
+        sd = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        ops.bn_bwd_reduce(dy, x, mv, w.detach(), b.detach(), eps, act, sd)
+        db, dw = sd[0].clone(), sd[1].clone()  # local parameter gradients (DDP averages them later)
+        if sync is not None:
+            sync(sd)
+        dx = torch.empty_like(x)
+        ops.bn_bwd_apply(dy, x, mv, w.detach(), b.detach(), eps, act, sd, total, dx)
+        return dx, dw, db, None, None, None, None, None, None, None, None
+
+
+def batch_norm_act_train(x, w, b, running_mean, running_var, momentum=0.1, eps=1e-5, act=ops.ACT_NONE, out_dtype=None,
+                         sync=None, world=1):
+    return BatchNormActFn.apply(x, w, b, running_mean, running_var, momentum, eps, act, out_dtype or compute_dtype(), sync, world)
+
+
+def batch_norm_act_eval(x, w, b, running_mean, running_var, eps=1e-5, act=ops.ACT_NONE, out_dtype=None):
+    mv = torch.stack([running_mean.detach().float(), running_var.detach().float()]).contiguous()
+    y = torch.empty(x.shape, dtype=out_dtype or compute_dtype(), device=x.device)
+    ops.bn_apply(x.contiguous(), mv, w.detach(), b.detach(), eps, act, y)
+    return y
+
+
+# ------------------------------------------------------------------------------------------------ attention
+class SelfAttnFn(torch.autograd.Function):
+    """qkv [B*N, 3*H*d] packed (q | k | v) -> o [B*N, H*d]"""
+
+    @staticmethod
+    def forward(ctx, qkv, B, N, H, d):
+        inner = H * d
+        o = torch.empty(B * N, inner, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+        ops.attn_fwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], o, lse, B, H, d, N, 0, N, 0, d ** -0.5)
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.cfg = (B, N, H, d)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        B, N, H, d = ctx.cfg
+        inner = H * d
+        dqkv = torch.empty_like(qkv)
+        ops.attn_bwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], o, lse, do.contiguous(), dqkv[:, :inner],
+                     dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:], B, H, d, N, 0, N, 0, d ** -0.5)
+        return dqkv, None, None, None, None
+
+
+class CrossAttnFn(torch.autograd.Function):
+    """q [B*Nq, H*d], kv [B*Nk, 2*H*d] packed (k | v) -> o [B*Nq, H*d]"""
+
+    @staticmethod
+    def forward(ctx, q, kv, B, Nq, Nk, H, d):
+        inner = H * d
+        o = torch.empty(B * Nq, inner, dtype=q.dtype, device=q.device)
+        lse = torch.empty(B, H, Nq, dtype=torch.float32, device=q.device)
+        ops.attn_fwd(q, kv[:, :inner], kv[:, inner:], o, lse, B, H, d, Nq, 0, Nk, 0, d ** -0.5)
+        ctx.save_for_backward(q, kv, o, lse)
+        ctx.cfg = (B, Nq, Nk, H, d)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, o, lse = ctx.saved_tensors
+        B, Nq, Nk, H, d = ctx.cfg
+        inner = H * d
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        ops.attn_bwd(q, kv[:, :inner], kv[:, inner:], o, lse, do.contiguous(), dq, dkv[:, :inner], dkv[:, inner:], B, H, d, Nq,
+                     0, Nk, 0, d ** -0.5)
+        return dq, dkv, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+class GegluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h):
+        M, c2 = h.shape
+        out = torch.empty(M, c2 // 2, dtype=h.dtype, device=h.device)
+        ops.geglu_fwd(h, out)
+        ctx.save_for_backward(h)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (h,) = ctx.saved_tensors
+        dh = torch.empty_like(h)
+        ops.geglu_bwd(h, dout.contiguous(), dh)
+        return dh
+
+
+class DropoutFn(torch.autograd.Function):
+    """y = x * mask[(row // rows_per_group), :]; mask multipliers drawn here (Dropout / Dropout2d)."""
+
+    @staticmethod
+    def forward(ctx, x, p, rows_per_group):
+        M, C = x.shape
+        g = (M + rows_per_group - 1) // rows_per_group
+        mask = torch.empty(g, C, dtype=torch.float32, device=x.device)
+        seed, off = _next_rng(g * C)
+        ops.dropout_mask(mask, p, seed, off)
+        y = torch.empty_like(x)
+        ops.mul_mask(x, mask, y, rows_per_group)
+        ctx.save_for_backward(mask)
+        ctx.rpg = rows_per_group
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dx = torch.empty_like(dy)
+        ops.mul_mask(dy.contiguous(), mask, dx, ctx.rpg)
+        return dx, None, None
+
+
+def dropout(x, p, training, rows_per_group=1):
+    if not training or p <= 0:
+        return x
+    return DropoutFn.apply(x, p, rows_per_group)
+
+
+class MaskTokenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, keep_u8, token):
+        out = torch.empty_like(x)
+        ops.mask_token_fwd(x.contiguous(), keep_u8, token.detach().reshape(-1).contiguous(), out)
+        ctx.save_for_backward(keep_u8)
+        ctx.tshape = token.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (keep,) = ctx.saved_tensors
+        dx = torch.empty_like(dout)
+        dt = torch.empty(dout.shape[1], dtype=torch.float32, device=dout.device)
+        ops.mask_token_bwd(dout.contiguous(), keep, dx, dt)
+        return dx, None, dt.view(ctx.tshape)
+
+
+class UnblockFn(torch.autograd.Function):
+    """[B, H*W (blocked), C] fp32 -> [B,H,W,C]"""
+
+    @staticmethod
+    def forward(ctx, x, B, H, W, levels):
+        C = x.shape[-1]
+        y = torch.empty(B, H, W, C, dtype=torch.float32, device=x.device)
+        ops.unblock(x.contiguous(), y, B, H, W, C, levels, False)
+        ctx.cfg = (B, H, W, C, levels, x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C, levels, shp = ctx.cfg
+        dx = torch.empty(shp, dtype=torch.float32, device=dy.device)
+        ops.unblock(dy.contiguous(), dx, B, H, W, C, levels, True)
+        return dx, None, None, None, None
+
+
+class UpsampleCEFn(torch.autograd.Function):
+    """loss = mean over ALL pixels of CE(bilinear_up(logits_low), label) (ignore_index contributes 0) - mmseg
+    CrossEntropyLoss(avg_non_ignore=False).  The full-resolution logits are never materialised."""
+
+    @staticmethod
+    def forward(ctx, logits_low, label, ignore_index, loss_weight):
+        loss, counts, dl = ops.upsample_ce(logits_low.contiguous(), label, ignore_index, need_grad=True)
+        ctx.save_for_backward(dl)
+        ctx.lw = loss_weight
+        ctx.mark_non_differentiable(counts)
+        if loss_weight != 1.0:
+            ops.axpby(loss, loss_weight, loss, 0.0)
+        return loss.view(()), counts
+
+    @staticmethod
+    def backward(ctx, dloss, _):
+        (dl,) = ctx.saved_tensors
+        g = dl.clone() if False else dl
+        ops.scale_by_device_scalar(g, dloss.contiguous().view(1))
+        if ctx.lw != 1.0:
+            ops.axpby(g, ctx.lw, g, 0.0)
+        return g, None, None, None

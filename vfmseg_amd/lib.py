@@ -57,6 +57,7 @@ SIGNATURES = {
     "vfm_mul_mask": [vp, ci, cl, vp, ci, cl, cl, vp, ci, cl, cl, cl, vp],
     "vfm_geglu_fwd": [vp, ci, cl, vp, ci, cl, cl, cl, vp],
     "vfm_geglu_bwd": [vp, ci, cl, vp, ci, cl, vp, ci, cl, cl, cl, vp],
+    "vfm_act_grad_mul": [vp, ci, cl, vp, ci, cl, vp, ci, cl, cl, cl, ci, vp],
     "vfm_mask_token_fwd": [vp, vp, vp, vp, cl, cl, vp],
     "vfm_mask_token_bwd": [vp, vp, vp, vp, cl, cl, vp],
     "vfm_layernorm_fwd": [vp, cl, vp, vp, cf, vp, ci, cl, vp, cl, cl, vp],

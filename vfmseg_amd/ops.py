@@ -121,6 +121,13 @@ def geglu_bwd(h, dout, dh):
     return dh
 
 
+def act_grad_mul(dy, pre, out, act):
+    lib = L.load()
+    L.check(lib.vfm_act_grad_mul(L.ptr(dy), L.dt_of(dy), _ld(dy), L.ptr(pre), L.dt_of(pre), _ld(pre), L.ptr(out),
+                                 L.dt_of(out), _ld(out), dy.shape[0], dy.shape[1], act, L.stream()), "vfm_act_grad_mul")
+    return out
+
+
 def mask_token_fwd(x, keep, token, out):
     lib = L.load()
     L.check(lib.vfm_mask_token_fwd(L.ptr(x), L.ptr(keep), L.ptr(token), L.ptr(out), x.shape[0], x.shape[1], L.stream()),

@@ -1,0 +1,294 @@
+"""Segmentors on the HIP path.  MsVFMEncoderDecoder mirrors rein/models/segmentors/Ms_VFM_encoder_decoder.py:62-474
+(multi-scale training: LR pass + HR crop, two heads; coarse-to-fine gated sliding inference); EncoderDecoder /
+LoraBackboneEncoderDecoder mirror the mmseg base class slice the reference configs use (SURVEY App. D,
+rein/models/segmentors/Lora_encoder_decoder.py:12-44)."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .heads import FeatPack
+from .registry import MODELS
+
+
+class PixelData:
+    def __init__(self, data):
+        self.data = data
+
+
+class SegDataSample:
+    """Minimal stand-in for mmseg.structures.SegDataSample: `.gt_sem_seg.data` [1,H,W] int64 and `.metainfo`."""
+
+    def __init__(self, gt_sem_seg=None, metainfo=None):
+        if gt_sem_seg is not None:
+            self.gt_sem_seg = PixelData(gt_sem_seg)
+        self.metainfo = metainfo or {}
+
+    def set_metainfo(self, d):
+        self.metainfo.update(d)
+
+
+class CfgDict(dict):
+    """dict with attribute access (mmengine ConfigDict subset used by the segmentors)."""
+
+    def __init__(self, d=None):
+        super().__init__()
+        for k, v in (d or {}).items():
+            self[k] = CfgDict(v) if isinstance(v, dict) else v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+@MODELS.register_module()
+class SegDataPreProcessor(nn.Module):
+    """mmseg SegDataPreProcessor for already-decoded tensors: float inputs are taken as normalised images and stacked;
+    labels are stacked into data_samples (padding to `size` with pad_val / seg_pad_val when shapes differ is a
+    next-row item: synthetic batches are already at `size`)."""
+
+    def __init__(self, mean=None, std=None, size=None, size_divisor=None, pad_val=0, seg_pad_val=255, bgr_to_rgb=False,
+                 rgb_to_bgr=False, batch_augments=None, test_cfg=None):
+        super().__init__()
+        self.size, self.pad_val, self.seg_pad_val, self.bgr_to_rgb = size, pad_val, seg_pad_val, bgr_to_rgb
+        self.register_buffer("mean", torch.tensor(mean if mean is not None else [0.0, 0.0, 0.0]).view(-1, 1, 1), False)
+        self.register_buffer("std", torch.tensor(std if std is not None else [1.0, 1.0, 1.0]).view(-1, 1, 1), False)
+
+    def forward(self, data, training=False):
+        inputs, samples = data["inputs"], data.get("data_samples")
+        if isinstance(inputs, (list, tuple)):
+            inputs = torch.stack(list(inputs), 0)
+        if inputs.dtype != torch.float32:
+            raise NotImplementedError("uint8 decode/normalise path is a next-row item; pass normalised float images")
+        return dict(inputs=inputs.cuda(non_blocking=True).contiguous(), data_samples=samples)
+
+
+def get_crop_bbox(img_h, img_w, crop_size, divisible=1):
+    """Ms_VFM_encoder_decoder.py:34-46 (np.random: same RNG stream as the reference)."""
+    assert crop_size[0] > 0 and crop_size[1] > 0
+    if img_h == crop_size[-2] and img_w == crop_size[-1]:
+        return (0, img_h, 0, img_w)
+    margin_h = max(img_h - crop_size[-2], 0)
+    margin_w = max(img_w - crop_size[-1], 0)
+    offset_h = np.random.randint(0, (margin_h + 1) // divisible) * divisible
+    offset_w = np.random.randint(0, (margin_w + 1) // divisible) * divisible
+    return offset_h, offset_h + crop_size[0], offset_w, offset_w + crop_size[1]
+
+
+def add_prefix(d, prefix):
+    return {f"{prefix}.{k}": v for k, v in d.items()}
+
+
+def grid_boxes(h_img, w_img, crop, stride):
+    h_crop, w_crop = crop
+    h_stride, w_stride = stride
+    h_grids = max(h_img - h_crop + h_stride - 1, 0) // h_stride + 1
+    w_grids = max(w_img - w_crop + w_stride - 1, 0) // w_stride + 1
+    out = []
+    for hi in range(h_grids):
+        for wi in range(w_grids):
+            y2 = min(hi * h_stride + h_crop, h_img)
+            x2 = min(wi * w_stride + w_crop, w_img)
+            out.append((max(y2 - h_crop, 0), y2, max(x2 - w_crop, 0), x2))
+    return out
+
+
+@MODELS.register_module()
+class EncoderDecoder(nn.Module):
+    def __init__(self, backbone, decode_head, neck=None, auxiliary_head=None, train_cfg=None, test_cfg=None,
+                 data_preprocessor=None, pretrained=None, init_cfg=None):
+        super().__init__()
+        if neck is not None or auxiliary_head is not None:
+            raise NotImplementedError("neck / auxiliary_head are outside the hot path")
+        self.data_preprocessor = MODELS.build(data_preprocessor or dict(type="SegDataPreProcessor"))
+        self.backbone = MODELS.build(backbone)
+        self.decode_head = MODELS.build(decode_head)
+        self.align_corners = self.decode_head.align_corners
+        self.num_classes = self.decode_head.num_classes
+        self.out_channels = self.decode_head.out_channels
+        self.train_cfg, self.test_cfg = CfgDict(train_cfg), CfgDict(test_cfg)
+        self.with_neck = False
+
+    # ---- features
+    def _tokens(self, jobs):
+        bb = self.backbone
+        if hasattr(bb, "forward_tokens"):
+            if bb.__class__.__name__ == "LoRABackbone":
+                xcat, (hp, wp) = bb.forward_tokens(jobs)
+            else:
+                xcat, (hp, wp) = bb.forward_tokens(jobs, training=False)
+            return xcat, hp, wp
+        raise NotImplementedError(type(bb))
+
+    def extract_feat(self, inputs):
+        xcat, hp, wp = self._tokens([(inputs, None)])
+        return FeatPack(xcat, inputs.shape[0], hp, wp)
+
+    # ---- mmengine BaseModel surface
+    def forward(self, inputs, data_samples=None, mode="tensor"):
+        if mode == "loss":
+            return self.loss(inputs, data_samples)
+        if mode == "predict":
+            return self.predict(inputs, data_samples)
+        return self.decode_head.forward(self.extract_feat(inputs))
+
+    def loss(self, inputs, data_samples):
+        fp = self.extract_feat(inputs)
+        seg_label = self.decode_head._stack_batch_gt(data_samples).cuda()
+        return add_prefix(self.decode_head.loss(fp, seg_label), "decode")
+
+    def parse_losses(self, losses):
+        total = None
+        log = {}
+        for k, v in losses.items():
+            log[k] = v
+            if "loss" in k:
+                total = v if total is None else total + v
+        log["loss"] = total
+        return total, log
+
+    def train_step(self, data, optim_wrapper):
+        data = self.data_preprocessor(data, True)
+        losses = self.forward(data["inputs"], data["data_samples"], mode="loss")
+        total, log = self.parse_losses(losses)
+        optim_wrapper.update_params(total)
+        return log
+
+    def encode_decode(self, inputs, batch_img_metas):
+        return self.decode_head.predict(self.extract_feat(inputs), batch_img_metas, self.test_cfg)
+
+    def whole_inference(self, inputs, batch_img_metas):
+        return self.encode_decode(inputs, batch_img_metas)
+
+    def slide_inference(self, inputs, batch_img_metas):
+        B, _, H, W = inputs.shape
+        preds = torch.zeros(B, self.out_channels, H, W, dtype=torch.float32, device=inputs.device)
+        count = torch.zeros(B, 1, H, W, dtype=torch.float32, device=inputs.device)
+        for (y1, y2, x1, x2) in grid_boxes(H, W, self.test_cfg.crop_size, self.test_cfg.stride):
+            xcat, hp, wp = self._tokens([(inputs, (y1, y2, x1, x2))])
+            lg = self.decode_head.forward_tokens(FeatPack(xcat, B, hp, wp))  # NHWC low-res
+            ops.slide_accumulate(lg, False, B, lg.shape[1], lg.shape[2], lg.shape[3], preds, count, (y1, x1, y2 - y1, x2 - x1))
+        ops.slide_finalize(preds, count)
+        return preds
+
+    def inference(self, inputs, batch_img_metas):
+        mode = self.test_cfg.get("mode", "whole")
+        assert mode in ("slide", "whole")
+        return self.slide_inference(inputs, batch_img_metas) if mode == "slide" else self.whole_inference(inputs, batch_img_metas)
+
+    @torch.no_grad()
+    def predict(self, inputs, data_samples=None):
+        if data_samples is not None and len(data_samples) and getattr(data_samples[0], "metainfo", None):
+            metas = [d.metainfo for d in data_samples]
+        else:
+            metas = [dict(ori_shape=inputs.shape[2:], img_shape=inputs.shape[2:], pad_shape=inputs.shape[2:],
+                          padding_size=[0, 0, 0, 0])] * inputs.shape[0]
+        seg_logits = self.inference(inputs, metas)
+        return self.postprocess_result(seg_logits, data_samples, metas)
+
+    def postprocess_result(self, seg_logits, data_samples, metas):
+        """argmax masks (uint8) per image; ori_shape == img_shape on the synthetic path (no un-padding / flip)."""
+        B, C, H, W = seg_logits.shape
+        am = torch.empty(B, H, W, dtype=torch.uint8, device=seg_logits.device)
+        ops.slide_finalize(seg_logits, None, am)
+        out = []
+        for i in range(B):
+            ds = data_samples[i] if data_samples else SegDataSample()
+            ds.seg_logits = PixelData(seg_logits[i])
+            ds.pred_sem_seg = PixelData(am[i:i + 1])
+            out.append(ds)
+        return out
+
+
+@MODELS.register_module()
+class LoraBackboneEncoderDecoder(EncoderDecoder):
+    """Lora_encoder_decoder.py:12-44: plain EncoderDecoder whose backbone is LoRA-wrapped."""
+
+    def __init__(self, Lora_config, checkpoint=None, backbone=None, **kw):
+        super().__init__(backbone=dict(type="LoRABackbone", backbone=backbone, checkpoint=checkpoint, Lora_config=Lora_config), **kw)
+
+
+@MODELS.register_module()
+class MsVFMEncoderDecoder(EncoderDecoder):
+    def __init__(self, backbone, decode_head, aux_head, neck=None, auxiliary_head=None, train_cfg=None, test_cfg=None,
+                 pretrained=None, init_cfg=None, scales=[1], hr_crop_size=None, crop_coord_divisible=1, feature_scale=1,
+                 data_preprocessor=None, debug=False, debug_interval=100, detail_loss=1.0):
+        super().__init__(backbone=backbone, decode_head=decode_head, neck=neck, auxiliary_head=auxiliary_head,
+                         train_cfg=train_cfg, test_cfg=test_cfg, data_preprocessor=data_preprocessor)
+        self.local_iter = 0
+        self.scales = sorted(scales)
+        assert len(self.scales) <= 2, "Only up to 2 scales are supported."
+        self.feature_scale = feature_scale
+        self.crop_size = hr_crop_size
+        self.crop_coord_divisible = crop_coord_divisible
+        self.hr_crop_box = None
+        self.fixed_crop_box = None  # parity tests / benchmarks pin the RNG consumer
+        self.aux_decoder = MODELS.build(aux_head)
+        self.detail_loss = detail_loss
+
+    # ---- training (Ms_VFM_encoder_decoder.py:125-200)
+    def loss(self, inputs, data_samples):
+        return self.forward_train(inputs, data_samples)
+
+    def forward_train(self, img, data_samples):
+        B, _, H, W = img.shape
+        s0, s1 = self.scales
+        assert s1 == 1 and self.crop_size is not None
+        lh, lw = int(H * s0), int(W * s0)
+        lr_img = torch.empty(B, 3, lh, lw, dtype=torch.float32, device=img.device)
+        ops.resize_bilinear(img, True, B, H, W, 3, lr_img, 1, (lh, lw))
+        box = self.fixed_crop_box or get_crop_bbox(H, W, self.crop_size, self.crop_coord_divisible)
+        self.hr_crop_box = box
+        y1, y2, x1, x2 = box
+        assert (lh, lw) == (y2 - y1, x2 - x1), "LR pass and HR crop must share the token grid to be batched"
+        # one batched backbone call: rows [0, B*P) = LR pass, [B*P, 2*B*P) = HR crop
+        xcat, hp, wp = self._tokens([(lr_img, None), (img, box)])
+        P = hp * wp
+        lr_fp, hr_fp = FeatPack(xcat[:B * P], B, hp, wp), FeatPack(xcat[B * P:], B, hp, wp)
+        seg_label = self.decode_head._stack_batch_gt(data_samples).to(img.device).squeeze(1).contiguous()  # [B,H,W]
+        lr_gt = torch.empty(B, lh, lw, dtype=torch.int64, device=img.device)
+        hr_gt = torch.empty(B, y2 - y1, x2 - x1, dtype=torch.int64, device=img.device)
+        ops.label_resize(seg_label, lr_gt, (lh, lw))                               # get_lr_seg: nearest 0.5x
+        ops.label_resize(seg_label, hr_gt, (H, W), (y1, x1, y2 - y1, x2 - x1))     # get_hr_seg: crop
+        losses = {}
+        lr_low = self.decode_head.forward_tokens(lr_fp)                            # [B, 4hp, 4wp, C] fp32
+        loss_lr = self.decode_head._loss_from_lowres(lr_low, lr_gt.unsqueeze(1), False)
+        losses.update(add_prefix(loss_lr, "decode_lr"))
+        # get_seg_logits (:160-167): detached full-res LR logits cropped at box/2 -> context for the detail head
+        assert all(v % 2 == 0 for v in box)
+        cy, cx, ch, cw = y1 // 2, x1 // 2, (y2 - y1) // 2, (x2 - x1) // 2
+        Bc, h4, w4, C = lr_low.shape
+        ctx = torch.empty(B, C, ch, cw, dtype=torch.float32, device=img.device)
+        ops.resize_bilinear(lr_low.detach(), False, B, h4, w4, C, ctx, 1, (lh, lw), (cy, cx, ch, cw))
+        hr_low = self.aux_decoder.forward_tokens(hr_fp, ctx)
+        loss_hr = self.aux_decoder._loss_from_lowres(hr_low, hr_gt.unsqueeze(1), False)
+        if self.detail_loss != 1.0:
+            loss_hr["loss_ce"] = loss_hr["loss_ce"] * self.detail_loss
+        losses.update(add_prefix(loss_hr, "decode_hr"))
+        self.local_iter += 1
+        return losses
+
+    # ---- inference (Ms_VFM_encoder_decoder.py:268-332, 400-466)
+    def enc_dec(self, inputs, context=None, box=None):
+        B = inputs.shape[0]
+        xcat, hp, wp = self._tokens([(inputs, box)])
+        fp = FeatPack(xcat, B, hp, wp)
+        if context is None:
+            return self.decode_head.forward_tokens(fp)
+        return self.aux_decoder.forward_tokens(fp, context)
+
+    def inference(self, inputs, batch_img_metas):
+        mode = self.test_cfg.get("mode", "lr_slide_inference")
+        if mode == "ms_slide_inference":
+            return self.ms_inference(inputs, batch_img_metas)
+        if mode == "hr_slide_inference":
+            return self.slide_inference(inputs, batch_img_metas)
+        raise NotImplementedError(f"test mode {mode} is not on the HIP path (ms_slide_inference / hr_slide_inference are)")
+
+    def ms_inference(self, inputs, batch_img_metas):
+        raise NotImplementedError("ms_inference on the HIP path lands with the pos-embed re-interpolation kernel")
