@@ -1,0 +1,189 @@
+"""Optimiser side of the hot path: PEFTOptimWrapperConstructor (rein/optimizers/peft_optimizer_constructor.py:18-170),
+a fused multi-tensor AdamW over ONE flat fp32 buffer (vfm_adamw) and PolyLR
+(configs/dg/gta2citys/dg_lora_dinov2_ms_masked.py:10-29).
+
+All trainable parameters are re-pointed into a flat buffer laid out in gradient-production order
+(VFMHead -> LinearHead -> LoRA layers L-1..0), and so are their gradients: the data-parallel all-reduce
+(vfmseg_amd.parallel) then works on contiguous bucket slices with no packing copies.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .registry import OPTIM_WRAPPER_CONSTRUCTORS
+
+_NORM_TYPES = (nn.modules.batchnorm._BatchNorm, nn.modules.instancenorm._InstanceNorm, nn.GroupNorm, nn.LayerNorm)
+
+
+def param_options(model, base_lr, base_wd, paramwise_cfg):
+    """-> {param_name: (lr_mult, weight_decay)} for every trainable parameter, following add_params():
+    a custom key (longest first, substring of the full name) wins; otherwise parameters of norm modules get
+    weight_decay * norm_decay_mult; everything else (incl. biases, LoRA factors, mask_token) the base values."""
+    custom = (paramwise_cfg or {}).get("custom_keys", {})
+    keys = sorted(sorted(custom.keys()), key=len, reverse=True)
+    norm_decay_mult = (paramwise_cfg or {}).get("norm_decay_mult", None)
+    bias_lr_mult = (paramwise_cfg or {}).get("bias_lr_mult", None)
+    bias_decay_mult = (paramwise_cfg or {}).get("bias_decay_mult", None)
+    out = {}
+
+    def visit(module, prefix):
+        is_norm = isinstance(module, _NORM_TYPES)
+        for name, p in module.named_parameters(recurse=False):
+            if not p.requires_grad:
+                continue
+            full = f"{prefix}.{name}" if prefix else name
+            lr_mult, wd = 1.0, base_wd
+            for k in keys:
+                if k in f"{prefix}.{name}":
+                    lr_mult = custom[k].get("lr_mult", 1.0)
+                    wd = base_wd * custom[k].get("decay_mult", 1.0)
+                    break
+            else:
+                if name == "bias" and not is_norm and bias_lr_mult is not None:
+                    lr_mult = bias_lr_mult
+                if is_norm and norm_decay_mult is not None:
+                    wd = base_wd * norm_decay_mult
+                elif name == "bias" and bias_decay_mult is not None:
+                    wd = base_wd * bias_decay_mult
+            out[full] = (lr_mult, wd)
+        for cn, child in module.named_children():
+            visit(child, f"{prefix}.{cn}" if prefix else cn)
+
+    visit(model, "")
+    return out
+
+
+def production_order(names):
+    """Gradient-production order of backward: aux_decoder, decode_head, then LoRA blocks from the last to the first."""
+    def key(n):
+        if "lora_" in n:
+            try:
+                blk = int(n.split("blocks.")[1].split(".")[0])
+            except Exception:
+                blk = 0
+            return (2, -blk, n)
+        if n.startswith("aux_decoder"):
+            return (0, 0, n)
+        return (1, 0, n)
+    return sorted(names, key=key)
+
+
+class PolyLR:
+    """mmengine PolyLR(by_epoch=False): lr_t = (base - eta_min) * (1 - t/T)^power + eta_min, t = steps taken."""
+
+    def __init__(self, base_lr, power=0.9, eta_min=0.0, begin=0, end=40000, **kw):
+        self.base_lr, self.power, self.eta_min, self.begin, self.end = base_lr, power, eta_min, begin, end
+
+    def lr(self, t):
+        t = min(max(t - self.begin, 0), self.end - self.begin)
+        return (self.base_lr - self.eta_min) * (1 - t / (self.end - self.begin)) ** self.power + self.eta_min
+
+
+class FusedAdamW:
+    def __init__(self, model, lr, weight_decay, betas=(0.9, 0.999), eps=1e-8, paramwise_cfg=None):
+        self.lr, self.betas, self.eps = lr, tuple(betas), eps
+        opts = param_options(model, lr, weight_decay, paramwise_cfg)
+        named = dict(model.named_parameters())
+        self.names = production_order([n for n in named if named[n].requires_grad])
+        assert set(self.names) == set(opts), "option table / trainable set mismatch"
+        self.params = [named[n] for n in self.names]
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        self.offsets = [0]
+        for s in sizes:
+            self.offsets.append(self.offsets[-1] + s)
+        n = self.offsets[-1]
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, a, b in zip(self.params, self.offsets[:-1], self.offsets[1:]):
+                view = self.flat[a:b].view(p.shape)
+                ops.cast(p.detach().reshape(1, -1).contiguous(), self.flat[a:b].view(1, -1))
+                p.data = view
+                p.grad = self.gflat[a:b].view(p.shape)
+        self.seg_start = torch.tensor(self.offsets[:-1], dtype=torch.int64, device=dev)
+        self.seg_lr = torch.tensor([opts[nm][0] for nm in self.names], dtype=torch.float32, device=dev)
+        self.seg_wd = torch.tensor([opts[nm][1] for nm in self.names], dtype=torch.float32, device=dev)
+        self.step_count = 0
+        self.param_groups = [dict(lr=lr)]
+
+    def bucket_slices(self):
+        """[(name, start, end)] contiguous gradient slices in production order: aux_decoder, decode_head, lora."""
+        cuts, cur = [], None
+        for nm, a in zip(self.names, self.offsets[:-1]):
+            g = "lora" if "lora_" in nm else ("aux_decoder" if nm.startswith("aux_decoder") else "decode_head")
+            if g != cur:
+                cuts.append([g, a, a])
+                cur = g
+            cuts[-1][2] = a + dict(zip(self.names, [p.numel() for p in self.params]))[nm]
+        return [tuple(c) for c in cuts]
+
+    def step(self, lr=None, grad_scale=1.0):
+        self.step_count += 1
+        lr = self.lr if lr is None else lr
+        self.param_groups[0]["lr"] = lr
+        ops.adamw(self.flat, self.gflat, self.m, self.v, self.seg_start, self.seg_lr, self.seg_wd, lr, self.betas, self.eps,
+                  self.step_count, grad_scale)
+
+    def zero_grad(self):
+        self.gflat.zero_()
+        for p, a, b in zip(self.params, self.offsets[:-1], self.offsets[1:]):
+            if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + a * 4:
+                p.grad = self.gflat[a:b].view(p.shape)
+
+    def state_dict(self):
+        return dict(step=self.step_count, m=self.m, v=self.v, names=self.names)
+
+    def load_state_dict(self, sd):
+        self.step_count = sd["step"]
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+
+
+class OptimWrapper:
+    """mmengine OptimWrapper.update_params: backward -> (grad sync) -> step -> zero_grad; scheduler stepped by iter."""
+
+    def __init__(self, optimizer, scheduler=None, grad_sync=None):
+        self.optimizer, self.scheduler, self.grad_sync = optimizer, scheduler, grad_sync
+        self.iter = 0
+
+    def update_params(self, loss):
+        loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync()
+        lr = self.scheduler.lr(self.iter) if self.scheduler is not None else None
+        self.optimizer.step(lr, grad_scale=getattr(self.grad_sync, "post_scale", 1.0))
+        self.optimizer.zero_grad()
+        self.iter += 1
+
+    def get_lr(self):
+        return self.optimizer.param_groups[0]["lr"]
+
+
+@OPTIM_WRAPPER_CONSTRUCTORS.register_module()
+class PEFTOptimWrapperConstructor:
+    def __init__(self, optim_wrapper_cfg, paramwise_cfg=None):
+        self.cfg = dict(optim_wrapper_cfg)
+        self.cfg.pop("constructor", None)
+        self.paramwise_cfg = paramwise_cfg if paramwise_cfg is not None else self.cfg.pop("paramwise_cfg", None)
+        self.optimizer_cfg = dict(self.cfg["optimizer"])
+
+    def __call__(self, model, param_scheduler=None):
+        model.train()
+        oc = dict(self.optimizer_cfg)
+        typ = oc.pop("type", "AdamW")
+        if typ != "AdamW":
+            raise NotImplementedError("the hot path ships the reference's optimiser (AdamW) only")
+        opt = FusedAdamW(model, oc.get("lr", 1e-3), oc.get("weight_decay", 0.01), oc.get("betas", (0.9, 0.999)),
+                         oc.get("eps", 1e-8), self.paramwise_cfg)
+        sched = None
+        if param_scheduler:
+            sc = dict(param_scheduler[0] if isinstance(param_scheduler, (list, tuple)) else param_scheduler)
+            assert sc.pop("type", "PolyLR") == "PolyLR"
+            sc.pop("by_epoch", None)
+            sched = PolyLR(opt.lr, **sc)
+        return OptimWrapper(opt, sched)
