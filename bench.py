@@ -102,8 +102,13 @@ def cpu_baseline(seconds_cap=40.0):
     from vfmseg_amd.registry import MODELS
     from vfmseg_amd.synth import synth_image, synth_label, synth_like
     import vfmseg_amd  # noqa: F401
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("VFMSEG_CPU_THREADS", "16"))))  # a GPU box grants a 16-core share
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: oracle train step on {cores} threads ...", file=sys.stderr, flush=True)
     model = MODELS.build(presets.dinov2_ms_masked())
     sd = synth_like(model.state_dict())
     del model
@@ -159,9 +164,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    print(f"[bench] rank {rank}: model built, warming up", file=sys.stderr, flush=True)
     for _ in range(a.warmup):
         model.train_step(data, ow)
     barrier()
+    print(f"[bench] rank {rank}: timing {a.steps} steps", file=sys.stderr, flush=True)
     timer.on = not a.no_roofline
     t0 = time.perf_counter()
     for _ in range(a.steps):
