@@ -1,9 +1,381 @@
-// bf16 MFMA flash attention (forward + backward).  Placeholder dispatch to the generic kernels until the MFMA
-// kernels below are complete.
-#include "common.h"
+// bf16 MFMA flash attention for head dim 64 (forward, dQ, dK/dV), gfx950.
+//
+// One wave owns 32 "stationary" sequence positions (queries for forward/dQ, keys for dK/dV): those sit on the MFMA
+// *lane* (column) index, so softmax statistics, LSE and delta are per-lane scalars and the first product's f32
+// accumulator is, after a bf16 convert, directly the B operand of the second product ("accumulator tile as the next
+// MFMA's operand", cdna_hip_programming.md §3) - no LDS round trip for P / dS.
+//   forward : S^T = K Q^T            ;  O^T  += V^T P^T
+//   dQ      : S^T, dP^T = V dO^T     ;  dQ^T += K^T dS^T
+//   dK/dV   : S = Q K^T, dP = dO V^T ;  dV^T += dO^T P ,  dK^T += Q^T dS
+// The streamed operand (K,V / Q,dO) is staged in 64-row LDS tiles by LDS-DMA (global_load_lds_dwordx4), double
+// buffered, 16-byte chunks XOR-swizzled by row so that both the row reads (ds_read_b128, first product) and the
+// transposed reads (ds_read_b64_tr_b16, second product) spread over the banks.
+#include "attn_common.h"
 
-int vfm_attn_f32_fwd_impl(const vfm_attn_desc* d, hipStream_t s);
-int vfm_attn_f32_bwd_impl(const vfm_attn_desc* d, hipStream_t s);
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-int vfm_attn_bf16_fwd_impl(const vfm_attn_desc* d, hipStream_t s) { return vfm_attn_f32_fwd_impl(d, s); }
-int vfm_attn_bf16_bwd_impl(const vfm_attn_desc* d, hipStream_t s) { return vfm_attn_f32_bwd_impl(d, s); }
+#define TROWS 64
+#define TILE_BYTES (TROWS * 128)
+#define LOG2E 1.4426950408889634f
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 4, 0, 0);
+}
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+// stage one [64 x 64] bf16 tile: sequence positions s0..s0+63 of image b (clamped), columns col0..col0+63
+__device__ __forceinline__ void stage_tile(const bf16_t* base, long ld, int col0, int b, int s0, int n, int n_main, int B, char* tile,
+                                           int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int piece = wave * 2 + j;
+    const int r = piece * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz(r);
+    int s = s0 + r;
+    if (s > n - 1) s = n - 1;
+    glds16(base + tok_row(b, s, n_main, B) * ld + col0 + c * 8, tile + piece * 1024);
+  }
+}
+// first-product A operand: rows rb*32 + (lane&31), 8 consecutive columns of k-step kk (16 columns per step)
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int rb, int kk, int lane) {
+  const int r = rb * 32 + (lane & 31);
+  return *reinterpret_cast<const bf16x8*>(tile + r * 128 + (((2 * kk + (lane >> 5)) ^ swz(r)) << 4));
+}
+// second-product A operand = (tile^T)[32 columns of block j][16 rows of step s in row-block rb], delivered in the
+// permuted k order of an accumulator-derived B operand: element e <-> tile row rb*32 + 16s + 8(e>>2) + 4h + (e&3)
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rb, int s, int j, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, h = g >> 1;
+  const int chunk = 4 * j + 2 * (g & 1) + (p >> 1);
+  const int r0 = rb * 32 + 16 * s + 4 * h + q;
+  const int r1 = r0 + 8;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(tile + r0 * 128 + ((chunk ^ swz(r0)) << 4) + ((p & 1) << 3)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(tile + r1 * 128 + ((chunk ^ swz(r1)) << 4) + ((p & 1) << 3)));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  return u.v;
+}
+// registers 8s..8s+7 of a 32x32 f32 accumulator -> bf16x8 B operand of k-step s
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (__bf16)a[8 * s + e];
+  return r;
+}
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }  // row of register r
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+// load the stationary operand's B fragments: 4 k-steps x 8 bf16 of row `row`, columns col0 + 16kk + 8h ..
+__device__ __forceinline__ void load_stationary(const bf16_t* base, long ld, long row, int col0, int h, bf16x8 (&f)[4]) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) f[kk] = *reinterpret_cast<const bf16x8*>(base + row * ld + col0 + 16 * kk + 8 * h);
+}
+
+// ------------------------------------------------------------------------------------------------------ forward
+template <bool DQ>
+__global__ void __launch_bounds__(256, 2) k_attn_bf16_q(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K tile, V tile)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.y, b = bh / p.H, hh = bh % p.H;
+  const int nq = p.nq_main + p.nq_extra, nk = p.nk_main + p.nk_extra;
+  const int col0 = hh * 64;
+  const int h = lane >> 5;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int qi = q0 + (lane & 31);
+  const bool qvalid = qi < nq;
+  const long qrow = tok_row(b, qvalid ? qi : nq - 1, p.nq_main, p.B);
+  const bf16_t* Kb = (const bf16_t*)p.k;
+  const bf16_t* Vb = (const bf16_t*)p.v;
+  bf16x8 qf[4], dof[4];
+  load_stationary((const bf16_t*)p.q, p.ldq, qrow, col0, h, qf);
+  float lse_l = 0.f, delta_l = 0.f;
+  if (DQ) {
+    load_stationary((const bf16_t*)p.dout, p.ld_do, qrow, col0, h, dof);
+    lse_l = p.lse[((long)b * p.H + hh) * nq + (qvalid ? qi : nq - 1)] * LOG2E;
+    delta_l = p.delta[((long)b * p.H + hh) * nq + (qvalid ? qi : nq - 1)];
+  }
+  const float c = p.scale * LOG2E;
+  f32x16 oacc[2] = {zero16(), zero16()};
+  float m = -INFINITY, l = 0.f;
+  const int nt = (nk + TROWS - 1) / TROWS;
+  auto stage = [&](int buf, int t) {
+    char* kt = smem + buf * 2 * TILE_BYTES;
+    stage_tile(Kb, p.ldk, col0, b, t * TROWS, nk, p.nk_main, p.B, kt, wave, lane);
+    stage_tile(Vb, p.ldv, col0, b, t * TROWS, nk, p.nk_main, p.B, kt + TILE_BYTES, wave, lane);
+  };
+  stage(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) {
+      stage(buf ^ 1, t + 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const char* kt = smem + buf * 2 * TILE_BYTES;
+    const char* vt = kt + TILE_BYTES;
+    f32x16 sacc[2] = {zero16(), zero16()};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) sacc[kb] = MFMA(row_frag(kt, kb, kk, lane), qf[kk], sacc[kb]);
+    const bool tail = (t == nt - 1) && (nk % TROWS != 0);
+    if (!DQ) {
+      // ---- online softmax over this lane's 32 keys of the tile (the other 32 live in lane ^ 32)
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (tail && (t * TROWS + kb * 32 + acc_row(r, h) >= nk)) sacc[kb][r] = -INFINITY;
+          mx = fmaxf(mx, sacc[kb][r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+      const float mnc = mn * c;
+      float rs = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -mnc));
+          sacc[kb][r] = pv;
+          rs += pv;
+        }
+      l = l * alpha + rs;
+      m = mn;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[j][r] *= alpha;
+    } else {
+      // ---- dS^T = P^T * (dP^T - delta), P^T = exp(scale*S^T - lse)
+      f32x16 dpacc[2] = {zero16(), zero16()};
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) dpacc[kb] = MFMA(row_frag(vt, kb, kk, lane), dof[kk], dpacc[kb]);
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -lse_l));
+          if (tail && (t * TROWS + kb * 32 + acc_row(r, h) >= nk)) pv = 0.f;
+          sacc[kb][r] = pv * (dpacc[kb][r] - delta_l);
+        }
+    }
+    // ---- second product: acc^T[col, query] += tile^T[col x key] * X[key x query]
+    const char* t2 = DQ ? kt : vt;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pb = acc_frag(sacc[kb], s);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) oacc[j] = MFMA(tr_frag(t2, kb, s, j, lane), pb, oacc[j]);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // ---- epilogue: lane = query, registers = output columns acc_row(r, h) + 32 j
+  float mult;
+  if (!DQ) {
+    l += __shfl_xor(l, 32, 64);
+    mult = 1.f / l;
+    if (qvalid && h == 0 && p.lse) p.lse[((long)b * p.H + hh) * nq + qi] = m * p.scale + __logf(l);
+  } else {
+    mult = p.scale;
+  }
+  if (qvalid) {
+    bf16_t* out = DQ ? (bf16_t*)p.dq : (bf16_t*)p.o;
+    const long ldo = DQ ? p.ld_dq : p.ldo;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        ushort4 v;
+        v.x = f32_to_bf16(oacc[j][4 * g + 0] * mult);
+        v.y = f32_to_bf16(oacc[j][4 * g + 1] * mult);
+        v.z = f32_to_bf16(oacc[j][4 * g + 2] * mult);
+        v.w = f32_to_bf16(oacc[j][4 * g + 3] * mult);
+        *reinterpret_cast<ushort4*>(out + qrow * ldo + col0 + 32 * j + 8 * g + 4 * h) = v;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------ dK / dV
+__global__ void __launch_bounds__(256, 2) k_attn_bf16_dkv(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (Q tile, dO tile, lse[64], delta[64] (+dummy))
+  constexpr int STAGE = 2 * TILE_BYTES + 1024;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.y, b = bh / p.H, hh = bh % p.H;
+  const int nq = p.nq_main + p.nq_extra, nk = p.nk_main + p.nk_extra;
+  const int col0 = hh * 64;
+  const int h = lane >> 5;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int ki = k0 + (lane & 31);
+  const bool kvalid = ki < nk;
+  const long krow = tok_row(b, kvalid ? ki : nk - 1, p.nk_main, p.B);
+  bf16x8 kf[4], vf[4];
+  load_stationary((const bf16_t*)p.k, p.ldk, krow, col0, h, kf);
+  load_stationary((const bf16_t*)p.v, p.ldv, krow, col0, h, vf);
+  const bf16_t* Qb = (const bf16_t*)p.q;
+  const bf16_t* Ob = (const bf16_t*)p.dout;
+  const float* lse_g = p.lse + ((long)b * p.H + hh) * nq;
+  const float* del_g = p.delta + ((long)b * p.H + hh) * nq;
+  const float c = p.scale * LOG2E;
+  f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+  const int nt = (nq + TROWS - 1) / TROWS;
+  auto stage = [&](int buf, int t) {
+    char* qt = smem + buf * STAGE;
+    stage_tile(Qb, p.ldq, col0, b, t * TROWS, nq, p.nq_main, p.B, qt, wave, lane);
+    stage_tile(Ob, p.ld_do, col0, b, t * TROWS, nq, p.nq_main, p.B, qt + TILE_BYTES, wave, lane);
+    int qq = t * TROWS + lane;
+    if (qq > nq - 1) qq = nq - 1;
+    // one 256-byte piece per wave: wave 0 -> lse, wave 1 -> delta, waves 2,3 -> scratch (keeps vmcnt uniform)
+    const float* src = (wave & 1) ? del_g : lse_g;
+    glds4(src + qq, qt + 2 * TILE_BYTES + wave * 256);
+  };
+  stage(0, 0);
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) {
+      stage(buf ^ 1, t + 1);
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    const char* qt = smem + buf * STAGE;
+    const char* ot = qt + TILE_BYTES;
+    const float* lse_s = reinterpret_cast<const float*>(qt + 2 * TILE_BYTES);
+    const float* del_s = lse_s + 64;
+    const bool tail = (t == nt - 1) && (nq % TROWS != 0);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16 sacc = zero16(), dpacc = zero16();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        sacc = MFMA(row_frag(qt, qb, kk, lane), kf[kk], sacc);
+        dpacc = MFMA(row_frag(ot, qb, kk, lane), vf[kk], dpacc);
+      }
+      f32x16 pacc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 ls = *reinterpret_cast<const float4*>(lse_s + qb * 32 + 8 * g + 4 * h);
+        const float4 dl = *reinterpret_cast<const float4*>(del_s + qb * 32 + 8 * g + 4 * h);
+        const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          float pv = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -lsv[e] * LOG2E));
+          if (tail && (t * TROWS + qb * 32 + acc_row(r, h) >= nq)) pv = 0.f;
+          pacc[r] = pv;
+          sacc[r] = pv * (dpacc[r] - dlv[e]);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 pb = acc_frag(pacc, s), dsb = acc_frag(sacc, s);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          dv[j] = MFMA(tr_frag(ot, qb, s, j, lane), pb, dv[j]);
+          dk[j] = MFMA(tr_frag(qt, qb, s, j, lane), dsb, dk[j]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  if (kvalid) {
+    bf16_t* odk = (bf16_t*)p.dk;
+    bf16_t* odv = (bf16_t*)p.dv;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        ushort4 a, bq;
+        a.x = f32_to_bf16(dk[j][4 * g + 0] * p.scale);
+        a.y = f32_to_bf16(dk[j][4 * g + 1] * p.scale);
+        a.z = f32_to_bf16(dk[j][4 * g + 2] * p.scale);
+        a.w = f32_to_bf16(dk[j][4 * g + 3] * p.scale);
+        bq.x = f32_to_bf16(dv[j][4 * g + 0]);
+        bq.y = f32_to_bf16(dv[j][4 * g + 1]);
+        bq.z = f32_to_bf16(dv[j][4 * g + 2]);
+        bq.w = f32_to_bf16(dv[j][4 * g + 3]);
+        *reinterpret_cast<ushort4*>(odk + krow * p.ld_dk + col0 + 32 * j + 8 * g + 4 * h) = a;
+        *reinterpret_cast<ushort4*>(odv + krow * p.ld_dv + col0 + 32 * j + 8 * g + 4 * h) = bq;
+      }
+  }
+}
+
+// delta[b,h,i] = sum_j dO[i,j] * O[i,j]  (one wave per 4 rows x all heads would be faster; this is ~1% of backward)
+__global__ void k_attn_delta_bf16(AttnP p) {
+  const int nq = p.nq_main + p.nq_extra;
+  const long total = (long)p.B * p.H * nq;
+  const bf16_t* dO = (const bf16_t*)p.dout;
+  const bf16_t* O = (const bf16_t*)p.o;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int hh = (int)(i % p.H);
+    const long t = i / p.H;
+    const int qi = (int)(t % nq);
+    const int b = (int)(t / nq);
+    const long row = tok_row(b, qi, p.nq_main, p.B);
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < 64; j += 8) {
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(dO + row * p.ld_do + hh * 64 + j);
+      const bf16x8 y = *reinterpret_cast<const bf16x8*>(O + row * p.ldo + hh * 64 + j);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a += (float)x[e] * (float)y[e];
+    }
+    p.delta[((long)b * p.H + hh) * nq + qi] = a;
+  }
+}
+
+static bool aligned_ok(const vfm_attn_desc* d, bool bwd) {
+  auto ok = [](const void* ptr, long ld) { return ((uintptr_t)ptr % 16 == 0) && (ld % 8 == 0); };
+  bool r = ok(d->q, d->ldq) && ok(d->k, d->ldk) && ok(d->v, d->ldv) && ok(d->o, d->ldo);
+  if (bwd) r = r && ok(d->dout, d->ld_do) && ok(d->dq, d->ld_dq) && ok(d->dk, d->ld_dk) && ok(d->dv, d->ld_dv);
+  return r;
+}
+
+int vfm_attn_bf16_fwd_impl(const vfm_attn_desc* d, hipStream_t s) {
+  VFM_CHECK(aligned_ok(d, false), VFM_E_ALIGN, "vfm_attn_fwd(bf16): operands must be 16-byte aligned, ld %% 8 == 0");
+  const AttnP p = to_p(d);
+  const int nq = d->nq_main + d->nq_extra;
+  const size_t shm = 4 * TILE_BYTES;
+  hipLaunchKernelGGL(k_attn_bf16_q<false>, dim3(cdiv(nq, 128), d->B * d->H), dim3(256), shm, s, p);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+int vfm_attn_bf16_bwd_impl(const vfm_attn_desc* d, hipStream_t s) {
+  VFM_CHECK(aligned_ok(d, true), VFM_E_ALIGN, "vfm_attn_bwd(bf16): operands must be 16-byte aligned, ld %% 8 == 0");
+  const AttnP p = to_p(d);
+  const int nq = d->nq_main + d->nq_extra, nk = d->nk_main + d->nk_extra;
+  const long total = (long)d->B * d->H * nq;
+  hipLaunchKernelGGL(k_attn_delta_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_attn_bf16_q<true>, dim3(cdiv(nq, 128), d->B * d->H), dim3(256), 4 * TILE_BYTES, s, p);
+  hipLaunchKernelGGL(k_attn_bf16_dkv, dim3(cdiv(nk, 128), d->B * d->H), dim3(256), 2 * (2 * TILE_BYTES + 1024), s, p);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}

@@ -1,24 +1,8 @@
 // Exact-fp32 attention (parity path): one thread per query (forward, dQ) or per key (dK, dV), K/V or Q/dO tiles
 // staged in LDS and broadcast-read.  VALU-bound by design; the bf16 MFMA flash kernels live in attention_bf16.hip.
-#include "common.h"
+#include "attn_common.h"
 
 #define AT_TILE 32
-
-struct AttnP {
-  const void* q; const void* k; const void* v; void* o;
-  int dt; long ldq, ldk, ldv, ldo;
-  int B, H;
-  int nq_main, nq_extra, nk_main, nk_extra;
-  float scale;
-  float* lse;
-  const void* dout; long ld_do;
-  void* dq; void* dk; void* dv; long ld_dq, ld_dk, ld_dv;
-  float* delta;
-};
-
-__device__ __forceinline__ long tok_row(int b, int i, int n_main, int B) {
-  return i < n_main ? (long)b * n_main + i : (long)B * n_main + b;  // the [cls] token lives after all patch tokens
-}
 
 template <int D>
 __global__ void __launch_bounds__(256) k_attn_f32_fwd(AttnP p) {
@@ -217,19 +201,6 @@ __global__ void __launch_bounds__(256) k_attn_f32_dkv(AttnP p) {
       for (int j = 0; j < D; ++j) st_any(p.dk, krow * p.ld_dk + h * D + j, p.dt, acc[j]);
     }
   }
-}
-
-static AttnP to_p(const vfm_attn_desc* d) {
-  AttnP p;
-  p.q = d->q; p.k = d->k; p.v = d->v; p.o = d->o;
-  p.dt = d->dt; p.ldq = d->ldq; p.ldk = d->ldk; p.ldv = d->ldv; p.ldo = d->ldo;
-  p.B = d->B; p.H = d->H;
-  p.nq_main = d->nq_main; p.nq_extra = d->nq_extra; p.nk_main = d->nk_main; p.nk_extra = d->nk_extra;
-  p.scale = d->scale; p.lse = d->lse;
-  p.dout = d->dout; p.ld_do = d->ld_do;
-  p.dq = d->dq; p.dk = d->dk; p.dv = d->dv; p.ld_dq = d->ld_dq; p.ld_dk = d->ld_dk; p.ld_dv = d->ld_dv;
-  p.delta = d->delta;
-  return p;
 }
 
 int vfm_attn_f32_fwd_impl(const vfm_attn_desc* d, hipStream_t s) {

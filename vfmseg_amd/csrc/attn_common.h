@@ -1,0 +1,34 @@
+// Shared by the attention kernels: parameter block and the token-row map of the cls-last layout.
+#pragma once
+#include "common.h"
+
+struct AttnP {
+  const void* q; const void* k; const void* v; void* o;
+  int dt; long ldq, ldk, ldv, ldo;
+  int B, H;
+  int nq_main, nq_extra, nk_main, nk_extra;
+  float scale;
+  float* lse;
+  const void* dout; long ld_do;
+  void* dq; void* dk; void* dv; long ld_dq, ld_dk, ld_dv;
+  float* delta;
+};
+
+__device__ __forceinline__ long tok_row(int b, int i, int n_main, int B) {
+  return i < n_main ? (long)b * n_main + i : (long)B * n_main + b;  // the [cls] token lives after all patch tokens
+}
+
+
+static inline AttnP to_p(const vfm_attn_desc* d) {
+  AttnP p;
+  p.q = d->q; p.k = d->k; p.v = d->v; p.o = d->o;
+  p.dt = d->dt; p.ldq = d->ldq; p.ldk = d->ldk; p.ldv = d->ldv; p.ldo = d->ldo;
+  p.B = d->B; p.H = d->H;
+  p.nq_main = d->nq_main; p.nq_extra = d->nq_extra; p.nk_main = d->nk_main; p.nk_extra = d->nk_extra;
+  p.scale = d->scale; p.lse = d->lse;
+  p.dout = d->dout; p.ld_do = d->ld_do;
+  p.dq = d->dq; p.dk = d->dk; p.dv = d->dv; p.ld_dq = d->ld_dq; p.ld_dk = d->ld_dk; p.ld_dv = d->ld_dv;
+  p.delta = d->delta;
+  return p;
+}
+
