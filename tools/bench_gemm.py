@@ -1,0 +1,52 @@
+"""Micro-benchmark of vfm_gemm (bf16) on the hot-path shapes, next to torch.matmul (hipBLASLt) as a yardstick.
+Interleaved rounds in one process, random data (cdna_hip_programming.md 5.4 rules 24/25)."""
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vfmseg_amd import ops
+
+SHAPES = [  # (M, N, K, out_dtype, label)
+    (4100, 3072, 1088, torch.bfloat16, "qkv+lora fwd"),
+    (4100, 1024, 1024, torch.float32, "proj fwd (+res)"),
+    (4100, 4096, 1024, torch.bfloat16, "fc1 fwd"),
+    (4100, 1024, 4096, torch.float32, "fc2 fwd (+res)"),
+    (4100, 1088, 3072, torch.bfloat16, "qkv dgrad"),
+    (4096, 4096, 4096, torch.bfloat16, "4096^3"),
+    (2048, 1024, 4096, torch.float32, "fusion_conv"),
+    (8192, 1024, 512, torch.bfloat16, "convT2"),
+    (32768, 19, 256, torch.float32, "conv_seg"),
+]
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    dev = "cuda"
+    for (M, N, K, odt, label) in SHAPES:
+        a = torch.randn(M, K, device=dev).bfloat16()
+        b = torch.randn(N, K, device=dev).bfloat16()
+        c = torch.empty(M, N, dtype=odt, device=dev)
+        res = torch.randn(M, N, device=dev) if odt == torch.float32 else None
+        bias = torch.randn(N, device=dev)
+        t_plain = timeit(lambda: ops.gemm(a, b, c))
+        t_epi = timeit(lambda: ops.gemm(a, b, c, bias=bias, residual=res))
+        t_ref = timeit(lambda: torch.matmul(a, b.t()))
+        fl = 2.0 * M * N * K
+        print(f"{label:18s} M={M:5d} N={N:5d} K={K:5d}  ours {t_plain*1e3:8.1f} us {fl/t_plain/1e9:7.1f} TF | +bias/res {t_epi*1e3:8.1f} us "
+              f"{fl/t_epi/1e9:7.1f} TF | torch {t_ref*1e3:8.1f} us {fl/t_ref/1e9:7.1f} TF", flush=True)
+
+
+if __name__ == "__main__":
+    main()
