@@ -124,6 +124,8 @@ typedef struct vfm_gemm_desc {
   long batch, stride_a, stride_b, stride_c;
 } vfm_gemm_desc;
 int vfm_gemm(const vfm_gemm_desc* d, void* stream);
+/* tuning / experiment knobs (e.g. key "gemm_cfg": force a bf16 GEMM tile configuration, -1 = heuristic) */
+int vfm_tune(const char* key, int value);
 
 /* ---- attention -------------------------------------------------------------------------------- */
 /* softmax(q k^T * scale) v per (image, head)  - xformers memory_efficient_attention (attention.py:73-89,

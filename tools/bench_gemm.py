@@ -40,12 +40,22 @@ def main():
         c = torch.empty(M, N, dtype=odt, device=dev)
         res = torch.randn(M, N, device=dev) if odt == torch.float32 else None
         bias = torch.randn(N, device=dev)
-        t_plain = timeit(lambda: ops.gemm(a, b, c))
-        t_epi = timeit(lambda: ops.gemm(a, b, c, bias=bias, residual=res))
-        t_ref = timeit(lambda: torch.matmul(a, b.t()))
         fl = 2.0 * M * N * K
-        print(f"{label:18s} M={M:5d} N={N:5d} K={K:5d}  ours {t_plain*1e3:8.1f} us {fl/t_plain/1e9:7.1f} TF | +bias/res {t_epi*1e3:8.1f} us "
-              f"{fl/t_epi/1e9:7.1f} TF | torch {t_ref*1e3:8.1f} us {fl/t_ref/1e9:7.1f} TF", flush=True)
+        ref = (a.float() @ b.float().t())
+        res_line = []
+        cfgs = [int(x) for x in os.environ.get("CFGS", "-1,0,1,2,3,5,6,7,8,9,10,11").split(",")]
+        for cfg in cfgs:
+            ops.tune("gemm_cfg", cfg)
+            try:
+                ops.gemm(a, b, c)
+                err = ((c.float() - ref).abs().max() / ref.abs().max()).item()
+                t = timeit(lambda: ops.gemm(a, b, c, bias=bias, residual=res))
+                res_line.append(f"c{cfg}:{fl/t/1e9:6.0f}" + ("" if err < 2e-2 else f"(ERR {err:.1e})"))
+            except Exception as ex:
+                res_line.append(f"c{cfg}:fail")
+        ops.tune("gemm_cfg", -1)
+        t_ref = timeit(lambda: torch.matmul(a, b.t()))
+        print(f"{label:16s} M={M:5d} N={N:5d} K={K:5d} torch {fl/t_ref/1e9:6.0f} TF | " + " ".join(res_line), flush=True)
 
 
 if __name__ == "__main__":

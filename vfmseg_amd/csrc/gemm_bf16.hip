@@ -1,0 +1,337 @@
+// bf16 MFMA GEMM for gfx950:  C[M,N] = epilogue(alpha * A[M,K] * B[N,K]^T), fp32 accumulation.
+//
+//   tile BM x BN x 64, WAVES = WM_W x WN_W waves, each wave a (BM/WM_W) x (BN/WN_W) sub-tile of 32x32x16 MFMAs
+//   operands staged by LDS-DMA (global_load_lds_dwordx4) into an NS-deep ring of LDS stages, prefetch distance NS-1,
+//     ONE raw s_barrier per K-step, counted s_waitcnt vmcnt(N) so the prefetch stays in flight across the barrier
+//   LDS image [rows][64] bf16 = 128-B rows; 16-B chunk c of row r lives at chunk c ^ ((r>>1)&7): the swizzle is applied
+//     to the per-lane SOURCE address (the DMA destination is lane-linear) and again on the ds_read_b128 fragment reads
+//   epilogue through LDS: accumulators -> row-major fp32 tile -> 16-byte vector loads/stores of bias / residual / aux / C
+//   XCD-aware bijective tile mapping (blocks b, b+8 share an XCD's L2)
+#include "gemm_epilogue.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define BK 64
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else static_assert(N < 0, "add the vmcnt immediate");
+}
+
+// vector epilogue on 4 consecutive columns (all pointers/leading dims 16-byte compatible; checked on the host)
+__device__ __forceinline__ void epi_store4(const EpiParams& e, long zoff, long m, long n, float4 v) {
+  float x[4] = {v.x * e.alpha, v.y * e.alpha, v.z * e.alpha, v.w * e.alpha};
+  if (e.bias) {
+    const long bn = n % e.bias_mod;  // bias_mod % 4 == 0 on this path
+    const float4 b = *reinterpret_cast<const float4*>(e.bias + bn);
+    x[0] += b.x, x[1] += b.y, x[2] += b.z, x[3] += b.w;
+  }
+  if (e.C2) {
+    const long o = zoff + m * e.ldc2 + n;
+    if (e.c2_dt == VFM_BF16) {
+      ushort4 p = {f32_to_bf16(x[0]), f32_to_bf16(x[1]), f32_to_bf16(x[2]), f32_to_bf16(x[3])};
+      *reinterpret_cast<ushort4*>((bf16_t*)e.C2 + o) = p;
+    } else {
+      *reinterpret_cast<float4*>((float*)e.C2 + o) = make_float4(x[0], x[1], x[2], x[3]);
+    }
+  }
+  if (e.ep_mode == VFM_EP_GELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = gelu_f(x[i]);
+  } else if (e.ep_mode == VFM_EP_RELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = fmaxf(x[i], 0.f);
+  } else if (e.ep_mode == VFM_EP_MUL_GELU_GRAD || e.ep_mode == VFM_EP_MUL) {
+    float a[4];
+    const long o = m * e.ld_aux + n;
+    if (e.aux_dt == VFM_BF16) {
+      const ushort4 p = *reinterpret_cast<const ushort4*>((const bf16_t*)e.aux + o);
+      a[0] = bf16_to_f32(p.x), a[1] = bf16_to_f32(p.y), a[2] = bf16_to_f32(p.z), a[3] = bf16_to_f32(p.w);
+    } else {
+      const float4 p = *reinterpret_cast<const float4*>((const float*)e.aux + o);
+      a[0] = p.x, a[1] = p.y, a[2] = p.z, a[3] = p.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] *= (e.ep_mode == VFM_EP_MUL ? a[i] : gelu_grad_f(a[i]));
+  }
+  if (e.colscale) {
+    const float4 s = *reinterpret_cast<const float4*>(e.colscale + n);
+    x[0] *= s.x, x[1] *= s.y, x[2] *= s.z, x[3] *= s.w;
+  }
+  if (e.residual) {
+    const long o = zoff + m * e.ldr + n;
+    if (e.r_dt == VFM_BF16) {
+      const ushort4 p = *reinterpret_cast<const ushort4*>((const bf16_t*)e.residual + o);
+      x[0] += bf16_to_f32(p.x), x[1] += bf16_to_f32(p.y), x[2] += bf16_to_f32(p.z), x[3] += bf16_to_f32(p.w);
+    } else {
+      const float4 p = *reinterpret_cast<const float4*>((const float*)e.residual + o);
+      x[0] += p.x, x[1] += p.y, x[2] += p.z, x[3] += p.w;
+    }
+  }
+  const long o = zoff + m * e.ldc + n;
+  if (e.c_dt == VFM_BF16) {
+    ushort4 p = {f32_to_bf16(x[0]), f32_to_bf16(x[1]), f32_to_bf16(x[2]), f32_to_bf16(x[3])};
+    *reinterpret_cast<ushort4*>((bf16_t*)e.C + o) = p;
+  } else {
+    *reinterpret_cast<float4*>((float*)e.C + o) = make_float4(x[0], x[1], x[2], x[3]);
+  }
+}
+
+template <int BM, int BN, int WM_W, int WN_W, int NS>
+struct Cfg {
+  static constexpr int WAVES = WM_W * WN_W;
+  static constexpr int THREADS = WAVES * 64;
+  static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int A_PIECES = BM / 8 / WAVES, B_PIECES = BN / 8 / WAVES;  // 1-KiB LDS-DMA pieces per wave
+  static constexpr int PIECES = A_PIECES + B_PIECES;
+  static constexpr int WM = BM / WM_W, WN = BN / WN_W;
+  static constexpr int MI = WM / 32, NI = WN / 32;
+  static constexpr int EPI_LD = WN + 4;                       // fp32 row stride of the epilogue image
+  static constexpr int EPI_BYTES = WAVES * 32 * EPI_LD * 4;   // one 32-row slab per wave at a time
+  static constexpr int SMEM = (NS * STAGE_BYTES > EPI_BYTES) ? NS * STAGE_BYTES : EPI_BYTES;
+  static_assert(BM % (8 * WAVES) == 0 && BN % (8 * WAVES) == 0, "tile rows must split into whole DMA pieces per wave");
+  static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA");
+};
+
+template <int BM, int BN, int WM_W, int WN_W, int NS, bool VEC>
+__global__ void __launch_bounds__(WM_W* WN_W * 64)
+    k_gemm_bf16(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, long M, long N, long K,
+                long stride_a, long stride_b, long stride_c, int tiles_m, int tiles_n, EpiParams e) {
+  using C = Cfg<BM, BN, WM_W, WN_W, NS>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN_W, wn = wave % WN_W;
+
+  // ---- XCD-aware tile mapping
+  const int ntiles = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GM = 8;
+  const int group = bid / (GM * tiles_n);
+  const int first_m = group * GM;
+  const int gsz = min(tiles_m - first_m, GM);
+  const int tm = first_m + (bid % (GM * tiles_n)) % gsz;
+  const int tn = (bid % (GM * tiles_n)) / gsz;
+  const long m0 = (long)tm * BM, n0 = (long)tn * BN;
+  const long z = blockIdx.y;
+  const bf16_t* Ab = A + z * stride_a;
+  const bf16_t* Bb = B + z * stride_b;
+
+  // ---- per-lane DMA sources (row clamp keeps every load in bounds; clamped rows are never stored)
+  const int lr = lane >> 3, pc = lane & 7;
+  const bf16_t* a_src[C::A_PIECES];
+  const bf16_t* b_src[C::B_PIECES];
+#pragma unroll
+  for (int j = 0; j < C::A_PIECES; ++j) {
+    const int r = (wave * C::A_PIECES + j) * 8 + lr;
+    long gm = m0 + r;
+    if (gm > M - 1) gm = M - 1;
+    a_src[j] = Ab + gm * lda + ((pc ^ ((r >> 1) & 7)) << 3);
+  }
+#pragma unroll
+  for (int j = 0; j < C::B_PIECES; ++j) {
+    const int r = (wave * C::B_PIECES + j) * 8 + lr;
+    long gn = n0 + r;
+    if (gn > N - 1) gn = N - 1;
+    b_src[j] = Bb + gn * ldb + ((pc ^ ((r >> 1) & 7)) << 3);
+  }
+  auto stage = [&](int slot, long k0) {
+    char* sa = smem + slot * C::STAGE_BYTES;
+    char* sb = sa + C::A_BYTES;
+#pragma unroll
+    for (int j = 0; j < C::A_PIECES; ++j) glds16(a_src[j] + k0, sa + (wave * C::A_PIECES + j) * 1024);
+#pragma unroll
+    for (int j = 0; j < C::B_PIECES; ++j) glds16(b_src[j] + k0, sb + (wave * C::B_PIECES + j) * 1024);
+  };
+
+  f32x16 acc[C::MI][C::NI];
+#pragma unroll
+  for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  int a_off[C::MI], a_sw[C::MI], b_off[C::NI], b_sw[C::NI];
+#pragma unroll
+  for (int i = 0; i < C::MI; ++i) {
+    const int r = wm * C::WM + i * 32 + fr;
+    a_off[i] = r * 128;
+    a_sw[i] = (r >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < C::NI; ++j) {
+    const int r = wn * C::WN + j * 32 + fr;
+    b_off[j] = r * 128;
+    b_sw[j] = (r >> 1) & 7;
+  }
+
+  const int nk = (int)(K / BK);
+  // ---- prologue: fill NS-1 stages
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nk) stage(s, (long)s * BK);
+
+  for (int t = 0; t < nk; ++t) {
+    // tile t must have landed: groups issued so far cover tiles t .. min(t+NS-2, nk-1)
+    const int inflight = min(NS - 2, nk - 1 - t);  // younger groups allowed to stay in flight
+    if (inflight >= NS - 2 && NS >= 2) wait_vmcnt<(NS - 2) * C::PIECES>();
+    else if (NS >= 4 && inflight == NS - 3) wait_vmcnt<(NS >= 3 ? (NS - 3) : 0) * C::PIECES>();
+    else if (NS >= 5 && inflight == NS - 4) wait_vmcnt<(NS >= 4 ? (NS - 4) : 0) * C::PIECES>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // everyone's pieces of tile t are in LDS; everyone finished reading tile t-1
+    if (t + NS - 1 < nk) stage((t + NS - 1) % NS, (long)(t + NS - 1) * BK);  // refills the slot tile t-1 used
+    const char* sa = smem + (t % NS) * C::STAGE_BYTES;
+    const char* sb = sa + C::A_BYTES;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8 af[C::MI], bfr[C::NI];
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + a_off[i] + (((2 * s + fh) ^ a_sw[i]) << 4));
+#pragma unroll
+      for (int j = 0; j < C::NI; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j] + (((2 * s + fh) ^ b_sw[j]) << 4));
+#pragma unroll
+      for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+        for (int j = 0; j < C::NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue
+  const long zoff = z * stride_c;
+  if constexpr (VEC) {
+    __syncthreads();  // all LDS reads of the last stage are done; the ring is reused as the epilogue image
+    float* img = reinterpret_cast<float*>(smem) + wave * 32 * C::EPI_LD;
+    constexpr int LANES_PER_ROW = C::WN / 4;          // float4 per lane
+    constexpr int ROWS_PER_PASS = 64 / LANES_PER_ROW;
+    const int rr = lane / LANES_PER_ROW, cc = (lane % LANES_PER_ROW) * 4;
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) {
+#pragma unroll
+      for (int j = 0; j < C::NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) img[((r & 3) + 8 * (r >> 2) + 4 * fh) * C::EPI_LD + j * 32 + fr] = acc[i][j][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pass = 0; pass < 32 / ROWS_PER_PASS; ++pass) {
+        const int row = pass * ROWS_PER_PASS + rr;
+        const long m = m0 + wm * C::WM + i * 32 + row;
+        const long n = n0 + wn * C::WN + cc;
+        const float4 v = *reinterpret_cast<const float4*>(img + row * C::EPI_LD + cc);
+        if (m < M && n < N) epi_store4(e, zoff, m, n, v);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+      for (int j = 0; j < C::NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long m = m0 + wm * C::WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+          const long n = n0 + wn * C::WN + j * 32 + fr;
+          if (m < M && n < N) epi_store(e, zoff, m, n, acc[i][j][r]);
+        }
+  }
+}
+
+template <int BM, int BN, int WM_W, int WN_W, int NS>
+static void launch_cfg(const vfm_gemm_desc* d, hipStream_t s, bool vec) {
+  using C = Cfg<BM, BN, WM_W, WN_W, NS>;
+  const int tiles_m = cdiv(d->M, BM), tiles_n = cdiv(d->N, BN);
+  const long batch = d->batch > 0 ? d->batch : 1;
+  static bool attr[2] = {false, false};
+  if (!attr[vec]) {
+    if (vec) (void)hipFuncSetAttribute((const void*)k_gemm_bf16<BM, BN, WM_W, WN_W, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+    else (void)hipFuncSetAttribute((const void*)k_gemm_bf16<BM, BN, WM_W, WN_W, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+    attr[vec] = true;
+  }
+  dim3 grid(tiles_m * tiles_n, (unsigned)batch), blk(C::THREADS);
+  if (vec)
+    hipLaunchKernelGGL((k_gemm_bf16<BM, BN, WM_W, WN_W, NS, true>), grid, blk, C::SMEM, s, (const bf16_t*)d->A, d->sa_m, (const bf16_t*)d->B,
+                       d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c, tiles_m, tiles_n, make_epi(d));
+  else
+    hipLaunchKernelGGL((k_gemm_bf16<BM, BN, WM_W, WN_W, NS, false>), grid, blk, C::SMEM, s, (const bf16_t*)d->A, d->sa_m, (const bf16_t*)d->B,
+                       d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c, tiles_m, tiles_n, make_epi(d));
+}
+
+static int g_force_cfg = -1;
+extern "C" int vfm_tune(const char* key, int value) {
+  if (key && strcmp(key, "gemm_cfg") == 0) {
+    g_force_cfg = value;
+    return VFM_OK;
+  }
+  VFM_FAIL(VFM_E_INVAL, "vfm_tune: unknown key");
+}
+
+static bool vec_ok(const vfm_gemm_desc* d) {
+  auto a16 = [](const void* p) { return ((uintptr_t)p % 16) == 0; };
+  const long bm = d->bias_mod > 0 ? d->bias_mod : d->N;
+  bool ok = (d->N % 4 == 0) && (d->ldc % 4 == 0) && a16(d->C) && (d->stride_c % 4 == 0);
+  if (d->bias) ok = ok && a16(d->bias) && (bm % 4 == 0);
+  if (d->colscale) ok = ok && a16(d->colscale);
+  if (d->residual) ok = ok && a16(d->residual) && (d->ldr % 4 == 0);
+  if (d->aux) ok = ok && a16(d->aux) && (d->ld_aux % 4 == 0);
+  if (d->C2) ok = ok && a16(d->C2) && (d->ldc2 % 4 == 0);
+  return ok;
+}
+
+// config ids (also the sweep space of tools/bench_gemm.py)
+//  0: 128x128 2x2 NS2   1: 128x128 2x2 NS3   2: 128x128 2x2 NS4   3: 128x64 2x2 NS3   4: 128x64 2x2 NS4
+//  5: 256x128 2x2 NS2   6: 256x128 2x2 NS3   7: 256x128 4x2 NS3   8: 256x256 2x4 NS2  9: 128x256 2x2 NS3
+//  10: 64x64 2x2 NS4    11: 256x64 4x2 NS3
+int vfm_gemm_bf16_impl(const vfm_gemm_desc* d, hipStream_t s) {
+  const bool vec = vec_ok(d);
+  int cfg = g_force_cfg;
+  if (cfg < 0) {
+    const long t128 = (long)cdiv(d->M, 128) * cdiv(d->N, 128);
+    if (d->N <= 64) cfg = 3;
+    else if (t128 >= 1024) cfg = 6;   // plenty of tiles: the larger tile halves L2 traffic per flop
+    else cfg = 1;
+  }
+  switch (cfg) {
+    case 0: launch_cfg<128, 128, 2, 2, 2>(d, s, vec); break;
+    case 1: launch_cfg<128, 128, 2, 2, 3>(d, s, vec); break;
+    case 2: launch_cfg<128, 128, 2, 2, 4>(d, s, vec); break;
+    case 3: launch_cfg<128, 64, 2, 2, 3>(d, s, vec); break;
+    case 4: launch_cfg<128, 64, 2, 2, 4>(d, s, vec); break;
+    case 5: launch_cfg<256, 128, 2, 2, 2>(d, s, vec); break;
+    case 6: launch_cfg<256, 128, 2, 2, 3>(d, s, vec); break;
+    case 7: launch_cfg<256, 128, 4, 2, 3>(d, s, vec); break;
+    case 8: launch_cfg<256, 256, 2, 4, 2>(d, s, vec); break;
+    case 9: launch_cfg<128, 256, 2, 2, 3>(d, s, vec); break;
+    case 10: launch_cfg<64, 64, 2, 2, 4>(d, s, vec); break;
+    case 11: launch_cfg<256, 64, 4, 2, 3>(d, s, vec); break;
+    default: VFM_FAIL(VFM_E_INVAL, "vfm_gemm(bf16): unknown config %d", cfg);
+  }
+  return VFM_OK;
+}

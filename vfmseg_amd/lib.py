@@ -70,6 +70,7 @@ SIGNATURES = {
     "vfm_bn_bwd_reduce": [vp, ci, vp, vp, vp, vp, cf, ci, vp, vp, cl, cl, vp],
     "vfm_bn_bwd_apply": [vp, ci, vp, vp, vp, vp, cf, ci, vp, cf, vp, cl, cl, vp],
     "vfm_gemm": [C.POINTER(GemmDesc), vp],
+    "vfm_tune": [C.c_char_p, ci],
     "vfm_attn_fwd": [C.POINTER(AttnDesc), vp],
     "vfm_attn_bwd": [C.POINTER(AttnDesc), vp],
     "vfm_patchify": [vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, ci, cl, ci, vp],

@@ -266,6 +266,11 @@ def gemm(a, b, c, *, alpha=1.0, bias=None, bias_mod=0, colscale=None, residual=N
     return c
 
 
+def tune(key, value):
+    lib = L.load()
+    L.check(lib.vfm_tune(key.encode(), int(value)), "vfm_tune")
+
+
 def _attn_desc(q, k, v, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, lse):
     a = L.AttnDesc()
     a.q, a.k, a.v, a.o = L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o)
