@@ -7,6 +7,7 @@ import torch
 from vfmseg_amd import ops
 
 SHAPES = [  # (M, N, K, out_dtype, label)
+    (4096, 4096, 1024, torch.bfloat16, "fc1 fwd M4096"),
     (4100, 3072, 1088, torch.bfloat16, "qkv+lora fwd"),
     (4100, 1024, 1024, torch.float32, "proj fwd (+res)"),
     (4100, 4096, 1024, torch.bfloat16, "fc1 fwd"),
@@ -43,7 +44,7 @@ def main():
         fl = 2.0 * M * N * K
         ref = (a.float() @ b.float().t())
         res_line = []
-        cfgs = [int(x) for x in os.environ.get("CFGS", "-1,0,1,2,3,5,6,7,8,9,10,11").split(",")]
+        cfgs = [int(x) for x in os.environ.get("CFGS", "0,3,7,10,12,13,14,15,16,17,18,19").split(",")]
         for cfg in cfgs:
             ops.tune("gemm_cfg", cfg)
             try:

@@ -209,17 +209,28 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
     if (t + NS - 1 < nk) stage((t + NS - 1) % NS, (long)(t + NS - 1) * BK);  // refills the slot tile t-1 used
     const char* sa = smem + (t % NS) * C::STAGE_BYTES;
     const char* sb = sa + C::A_BYTES;
+    // fragment double buffering: the ds_reads of k-step s+1 are issued before the MFMAs of k-step s
+    bf16x8 af[2][C::MI], bfr[2][C::NI];
+#pragma unroll
+    for (int i = 0; i < C::MI; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(sa + a_off[i] + (((fh) ^ a_sw[i]) << 4));
+#pragma unroll
+    for (int j = 0; j < C::NI; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j] + (((fh) ^ b_sw[j]) << 4));
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
-      bf16x8 af[C::MI], bfr[C::NI];
+      const int cur = s & 1, nxt = cur ^ 1;
+      if (s + 1 < BK / 16) {
 #pragma unroll
-      for (int i = 0; i < C::MI; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + a_off[i] + (((2 * s + fh) ^ a_sw[i]) << 4));
+        for (int i = 0; i < C::MI; ++i)
+          af[nxt][i] = *reinterpret_cast<const bf16x8*>(sa + a_off[i] + (((2 * (s + 1) + fh) ^ a_sw[i]) << 4));
 #pragma unroll
-      for (int j = 0; j < C::NI; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j] + (((2 * s + fh) ^ b_sw[j]) << 4));
+        for (int j = 0; j < C::NI; ++j)
+          bfr[nxt][j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j] + (((2 * (s + 1) + fh) ^ b_sw[j]) << 4));
+      }
 #pragma unroll
       for (int i = 0; i < C::MI; ++i)
 #pragma unroll
-        for (int j = 0; j < C::NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < C::NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
     }
   }
 
@@ -308,7 +319,8 @@ static bool vec_ok(const vfm_gemm_desc* d) {
 // config ids (also the sweep space of tools/bench_gemm.py)
 //  0: 128x128 2x2 NS2   1: 128x128 2x2 NS3   2: 128x128 2x2 NS4   3: 128x64 2x2 NS3   4: 128x64 2x2 NS4
 //  5: 256x128 2x2 NS2   6: 256x128 2x2 NS3   7: 256x128 4x2 NS3   8: 256x256 2x4 NS2  9: 128x256 2x2 NS3
-//  10: 64x64 2x2 NS4    11: 256x64 4x2 NS3
+//  10: 64x64 2x2 NS4    11: 256x64 4x2 NS3    12: 128x128 4x2 NS2  13: 128x128 4x2 NS3  14: 256x128 4x2 NS2
+//  15: 256x256 4x2 NS2  16: 256x256 4x4 NS2   17: 128x128 2x4 NS2  18: 64x128 2x2 NS2   19: 128x64 2x2 NS2
 int vfm_gemm_bf16_impl(const vfm_gemm_desc* d, hipStream_t s) {
   const bool vec = vec_ok(d);
   int cfg = g_force_cfg;
@@ -331,6 +343,14 @@ int vfm_gemm_bf16_impl(const vfm_gemm_desc* d, hipStream_t s) {
     case 9: launch_cfg<128, 256, 2, 2, 3>(d, s, vec); break;
     case 10: launch_cfg<64, 64, 2, 2, 4>(d, s, vec); break;
     case 11: launch_cfg<256, 64, 4, 2, 3>(d, s, vec); break;
+    case 12: launch_cfg<128, 128, 4, 2, 2>(d, s, vec); break;
+    case 13: launch_cfg<128, 128, 4, 2, 3>(d, s, vec); break;
+    case 14: launch_cfg<256, 128, 4, 2, 2>(d, s, vec); break;
+    case 15: launch_cfg<256, 256, 4, 2, 2>(d, s, vec); break;
+    case 16: launch_cfg<256, 256, 4, 4, 2>(d, s, vec); break;
+    case 17: launch_cfg<128, 128, 2, 4, 2>(d, s, vec); break;
+    case 18: launch_cfg<64, 128, 2, 2, 2>(d, s, vec); break;
+    case 19: launch_cfg<128, 64, 2, 2, 2>(d, s, vec); break;
     default: VFM_FAIL(VFM_E_INVAL, "vfm_gemm(bf16): unknown config %d", cfg);
   }
   return VFM_OK;
