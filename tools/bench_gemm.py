@@ -44,7 +44,7 @@ def main():
         fl = 2.0 * M * N * K
         ref = (a.float() @ b.float().t())
         res_line = []
-        cfgs = [int(x) for x in os.environ.get("CFGS", "0,3,7,10,12,13,14,15,16,17,18,19").split(",")]
+        cfgs = [int(x) for x in os.environ.get("CFGS", "0,12,16,17,18,19").split(",")]
         for cfg in cfgs:
             ops.tune("gemm_cfg", cfg)
             try:

@@ -135,7 +135,9 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   const int group = bid / (GM * tiles_n);
   const int first_m = group * GM;
   const int gsz = min(tiles_m - first_m, GM);
-  const int tm = first_m + (bid % (GM * tiles_n)) % gsz;
+  // the last tile row may be a nearly empty tail (e.g. the 4 [cls] rows of M = 4096 + 4): such tiles skip the MFMAs of
+  // row blocks beyond M, so they are short - dispatch them FIRST and let their CUs pick up regular tiles early
+  const int tm = tiles_m - 1 - (first_m + (bid % (GM * tiles_n)) % gsz);
   const int tn = (bid % (GM * tiles_n)) / gsz;
   const long m0 = (long)tm * BM, n0 = (long)tn * BN;
   const long z = blockIdx.y;
@@ -178,6 +180,9 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int fr = lane & 31, fh = lane >> 5;
+  bool live[C::MI];  // wave-uniform: does this 32-row block hold any row < M ?
+#pragma unroll
+  for (int i = 0; i < C::MI; ++i) live[i] = (m0 + wm * C::WM + i * 32) < M;
   int a_off[C::MI], a_sw[C::MI], b_off[C::NI], b_sw[C::NI];
 #pragma unroll
   for (int i = 0; i < C::MI; ++i) {
@@ -228,9 +233,11 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
       }
 #pragma unroll
       for (int i = 0; i < C::MI; ++i)
+        if (live[i]) {
 #pragma unroll
-        for (int j = 0; j < C::NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < C::NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+        }
     }
   }
 
