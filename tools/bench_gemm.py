@@ -8,6 +8,9 @@ from vfmseg_amd import ops
 
 SHAPES = [  # (M, N, K, out_dtype, label)
     (4096, 4096, 1024, torch.bfloat16, "fc1 fwd M4096"),
+    (4096, 1024, 1024, torch.float32, "proj M4096"),
+    (4, 4096, 1024, torch.bfloat16, "skinny fc1"),
+    (4, 1024, 4096, torch.float32, "skinny fc2"),
     (4100, 3072, 1088, torch.bfloat16, "qkv+lora fwd"),
     (4100, 1024, 1024, torch.float32, "proj fwd (+res)"),
     (4100, 4096, 1024, torch.bfloat16, "fc1 fwd"),
@@ -44,7 +47,7 @@ def main():
         fl = 2.0 * M * N * K
         ref = (a.float() @ b.float().t())
         res_line = []
-        cfgs = [int(x) for x in os.environ.get("CFGS", "0,12,16,17,18,19").split(",")]
+        cfgs = [int(x) for x in os.environ.get("CFGS", "0,7,12,14,16,17,18,19").split(",")]
         for cfg in cfgs:
             ops.tune("gemm_cfg", cfg)
             try:

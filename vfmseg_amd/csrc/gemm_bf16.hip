@@ -135,9 +135,7 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   const int group = bid / (GM * tiles_n);
   const int first_m = group * GM;
   const int gsz = min(tiles_m - first_m, GM);
-  // the last tile row may be a nearly empty tail (e.g. the 4 [cls] rows of M = 4096 + 4): such tiles skip the MFMAs of
-  // row blocks beyond M, so they are short - dispatch them FIRST and let their CUs pick up regular tiles early
-  const int tm = tiles_m - 1 - (first_m + (bid % (GM * tiles_n)) % gsz);
+  const int tm = first_m + (bid % (GM * tiles_n)) % gsz;
   const int tn = (bid % (GM * tiles_n)) / gsz;
   const long m0 = (long)tm * BM, n0 = (long)tn * BN;
   const long z = blockIdx.y;
@@ -180,9 +178,6 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int fr = lane & 31, fh = lane >> 5;
-  bool live[C::MI];  // wave-uniform: does this 32-row block hold any row < M ?
-#pragma unroll
-  for (int i = 0; i < C::MI; ++i) live[i] = (m0 + wm * C::WM + i * 32) < M;
   int a_off[C::MI], a_sw[C::MI], b_off[C::NI], b_sw[C::NI];
 #pragma unroll
   for (int i = 0; i < C::MI; ++i) {
@@ -233,11 +228,9 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
       }
 #pragma unroll
       for (int i = 0; i < C::MI; ++i)
-        if (live[i]) {
 #pragma unroll
-          for (int j = 0; j < C::NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < C::NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
     }
   }
 
@@ -302,10 +295,62 @@ static void launch_cfg(const vfm_gemm_desc* d, hipStream_t s, bool vec) {
                        d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c, tiles_m, tiles_n, make_epi(d));
 }
 
+
+// ------------------------------------------------------------------------------------------------ skinny tail
+// M <= 32 rows (the [cls] rows that follow the 128-aligned patch-token rows): one block = 32 rows x 32 columns, the 4
+// waves split K four ways, operands go straight from global memory into MFMA fragments (no LDS staging, no barriers
+// in the loop: B is streamed exactly once), partial sums meet in LDS for the shared epilogue.
+__global__ void __launch_bounds__(256) k_gemm_bf16_skinny(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
+                                                          long M, long N, long K, long stride_a, long stride_b, long stride_c,
+                                                          EpiParams e) {
+  __shared__ float part[4][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const long n0 = (long)blockIdx.x * 32;
+  const long z = blockIdx.y;
+  long am = fr;
+  if (am > M - 1) am = M - 1;
+  long bn = n0 + fr;
+  if (bn > N - 1) bn = N - 1;
+  const bf16_t* ap = A + z * stride_a + am * lda + fh * 8;
+  const bf16_t* bp = B + z * stride_b + bn * ldb + fh * 8;
+  const long kq = K / 4;  // K % 64 == 0 -> kq % 16 == 0
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const long kbeg = wave * kq, kend = kbeg + kq;
+#pragma unroll 4
+  for (long k = kbeg; k < kend; k += 16) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + k);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp + k);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * fh][fr] = acc[r];
+  __syncthreads();
+  const long zoff = z * stride_c;
+  for (int i = tid; i < 32 * 32; i += 256) {
+    const int row = i >> 5, col = i & 31;
+    const long m = row, n = n0 + col;
+    if (m < M && n < N) epi_store(e, zoff, m, n, part[0][row][col] + part[1][row][col] + part[2][row][col] + part[3][row][col]);
+  }
+}
+
+static void launch_skinny(const vfm_gemm_desc* d, hipStream_t s) {
+  const long batch = d->batch > 0 ? d->batch : 1;
+  hipLaunchKernelGGL(k_gemm_bf16_skinny, dim3(cdiv(d->N, 32), (unsigned)batch), dim3(256), 0, s, (const bf16_t*)d->A, d->sa_m,
+                     (const bf16_t*)d->B, d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c, make_epi(d));
+}
+
 static int g_force_cfg = -1;
+static int g_split_tail = 1;
 extern "C" int vfm_tune(const char* key, int value) {
   if (key && strcmp(key, "gemm_cfg") == 0) {
     g_force_cfg = value;
+    return VFM_OK;
+  }
+  if (key && strcmp(key, "gemm_split_tail") == 0) {
+    g_split_tail = value;
     return VFM_OK;
   }
   VFM_FAIL(VFM_E_INVAL, "vfm_tune: unknown key");
@@ -328,7 +373,38 @@ static bool vec_ok(const vfm_gemm_desc* d) {
 //  5: 256x128 2x2 NS2   6: 256x128 2x2 NS3   7: 256x128 4x2 NS3   8: 256x256 2x4 NS2  9: 128x256 2x2 NS3
 //  10: 64x64 2x2 NS4    11: 256x64 4x2 NS3    12: 128x128 4x2 NS2  13: 128x128 4x2 NS3  14: 256x128 4x2 NS2
 //  15: 256x256 4x2 NS2  16: 256x256 4x4 NS2   17: 128x128 2x4 NS2  18: 64x128 2x2 NS2   19: 128x64 2x2 NS2
-int vfm_gemm_bf16_impl(const vfm_gemm_desc* d, hipStream_t s) {
+static int gemm_main(const vfm_gemm_desc* d, hipStream_t s);
+
+int vfm_gemm_bf16_impl(const vfm_gemm_desc* d0, hipStream_t s) {
+  // A few rows past a 128-row boundary (M = B*1024 patch tokens + B [cls] tokens) would cost a whole extra row of
+  // latency-bound tiles: peel them off into the skinny kernel.
+  const long tail = d0->M % 128;
+  if (g_split_tail && d0->M > 512 && tail > 0 && tail <= 32 && (d0->batch <= 1)) {
+    vfm_gemm_desc dm = *d0, dt = *d0;
+    const long mm = d0->M - tail;
+    dm.M = mm;
+    dt.M = tail;
+    auto adv = [&](const void* p, int dt_, long ld) -> const void* {
+      return p ? (const void*)((const char*)p + mm * ld * (dt_ == VFM_BF16 ? 2 : 4)) : nullptr;
+    };
+    dt.A = adv(d0->A, VFM_BF16, d0->sa_m);
+    dt.C = (void*)adv(d0->C, d0->c_dt, d0->ldc);
+    dt.residual = adv(d0->residual, d0->r_dt, d0->ldr);
+    dt.aux = adv(d0->aux, d0->aux_dt, d0->ld_aux);
+    dt.C2 = (void*)adv(d0->C2, d0->c2_dt, d0->ldc2);
+    int rc = gemm_main(&dm, s);
+    if (rc) return rc;
+    launch_skinny(&dt, s);
+    return VFM_OK;
+  }
+  if (d0->M <= 32 && d0->N >= 32) {
+    launch_skinny(d0, s);
+    return VFM_OK;
+  }
+  return gemm_main(d0, s);
+}
+
+static int gemm_main(const vfm_gemm_desc* d, hipStream_t s) {
   const bool vec = vec_ok(d);
   int cfg = g_force_cfg;
   if (cfg < 0) {
