@@ -150,18 +150,24 @@ extern "C" int vfm_scale_by_device_scalar(float* y, const float* scalar, long n,
 }
 
 // ------------------------------------------------------------------------------------------------ column sums
-// stage 1: grid (cdiv(cols,64), 64): block (64 cols x 4 row-lanes) sums a strided row slice -> ws[by, c]
+// stage 1: block = CT columns x (256/CT) row lanes; grid (cdiv(cols,CT), parts): ws[part, c] = sum over the part's rows.
+// CT adapts to narrow matrices (e.g. 19 logit columns) so that all 256 threads stay busy.
 template <typename T>
-__global__ void k_colsum1(const T* __restrict__ x, long ld, long rows, long cols, float* __restrict__ ws) {
-  __shared__ float sh[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const long c = (long)blockIdx.x * 64 + tx;
+__global__ void k_colsum1(const T* __restrict__ x, long ld, long rows, long cols, float* __restrict__ ws, int CT) {
+  __shared__ float sh[256];
+  const int rl = 256 / CT;
+  const int tx = threadIdx.x % CT, ty = threadIdx.x / CT;
+  const long c = (long)blockIdx.x * CT + tx;
   float acc = 0.f;
   if (c < cols)
-    for (long r = (long)blockIdx.y * 4 + ty; r < rows; r += (long)gridDim.y * 4) acc += ld_f32(x + r * ld + c);
-  sh[ty][tx] = acc;
+    for (long r = (long)blockIdx.y * rl + ty; r < rows; r += (long)gridDim.y * rl) acc += ld_f32(x + r * ld + c);
+  sh[threadIdx.x] = acc;
   __syncthreads();
-  if (ty == 0 && c < cols) ws[(long)blockIdx.y * cols + c] = sh[0][tx] + sh[1][tx] + sh[2][tx] + sh[3][tx];
+  if (ty == 0 && c < cols) {
+    float a = 0.f;
+    for (int k = 0; k < rl; ++k) a += sh[k * CT + tx];
+    ws[(long)blockIdx.y * cols + c] = a;
+  }
 }
 __global__ void k_colsum2(const float* __restrict__ ws, long cols, int parts, float* __restrict__ out, int accumulate) {
   const long c = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -175,12 +181,17 @@ extern "C" int vfm_colsum(const void* x, int dt, long ld, long rows, long cols, 
   VFM_CHECK(ld >= cols && ws, VFM_E_SHAPE, "vfm_colsum: bad args");
   if (cols == 0) return VFM_OK;
   hipStream_t s = (hipStream_t)stream;
-  const int parts = 64;
-  dim3 grid(cdiv(cols, 64), parts);
-  if (dt == VFM_F32) hipLaunchKernelGGL(k_colsum1<float>, grid, dim3(256), 0, s, (const float*)x, ld, rows, cols, ws);
-  else if (dt == VFM_BF16) hipLaunchKernelGGL(k_colsum1<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, rows, cols, ws);
+  int CT = 64;
+  while (CT > 8 && CT / 2 >= cols) CT /= 2;
+  const int rl = 256 / CT;
+  long parts = (rows + rl * 8 - 1) / (rl * 8);  // >= 8 rows per thread
+  if (parts > 64) parts = 64;
+  if (parts < 1) parts = 1;
+  dim3 grid(cdiv(cols, CT), (unsigned)parts);
+  if (dt == VFM_F32) hipLaunchKernelGGL(k_colsum1<float>, grid, dim3(256), 0, s, (const float*)x, ld, rows, cols, ws, CT);
+  else if (dt == VFM_BF16) hipLaunchKernelGGL(k_colsum1<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, rows, cols, ws, CT);
   else VFM_FAIL(VFM_E_INVAL, "vfm_colsum: dtype");
-  hipLaunchKernelGGL(k_colsum2, dim3(cdiv(cols, 256)), dim3(256), 0, s, ws, cols, parts, out, accumulate);
+  hipLaunchKernelGGL(k_colsum2, dim3(cdiv(cols, 256)), dim3(256), 0, s, ws, cols, (int)parts, out, accumulate);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }

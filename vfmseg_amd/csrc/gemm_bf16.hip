@@ -297,13 +297,13 @@ static void launch_cfg(const vfm_gemm_desc* d, hipStream_t s, bool vec) {
 
 
 // ------------------------------------------------------------------------------------------------ skinny tail
-// M <= 32 rows (the [cls] rows that follow the 128-aligned patch-token rows): one block = 32 rows x 32 columns, the 4
-// waves split K four ways, operands go straight from global memory into MFMA fragments (no LDS staging, no barriers
+// M <= 32 rows (the [cls] rows that follow the 128-aligned patch-token rows): one block = 32 rows x 32 columns, the 8
+// waves split K eight ways, operands go straight from global memory into MFMA fragments (no LDS staging, no barriers
 // in the loop: B is streamed exactly once), partial sums meet in LDS for the shared epilogue.
-__global__ void __launch_bounds__(256) k_gemm_bf16_skinny(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
+__global__ void __launch_bounds__(512) k_gemm_bf16_skinny(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
                                                           long M, long N, long K, long stride_a, long stride_b, long stride_c,
                                                           EpiParams e) {
-  __shared__ float part[4][32][33];
+  __shared__ float part[8][32][33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const long n0 = (long)blockIdx.x * 32;
@@ -314,12 +314,13 @@ __global__ void __launch_bounds__(256) k_gemm_bf16_skinny(const bf16_t* __restri
   if (bn > N - 1) bn = N - 1;
   const bf16_t* ap = A + z * stride_a + am * lda + fh * 8;
   const bf16_t* bp = B + z * stride_b + bn * ldb + fh * 8;
-  const long kq = K / 4;  // K % 64 == 0 -> kq % 16 == 0
+  const long kq = (K / 16 + 7) / 8 * 16;  // K split over the 8 waves in whole 16-wide MFMA steps
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const long kbeg = wave * kq, kend = kbeg + kq;
-#pragma unroll 4
+  const long kbeg = wave * kq;
+  const long kend = (kbeg + kq < K) ? kbeg + kq : K;
+#pragma unroll 8
   for (long k = kbeg; k < kend; k += 16) {
     const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + k);
     const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp + k);
@@ -329,16 +330,21 @@ __global__ void __launch_bounds__(256) k_gemm_bf16_skinny(const bf16_t* __restri
   for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * fh][fr] = acc[r];
   __syncthreads();
   const long zoff = z * stride_c;
-  for (int i = tid; i < 32 * 32; i += 256) {
+  for (int i = tid; i < 32 * 32; i += 512) {
     const int row = i >> 5, col = i & 31;
     const long m = row, n = n0 + col;
-    if (m < M && n < N) epi_store(e, zoff, m, n, part[0][row][col] + part[1][row][col] + part[2][row][col] + part[3][row][col]);
+    if (m < M && n < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += part[w][row][col];
+      epi_store(e, zoff, m, n, v);
+    }
   }
 }
 
 static void launch_skinny(const vfm_gemm_desc* d, hipStream_t s) {
   const long batch = d->batch > 0 ? d->batch : 1;
-  hipLaunchKernelGGL(k_gemm_bf16_skinny, dim3(cdiv(d->N, 32), (unsigned)batch), dim3(256), 0, s, (const bf16_t*)d->A, d->sa_m,
+  hipLaunchKernelGGL(k_gemm_bf16_skinny, dim3(cdiv(d->N, 32), (unsigned)batch), dim3(512), 0, s, (const bf16_t*)d->A, d->sa_m,
                      (const bf16_t*)d->B, d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c, make_epi(d));
 }
 
@@ -408,10 +414,13 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s) {
   const bool vec = vec_ok(d);
   int cfg = g_force_cfg;
   if (cfg < 0) {
+    // measured on MI355X (tools/bench_gemm.py): with ~one wave of tiles, occupancy (waves per SIMD) decides
     const long t128 = (long)cdiv(d->M, 128) * cdiv(d->N, 128);
-    if (d->N <= 64) cfg = 3;
-    else if (t128 >= 1024) cfg = 6;   // plenty of tiles: the larger tile halves L2 traffic per flop
-    else cfg = 1;
+    const long t256 = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
+    if (d->N <= 32) cfg = 10;                                        // 64x64 tiles: many rows, few columns
+    else if (t128 <= 160) cfg = 18;                                  // small problems: 64x128 tiles fill more CUs
+    else if (d->N >= 2048 && (t256 % 256 == 0 || t256 >= 768)) cfg = 16;  // 256x256, 16 waves: exact / many rounds
+    else cfg = 17;                                                   // 128x128, 8 waves, 2 blocks per CU
   }
   switch (cfg) {
     case 0: launch_cfg<128, 128, 2, 2, 2>(d, s, vec); break;
