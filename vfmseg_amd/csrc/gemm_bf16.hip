@@ -303,6 +303,8 @@ static void launch_cfg(const vfm_gemm_desc* d, hipStream_t s, bool vec) {
 __global__ void __launch_bounds__(512) k_gemm_bf16_skinny(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
                                                           long M, long N, long K, long stride_a, long stride_b, long stride_c,
                                                           EpiParams e) {
+  // per-wave staging image of a [32 columns(n) x 128 k] slice of B: 256-B rows, chunk c of row r at c ^ (r & 15)
+  __shared__ __attribute__((aligned(16))) char stg[8][32 * 256];
   __shared__ float part[8][32][33];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
@@ -310,21 +312,57 @@ __global__ void __launch_bounds__(512) k_gemm_bf16_skinny(const bf16_t* __restri
   const long z = blockIdx.y;
   long am = fr;
   if (am > M - 1) am = M - 1;
-  long bn = n0 + fr;
-  if (bn > N - 1) bn = N - 1;
   const bf16_t* ap = A + z * stride_a + am * lda + fh * 8;
-  const bf16_t* bp = B + z * stride_b + bn * ldb + fh * 8;
-  const long kq = (K / 16 + 7) / 8 * 16;  // K split over the 8 waves in whole 16-wide MFMA steps
+  const bf16_t* Bz = B + z * stride_b;
+  // coalesced loader map: one wave-instruction = 4 rows x 256 B
+  const int lrow = lane >> 4, lch = lane & 15;
+  const bf16_t* bsrc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    long bn = n0 + 4 * i + lrow;
+    if (bn > N - 1) bn = N - 1;
+    bsrc[i] = Bz + bn * ldb + lch * 8;
+  }
+  const long nchunk = K / 128;                       // K % 128 may be 64: handled by the remainder chunk below
+  const long per = (nchunk + 7) / 8;
+  const long c_beg = wave * per, c_end = (c_beg + per < nchunk) ? c_beg + per : nchunk;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const long kbeg = wave * kq;
-  const long kend = (kbeg + kq < K) ? kbeg + kq : K;
-#pragma unroll 8
-  for (long k = kbeg; k < kend; k += 16) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + k);
-    const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp + k);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  char* W = stg[wave];
+  for (long cidx = c_beg; cidx < c_end; ++cidx) {
+    const long k0 = cidx * 128;
+    uint4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const uint4*>(bsrc[i] + k0);
+    bf16x8 af[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) af[s2] = *reinterpret_cast<const bf16x8*>(ap + k0 + 16 * s2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 4 * i + lrow;
+      *reinterpret_cast<uint4*>(W + row * 256 + ((lch ^ (row & 15)) << 4)) = v[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) {
+      const bf16x8 bf = *reinterpret_cast<const bf16x8*>(W + fr * 256 + (((2 * s2 + fh) ^ (fr & 15)) << 4));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s2], bf, acc, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if ((K % 128) != 0 && wave == 7) {  // trailing 64-wide half chunk (K % 64 == 0 is guaranteed by the caller)
+    const long k0 = nchunk * 128;
+    long bn = n0 + fr;
+    if (bn > N - 1) bn = N - 1;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + k0 + 16 * s2);
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bz + bn * ldb + fh * 8 + k0 + 16 * s2);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * fh][fr] = acc[r];
