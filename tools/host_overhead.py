@@ -1,0 +1,31 @@
+"""Host-side enqueue time of one train step vs its GPU time (are we launch-bound?)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from vfmseg_amd import functional as Fh
+
+dev = torch.device("cuda", 0)
+model, ow = bench.build(dev, 2)
+Fh.manual_seed(1)
+data = bench.make_batch(2, 0, 0, dev)
+for _ in range(3):
+    model.train_step(data, ow)
+torch.cuda.synchronize()
+for _ in range(3):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.train_step(data, ow)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"enqueue {1e3*(t1-t0):.1f} ms, total {1e3*(t2-t0):.1f} ms", flush=True)
+# phase split
+import cProfile, pstats
+pr = cProfile.Profile()
+pr.enable()
+model.train_step(data, ow)
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr).sort_stats("cumulative")
+st.print_stats(25)

@@ -121,8 +121,24 @@ def check(rc, name):
         raise HipError(f"{name} failed ({rc}): {load().vfm_last_error().decode()}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_dev_index = None
+
+
 def stream():
+    """Raw hipStream_t of torch's current stream on the current device (fast path: no Stream object)."""
+    global _dev_index
+    if _raw_stream is not None:
+        if _dev_index is None:
+            _dev_index = torch.cuda.current_device()
+        return _raw_stream(_dev_index)
     return torch.cuda.current_stream().cuda_stream
+
+
+def set_device_index(i):
+    """Call after torch.cuda.set_device() when a process changes its device (one process per GPU: once)."""
+    global _dev_index
+    _dev_index = i
 
 
 def dt_of(t):
