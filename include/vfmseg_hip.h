@@ -166,6 +166,10 @@ int vfm_assemble_tokens(const float* patch_tok, const float* cls, const float* p
 int vfm_resize_bilinear(const void* in, int in_dt, int in_nchw, int B, int Hi, int Wi, int C, long in_ld_c, void* out,
                         int out_dt, int out_mode, long out_ld_c, int Hv, int Wv, int y0, int x0, int hc, int wc,
                         void* stream);
+/* bicubic (A=-0.75, align_corners=False, explicit source scales as F.interpolate(scale_factor=...) passes them) on a
+ * token-major fp32 map [Hi,Wi,C] -> [Ho,Wo,C]: DINOv2 pos-embed re-interpolation (dino_v2.py:184-215) */
+int vfm_resize_bicubic(const float* in, int Hi, int Wi, int C, float* out, int Ho, int Wo, float scale_y, float scale_x,
+                       void* stream);
 /* nearest (F.interpolate mode='nearest': src=floor(dst*scale)) + crop for int64 label maps (get_lr_seg/get_hr_seg,
  * Ms_VFM_encoder_decoder.py:148-158). in [B,Hi,Wi] -> out [B,hc,wc] of the virtual Hv x Wv map */
 int vfm_label_resize(const int64_t* in, int B, int Hi, int Wi, int64_t* out, int Hv, int Wv, int y0, int x0, int hc,

@@ -317,7 +317,19 @@ class DinoEngine:
         s = int(math.sqrt(n))
         if hp == s and wp == s:
             return v.pos_embed.detach().reshape(n + 1, -1).float().contiguous()
-        raise NotImplementedError("pos-embed bicubic re-interpolation (dino_v2.py:184-215) is not on the HIP path yet")
+        key = (hp, wp)
+        if key not in self._pos_cache:
+            # dino_v2.py:184-215: bicubic with scale_factor = (h0 + 0.1) / sqrt(N); F.interpolate maps coordinates with
+            # 1 / scale_factor.  The pos-embed is frozen, so the result is cached per token grid.
+            D = v.embed_dim
+            pe = v.pos_embed.detach().reshape(n + 1, D).float().contiguous()
+            out = torch.empty(1 + hp * wp, D, dtype=torch.float32, device=pe.device)
+            ops.cast(pe[:1], out[:1])
+            sy, sx = s / (hp + 0.1), s / (wp + 0.1)
+            assert int(s * ((hp + 0.1) / s)) == hp and int(s * ((wp + 0.1) / s)) == wp
+            ops.resize_bicubic(pe[1:], s, s, D, out[1:], hp, wp, sy, sx)
+            self._pos_cache[key] = out
+        return self._pos_cache[key]
 
     # ---- forward
     def forward(self, jobs, training, seed):
@@ -357,7 +369,7 @@ class DinoEngine:
         for li, (blk, Lp) in enumerate(zip(v.blocks, P["layers"])):
             S = {"x_in": x}
             kq = Lp["qkv"].k
-            a1 = torch.zeros(M, kq, dtype=cd, device=dev) if kq > D else torch.empty(M, D, dtype=cd, device=dev)
+            a1 = torch.empty(M, kq, dtype=cd, device=dev)  # [LN(x) | T]: the T GEMM writes all R_PAD columns (A is zero-padded)
             st1 = torch.empty(M, 2, dtype=torch.float32, device=dev)
             ops.layernorm_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1)
             if lora:

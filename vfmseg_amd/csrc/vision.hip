@@ -145,6 +145,57 @@ extern "C" int vfm_resize_bilinear(const void* in, int in_dt, int in_nchw, int B
   return VFM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------- bicubic
+// ATen upsample_bicubic2d (align_corners=False, A=-0.75): src = scale*(dst+0.5)-0.5 (not clamped), 4x4 taps with indices
+// clamped to the border.  Used once per token grid to re-interpolate the frozen DINOv2 pos-embed (dino_v2.py:184-215).
+__device__ __forceinline__ void cubic_coeffs(float t, float (&w)[4]) {
+  const float A = -0.75f;
+  const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+  w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+  w[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+  w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+  w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+__global__ void k_resize_bicubic(const float* __restrict__ in, int Hi, int Wi, int C, float* __restrict__ out, int Ho, int Wo,
+                                 float sy, float sx) {
+  const long total = (long)Ho * Wo * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int x = (int)(t % Wo);
+    const int y = (int)(t / Wo);
+    const float fy = sy * (y + 0.5f) - 0.5f, fx = sx * (x + 0.5f) - 0.5f;
+    const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+    float wy[4], wx[4];
+    cubic_coeffs(fy - iy, wy);
+    cubic_coeffs(fx - ix, wx);
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      int yy = iy - 1 + a;
+      yy = yy < 0 ? 0 : (yy > Hi - 1 ? Hi - 1 : yy);
+      float row = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        int xx = ix - 1 + b;
+        xx = xx < 0 ? 0 : (xx > Wi - 1 ? Wi - 1 : xx);
+        row += wx[b] * in[((long)yy * Wi + xx) * C + c];
+      }
+      acc += wy[a] * row;
+    }
+    out[i] = acc;
+  }
+}
+extern "C" int vfm_resize_bicubic(const float* in, int Hi, int Wi, int C, float* out, int Ho, int Wo, float scale_y,
+                                  float scale_x, void* stream) {
+  const long total = (long)Ho * Wo * C;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_resize_bicubic, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, out, Ho, Wo, scale_y, scale_x);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------- labels
 __global__ void k_label_resize(const int64_t* __restrict__ in, int B, int Hi, int Wi, int64_t* __restrict__ out, float sy,
                                float sx, int y0, int x0, int hc, int wc) {

@@ -76,6 +76,7 @@ SIGNATURES = {
     "vfm_patchify": [vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, ci, cl, ci, vp],
     "vfm_assemble_tokens": [vp, vp, vp, vp, ci, ci, ci, vp],
     "vfm_resize_bilinear": [vp, ci, ci, ci, ci, ci, ci, cl, vp, ci, ci, cl, ci, ci, ci, ci, ci, ci, vp],
+    "vfm_resize_bicubic": [vp, ci, ci, ci, vp, ci, ci, cf, cf, vp],
     "vfm_label_resize": [vp, ci, ci, ci, vp, ci, ci, ci, ci, ci, ci, vp],
     "vfm_unblock": [vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "vfm_upsample_ce": [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp],

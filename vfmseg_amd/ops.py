@@ -332,6 +332,13 @@ def resize_bilinear(inp, in_nchw, B, Hi, Wi, Cc, out, out_mode, virt, window=Non
     return out
 
 
+def resize_bicubic(inp, Hi, Wi, Cc, out, Ho, Wo, scale_y, scale_x):
+    lib = L.load()
+    L.check(lib.vfm_resize_bicubic(L.ptr(inp), Hi, Wi, Cc, L.ptr(out), Ho, Wo, float(scale_y), float(scale_x), L.stream()),
+            "vfm_resize_bicubic")
+    return out
+
+
 def label_resize(lab, out, virt, window=None):
     lib = L.load()
     B, Hi, Wi = lab.shape

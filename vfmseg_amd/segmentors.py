@@ -291,4 +291,46 @@ class MsVFMEncoderDecoder(EncoderDecoder):
         raise NotImplementedError(f"test mode {mode} is not on the HIP path (ms_slide_inference / hr_slide_inference are)")
 
     def ms_inference(self, inputs, batch_img_metas):
-        raise NotImplementedError("ms_inference on the HIP path lands with the pos-embed re-interpolation kernel")
+        """Ms_VFM_encoder_decoder.py:400-466.  Stage 0: whole-image pass at a hard-coded (512, 1024) through the
+        LinearHead, bilinear to the image size.  Stage 1: per 512^2 window, confidence gate (fraction of pixels whose
+        max softmax exceeds `threadshod`; one device->host sync per window, as in the reference) and, when below
+        `conf`, the VFMHead refinement with that window's coarse logits as context; sliding accumulate."""
+        thr = self.test_cfg.get("threadshod", 1.0)
+        conf = self.test_cfg.get("conf", 1.0)
+        B, _, H, W = inputs.shape
+        dev = inputs.device
+        C = self.out_channels
+        small = torch.empty(B, 3, 512, 1024, dtype=torch.float32, device=dev)
+        ops.resize_bilinear(inputs, True, B, H, W, 3, small, 1, (512, 1024))
+        lg0 = self.enc_dec(small)                                   # NHWC low-res logits of the coarse pass
+        seg = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
+        ops.resize_bilinear(lg0, False, B, lg0.shape[1], lg0.shape[2], C, seg, 1, (H, W))  # predict_by_feat -> image size
+        dec = getattr(self.aux_decoder, "transformer_decoder", None)
+        had_mask = getattr(dec, "mask_enable", None)
+        if had_mask is not None:
+            dec.mask_enable = False
+        preds = torch.zeros(B, C, H, W, dtype=torch.float32, device=dev)
+        count = torch.zeros(B, 1, H, W, dtype=torch.float32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.last_refined = []
+        try:
+            for (y1, y2, x1, x2) in grid_boxes(H, W, self.test_cfg.crop_size, self.test_cfg.stride):
+                hc, wc = y2 - y1, x2 - x1
+                self.hr_crop_box = (y1, y2, x1, x2)
+                cnt.zero_()
+                ops.conf_gate_count(seg, (y1, x1, hc, wc), thr, cnt)
+                frac = cnt.item() / float(B * hc * wc)              # data-dependent control flow: host sync
+                ctx = torch.empty(B, C, hc, wc, dtype=torch.float32, device=dev)
+                ops.strided_copy(seg, ctx, (B, C, hc, wc), (seg.stride(0), seg.stride(1), seg.stride(2), 1),
+                                 (C * hc * wc, hc * wc, wc, 1))
+                if frac < conf:
+                    lg = self.enc_dec(inputs, ctx, box=(y1, y2, x1, x2))   # [B, hp, wp, C]
+                    ops.slide_accumulate(lg, False, B, lg.shape[1], lg.shape[2], C, preds, count, (y1, x1, hc, wc))
+                    self.last_refined.append((y1, y2, x1, x2))
+                else:
+                    ops.slide_accumulate(ctx, True, B, hc, wc, C, preds, count, (y1, x1, hc, wc))
+        finally:
+            if had_mask is not None:
+                dec.mask_enable = had_mask
+        ops.slide_finalize(preds, count)
+        return preds
