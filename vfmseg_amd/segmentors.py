@@ -321,7 +321,8 @@ class MsVFMEncoderDecoder(EncoderDecoder):
                 ops.conf_gate_count(seg, (y1, x1, hc, wc), thr, cnt)
                 frac = cnt.item() / float(B * hc * wc)              # data-dependent control flow: host sync
                 ctx = torch.empty(B, C, hc, wc, dtype=torch.float32, device=dev)
-                ops.strided_copy(seg, ctx, (B, C, hc, wc), (seg.stride(0), seg.stride(1), seg.stride(2), 1),
+                win = seg[:, :, y1:y2, x1:x2]
+                ops.strided_copy(win, ctx, (B, C, hc, wc), (win.stride(0), win.stride(1), win.stride(2), 1),
                                  (C * hc * wc, hc * wc, wc, 1))
                 if frac < conf:
                     lg = self.enc_dec(inputs, ctx, box=(y1, y2, x1, x2))   # [B, hp, wp, C]
