@@ -1,0 +1,51 @@
+"""Config loader / registry surface (CPU): _base_ inheritance, {{_base_.x}}, cfg-options, registry names."""
+import os
+import textwrap
+
+import vfmseg_amd  # noqa: F401
+from vfmseg_amd.config import Config, parse_cfg_options
+from vfmseg_amd.registry import MODELS, OPTIM_WRAPPER_CONSTRUCTORS
+
+
+def test_base_inheritance_and_substitution(tmp_path):
+    (tmp_path / "base.py").write_text(textwrap.dedent("""
+        crop_size = (512, 512)
+        model = dict(type='EncoderDecoder', backbone=dict(type='X', depth=12), test_cfg=dict(mode='slide', stride=[320, 320]))
+        pipeline = [dict(type='Resize', scale=(1024, 512)), dict(type='Pack')]
+    """))
+    (tmp_path / "child.py").write_text(textwrap.dedent("""
+        from copy import deepcopy
+        _base_ = ['./base.py']
+        model = dict(backbone=dict(depth=24), test_cfg=dict(_delete_=True, mode='whole'))
+        val = dict(pipeline={{_base_.pipeline}}, size={{_base_.crop_size}})
+        lr = 1e-4 * 2
+    """))
+    cfg = Config.fromfile(str(tmp_path / "child.py"))
+    assert cfg.model.type == "EncoderDecoder" and cfg.model.backbone.depth == 24 and cfg.model.backbone.type == "X"
+    assert cfg.model.test_cfg == dict(mode="whole")
+    assert cfg.val.pipeline[0]["type"] == "Resize" and tuple(cfg.val.size) == (512, 512)
+    assert abs(cfg.lr - 2e-4) < 1e-12
+    cfg.merge_from_dict(parse_cfg_options(["model.backbone.depth=2", "work_dir=foo"]))
+    assert cfg.model.backbone.depth == 2 and cfg.work_dir == "foo"
+    cfg.model.train_cfg = dict(work_dir="w")   # attribute mutation as tools/train.py:108-109 does
+    assert cfg.model.train_cfg.work_dir == "w"
+
+
+def test_registry_has_reference_names():
+    for n in ["MsVFMEncoderDecoder", "LoraBackboneEncoderDecoder", "EncoderDecoder", "LoRABackbone", "DinoVisionTransformer",
+              "LinearHead", "VFMHead", "MaskTransformerDecoder", "TransformerDecoder", "CrossEntropyLoss", "SegDataPreProcessor"]:
+        assert n in MODELS, n
+    assert "PEFTOptimWrapperConstructor" in OPTIM_WRAPPER_CONSTRUCTORS
+
+
+def test_repo_config_builds_reference_key_scheme():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = Config.fromfile(os.path.join(root, "configs", "dg_lora_dinov2_ms_masked.py"))
+    cfg.model.backbone.backbone.depth = 2
+    m = MODELS.build(cfg.model)
+    keys = set(m.state_dict())
+    assert "backbone.model.base_model.model.blocks.1.attn.qkv.lora_A.default.weight" in keys
+    assert "decode_head.output_upscaling.1.running_mean" in keys and "aux_decoder.transformer_decoder.mask_token" in keys
+    from tests.helpers import model_shapes
+    want = set(model_shapes(depth=2))
+    assert keys == want, (sorted(keys - want)[:5], sorted(want - keys)[:5])

@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""Training entry point with the reference's flags (tools/train.py:19-61): CONFIG [--work-dir --resume --amp
+--cfg-options k=v ... --launcher {none,pytorch,slurm,mpi}].  Launch multi-GPU runs with
+`python -m torch.distributed.run --nproc-per-node N tools/train.py CONFIG --launcher pytorch`."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser(description="Train a segmentor on the MI355X HIP path")
+    ap.add_argument("config")
+    ap.add_argument("--work-dir")
+    ap.add_argument("--resume", action="store_true")
+    ap.add_argument("--amp", action="store_true", help="accepted for CLI parity; bf16 MFMA compute is the default")
+    ap.add_argument("--cfg-options", nargs="+")
+    ap.add_argument("--launcher", choices=["none", "pytorch", "slurm", "mpi"], default="none")
+    ap.add_argument("--local_rank", "--local-rank", type=int, default=0)
+    ap.add_argument("--max-iters", type=int, default=None)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    a = ap.parse_args()
+    if "LOCAL_RANK" not in os.environ:
+        os.environ["LOCAL_RANK"] = str(a.local_rank)
+    import vfmseg_amd  # noqa: F401
+    from vfmseg_amd.config import Config, parse_cfg_options
+    from vfmseg_amd.precision import set_compute_dtype
+    from vfmseg_amd.runner import Runner
+    set_compute_dtype(a.dtype)
+    cfg = Config.fromfile(a.config)
+    cfg.merge_from_dict(parse_cfg_options(a.cfg_options))
+    cfg["work_dir"] = a.work_dir or cfg.get("work_dir") or os.path.join("./work_dirs", os.path.splitext(os.path.basename(a.config))[0])
+    if "train_cfg" not in cfg["model"] or cfg["model"]["train_cfg"] is None:
+        cfg["model"]["train_cfg"] = {}
+    cfg["model"]["train_cfg"]["work_dir"] = cfg["work_dir"]           # tools/train.py:108-109
+    cfg["model"]["train_cfg"]["log_config"] = cfg.get("log_config", dict(interval=50, img_interval=500))
+    runner = Runner.from_cfg(cfg)
+    if a.resume:
+        cks = sorted(f for f in os.listdir(cfg["work_dir"]) if f.startswith("iter_")) if os.path.isdir(cfg["work_dir"]) else []
+        if cks:
+            runner.resume(os.path.join(cfg["work_dir"], cks[-1]))
+    runner.train(a.max_iters, log_interval=cfg.get("default_hooks", {}).get("logger", {}).get("interval", 50),
+                 ckpt_interval=cfg.get("default_hooks", {}).get("checkpoint", {}).get("interval", 4000))
+
+
+if __name__ == "__main__":
+    main()
