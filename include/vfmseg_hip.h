@@ -103,7 +103,8 @@ int vfm_bn_bwd_apply(const void* dy, int dy_dt, const float* x, const float* mea
 
 /* ---- GEMM ------------------------------------------------------------------------------------- */
 /* C[M,N] = epilogue( alpha * sum_k A[m,k] * B[n,k] )       (torch.nn.Linear / 1x1 conv / ConvT2x2 / dgrad / wgrad)
- *   in_dt VFM_BF16: MFMA bf16 path, A/B bf16 row-major with K contiguous, K % 64 == 0 (pad with zeros)
+ *   in_dt VFM_BF16: MFMA bf16 path, A bf16 [M,K] with K contiguous, K % 64 == 0 (pad with zeros); B either [N,K]
+ *                   (sb_k == 1) or [K,N] (sb_n == 1, N % 8 == 0: weight-gradient GEMMs consume activations in place)
  *   in_dt VFM_F32 : exact-fp32 MFMA path, arbitrary element strides (sa_m,sa_k),(sb_n,sb_k), any K
  * epilogue order:  v = alpha*acc + bias[n % bias_mod];  if C2: C2 = v (pre-activation, saved for backward)
  *                  ep_mode: GELU/RELU -> v = act(v);  MUL_GELU_GRAD -> v *= gelu'(aux[m,n]);  MUL -> v *= aux[m,n]
@@ -122,6 +123,7 @@ typedef struct vfm_gemm_desc {
   int ep_mode; const void* aux; int aux_dt; long ld_aux;
   void* C2; int c2_dt; long ldc2;
   long batch, stride_a, stride_b, stride_c;
+  long kb_rows; /* bf16, B given as [K,N] (sb_n == 1): number of valid rows of B (<= K; A must be zero beyond); 0 = K */
 } vfm_gemm_desc;
 int vfm_gemm(const vfm_gemm_desc* d, void* stream);
 /* tuning / experiment knobs (e.g. key "gemm_cfg": force a bf16 GEMM tile configuration, -1 = heuristic) */

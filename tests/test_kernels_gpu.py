@@ -234,6 +234,31 @@ def test_gemm_bf16(M, N, K):
     assert relerr(cw[:, :N], a.double() @ b.double().t()) < 2e-5 and cw[:, N:].abs().sum() == 0
 
 
+@pytest.mark.parametrize("P,M,Q", [(64, 4100, 3072), (64, 4100, 1024), (1024, 2048, 4096), (19, 1000, 256), (200, 333, 128)])
+def test_gemm_bf16_transposed_b(P, M, Q):
+    """Weight-gradient form: out[P,Q] = xs^T[P,M] @ y[M,Q], y consumed in place ([K,N] operand), tokens zero-padded."""
+    xs, y = rnd(M, P, seed=60).bfloat16(), rnd(M, Q, seed=61).bfloat16()
+    mp = (M + 63) // 64 * 64
+    xt = torch.zeros(P, mp, dtype=torch.bfloat16, device=DEV)
+    ops.transpose(xs.to(DEV), xt, pad_rows=mp)
+    out = torch.empty(P, Q, device=DEV)
+    ops.gemm(xt, y.to(DEV), out, trans_b=True, kb_rows=M)
+    ref = xs.double().t() @ y.double()
+    assert relerr(out, ref) < 2e-5, relerr(out, ref)
+    # y as a column slice of a wider buffer + split-K batching
+    if M % 128 == 0 or M == 2048:
+        wide = torch.zeros(M, Q + 64, dtype=torch.bfloat16, device=DEV)
+        wide[:, :Q] = y.to(DEV)
+        kch = 4
+        ck = mp // kch
+        slabs = torch.empty(kch, P, Q, device=DEV)
+        a = torch.as_strided(xt, (kch, P, ck), (ck, mp, 1))
+        yv = wide[:, :Q]
+        b = torch.as_strided(yv, (kch, ck, Q), (ck * yv.stride(0), yv.stride(0), 1))
+        ops.gemm_batched_bt(a, b, slabs, M)
+        assert relerr(slabs.sum(0), ref) < 2e-5
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("nq_extra,nk_extra,nq,nk", [(1, 1, 200, 200), (0, 0, 256, 256), (0, 0, 130, 70), (1, 1, 1024, 1024)])
 def test_attention(dt, nq_extra, nk_extra, nq, nk):

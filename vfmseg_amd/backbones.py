@@ -450,12 +450,14 @@ class DinoEngine:
                 A, Bm = q.lora_A["default"].weight, q.lora_B["default"].weight
                 a1 = S["a1"]
                 xd = S["xd"] if S["xd"] is not None else a1[:, :D]
+                # dB^T[r, out] = T^T @ dqkv ;  dA[r, in] = s * dT^T @ drop(xn)   (reductions over the M tokens)
+                gBt = torch.empty(R_PAD, Bm.shape[0], dtype=torch.float32, device=dev)
+                gAp = torch.empty(R_PAD, A.shape[1], dtype=torch.float32, device=dev)
+                _wgrad_small_t(a1[:, D:D + R_PAD], dqkv, gBt)
+                _wgrad_small_t(da1[:, D:D + R_PAD], xd, gAp, alpha=q.scaling)
                 gB = torch.empty_like(Bm, dtype=torch.float32)
-                gA = torch.empty_like(A, dtype=torch.float32)
-                # dB[out, r] = dqkv^T @ T ;  dA[r, in] = s * dT^T @ drop(xn)
-                _wgrad_cols(dqkv, a1[:, D:D + r], gB)
-                _wgrad_cols(da1[:, D:D + r], xd, gA, alpha=q.scaling)
-                grads[2 * li], grads[2 * li + 1] = gA, gB
+                ops.strided_copy(gBt, gB, (Bm.shape[0], r), (1, gBt.stride(0)), (r, 1))
+                grads[2 * li], grads[2 * li + 1] = gAp[:r], gB
                 # d LN1(x) = da1[:, :D] + mask * (s * dT @ A)
                 ep = dict(ep_mode=ops.EP_MUL, aux=S["mask"]) if S["mask"] is not None else {}
                 ops.gemm(da1[:, D:D + R_PAD], Lp["at"], da1[:, :D], alpha=q.scaling, residual=da1[:, :D], **ep)
@@ -469,18 +471,19 @@ def _pack_at(A, at, r):
     ops.strided_copy(A, at, (A.shape[1], r), (1, A.stride(0)), (at.stride(0), 1))
 
 
-def _wgrad_cols(dy, x, grad_out, alpha=1.0):
-    """grad_out[N,K] = alpha * dy^T @ x, where dy / x may be column slices (made contiguous by the transposes)."""
-    if dy.dtype == torch.bfloat16:
-        M = dy.shape[0]
+def _wgrad_small_t(xs, y, out, alpha=1.0):
+    """out[P, Q] = alpha * xs^T @ y   with xs [M, P] small (P <= 64) and y [M, Q] large, consumed in place.
+    bf16: only the small operand is transposed (zero-padded to a multiple of 64 tokens); the large one is the
+    transposed-B operand of the MFMA GEMM.  f32: strided operands."""
+    M = xs.shape[0]
+    if xs.dtype == torch.bfloat16:
         mp = (M + 63) // 64 * 64
-        dyt = torch.empty(dy.shape[1], mp, dtype=dy.dtype, device=dy.device)
-        xt = torch.empty(x.shape[1], mp, dtype=x.dtype, device=x.device)
-        ops.transpose(dy, dyt, pad_rows=mp)
-        ops.transpose(x, xt, pad_rows=mp)
-        ops.gemm(dyt, xt, grad_out, alpha=alpha)
+        xt = torch.empty(xs.shape[1], mp, dtype=xs.dtype, device=xs.device)
+        ops.transpose(xs, xt, pad_rows=mp)
+        ops.gemm(xt, y, out, alpha=alpha, trans_b=True, kb_rows=M)
     else:
-        ops.gemm(dy, x, grad_out, alpha=alpha, trans_a=True, trans_b=True)
+        ops.gemm(xs, y, out, alpha=alpha, trans_a=True, trans_b=True)
+    return out
 
 
 class _BackboneFn(torch.autograd.Function):

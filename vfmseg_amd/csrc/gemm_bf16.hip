@@ -114,10 +114,15 @@ struct Cfg {
   static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of the 32x32 MFMA");
 };
 
-template <int BM, int BN, int WM_W, int WN_W, int NS, bool VEC>
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// BT = true: B is given as [K, N] row-major (N contiguous) - weight-gradient GEMMs reduce over tokens, so the activation
+// operand is consumed in place and its MFMA fragments come from transposed LDS reads (ds_read_b64_tr_b16); rows k >= kb_rows
+// are clamped (the A operand is zero there).
+template <int BM, int BN, int WM_W, int WN_W, int NS, bool VEC, bool BT>
 __global__ void __launch_bounds__(WM_W* WN_W * 64)
     k_gemm_bf16(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, long M, long N, long K,
-                long stride_a, long stride_b, long stride_c, int tiles_m, int tiles_n, EpiParams e) {
+                long stride_a, long stride_b, long stride_c, int tiles_m, int tiles_n, long kb_rows, EpiParams e) {
   using C = Cfg<BM, BN, WM_W, WN_W, NS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -141,6 +146,13 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   const long z = blockIdx.y;
   const bf16_t* Ab = A + z * stride_a;
   const bf16_t* Bb = B + z * stride_b;
+  // BT: valid B rows of this batch slice (split-K batches slice the token dimension; the last slice may be short)
+  long kb_valid = K;
+  if constexpr (BT) {
+    kb_valid = kb_rows - (ldb > 0 ? z * (stride_b / ldb) : 0);
+    if (kb_valid > K) kb_valid = K;
+    if (kb_valid < 1) kb_valid = 1;
+  }
 
   // ---- per-lane DMA sources (row clamp keeps every load in bounds; clamped rows are never stored)
   const int lr = lane >> 3, pc = lane & 7;
@@ -153,12 +165,24 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
     if (gm > M - 1) gm = M - 1;
     a_src[j] = Ab + gm * lda + ((pc ^ ((r >> 1) & 7)) << 3);
   }
+  int bt_row[C::B_PIECES];  // BT: k-row of this lane inside the tile, per piece
 #pragma unroll
   for (int j = 0; j < C::B_PIECES; ++j) {
-    const int r = (wave * C::B_PIECES + j) * 8 + lr;
-    long gn = n0 + r;
-    if (gn > N - 1) gn = N - 1;
-    b_src[j] = Bb + gn * ldb + ((pc ^ ((r >> 1) & 7)) << 3);
+    if constexpr (!BT) {
+      const int r = (wave * C::B_PIECES + j) * 8 + lr;
+      long gn = n0 + r;
+      if (gn > N - 1) gn = N - 1;
+      b_src[j] = Bb + gn * ldb + ((pc ^ ((r >> 1) & 7)) << 3);
+    } else {
+      static_assert(!BT || BN == 128, "transposed-B path is built for BN = 128 (256-byte LDS rows)");
+      const int piece = wave * C::B_PIECES + j;          // 1 KiB = 4 k-rows x 256 B
+      const int r = piece * 4 + (lane >> 4);
+      const int c = (lane & 15) ^ ((r & 3) << 2);
+      long gn = n0 + c * 8;
+      if (gn > N - 8) gn = N - 8;                        // N % 8 == 0: clamped chunks are never stored
+      bt_row[j] = r;
+      b_src[j] = Bb + gn;
+    }
   }
   auto stage = [&](int slot, long k0) {
     char* sa = smem + slot * C::STAGE_BYTES;
@@ -166,7 +190,15 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
 #pragma unroll
     for (int j = 0; j < C::A_PIECES; ++j) glds16(a_src[j] + k0, sa + (wave * C::A_PIECES + j) * 1024);
 #pragma unroll
-    for (int j = 0; j < C::B_PIECES; ++j) glds16(b_src[j] + k0, sb + (wave * C::B_PIECES + j) * 1024);
+    for (int j = 0; j < C::B_PIECES; ++j) {
+      if constexpr (!BT) {
+        glds16(b_src[j] + k0, sb + (wave * C::B_PIECES + j) * 1024);
+      } else {
+        long kr = k0 + bt_row[j];
+        if (kr > kb_valid - 1) kr = kb_valid - 1;
+        glds16(b_src[j] + kr * ldb, sb + (wave * C::B_PIECES + j) * 1024);
+      }
+    }
   };
 
   f32x16 acc[C::MI][C::NI];
@@ -210,11 +242,28 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
     const char* sa = smem + (t % NS) * C::STAGE_BYTES;
     const char* sb = sa + C::A_BYTES;
     // fragment double buffering: the ds_reads of k-step s+1 are issued before the MFMAs of k-step s
+    auto read_b = [&](int s2, int j) -> bf16x8 {
+      if constexpr (!BT) {
+        return *reinterpret_cast<const bf16x8*>(sb + b_off[j] + (((2 * s2 + fh) ^ b_sw[j]) << 4));
+      } else {
+        const int g = lane >> 4, i2 = lane & 15, q = i2 >> 2, p = i2 & 3, h2 = g >> 1;
+        const int chunk = (wn * C::WN + j * 32) / 8 + 2 * (g & 1) + (p >> 1);
+        const int r0 = 16 * s2 + 8 * h2 + q, r1 = r0 + 4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(sb + r0 * 256 + ((chunk ^ ((r0 & 3) << 2)) << 4) + ((p & 1) << 3)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(sb + r1 * 256 + ((chunk ^ ((r1 & 3) << 2)) << 4) + ((p & 1) << 3)));
+        union { struct { s16x4 a, b; } st; bf16x8 v; } u;
+        u.st.a = lo;
+        u.st.b = hi;
+        return u.v;
+      }
+    };
     bf16x8 af[2][C::MI], bfr[2][C::NI];
 #pragma unroll
     for (int i = 0; i < C::MI; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(sa + a_off[i] + (((fh) ^ a_sw[i]) << 4));
 #pragma unroll
-    for (int j = 0; j < C::NI; ++j) bfr[0][j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j] + (((fh) ^ b_sw[j]) << 4));
+    for (int j = 0; j < C::NI; ++j) bfr[0][j] = read_b(0, j);
 #pragma unroll
     for (int s = 0; s < BK / 16; ++s) {
       const int cur = s & 1, nxt = cur ^ 1;
@@ -223,8 +272,7 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
         for (int i = 0; i < C::MI; ++i)
           af[nxt][i] = *reinterpret_cast<const bf16x8*>(sa + a_off[i] + (((2 * (s + 1) + fh) ^ a_sw[i]) << 4));
 #pragma unroll
-        for (int j = 0; j < C::NI; ++j)
-          bfr[nxt][j] = *reinterpret_cast<const bf16x8*>(sb + b_off[j] + (((2 * (s + 1) + fh) ^ b_sw[j]) << 4));
+        for (int j = 0; j < C::NI; ++j) bfr[nxt][j] = read_b(s + 1, j);
       }
 #pragma unroll
       for (int i = 0; i < C::MI; ++i)
@@ -275,26 +323,35 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   }
 }
 
-template <int BM, int BN, int WM_W, int WN_W, int NS>
-static void launch_cfg(const vfm_gemm_desc* d, hipStream_t s, bool vec) {
+template <int BM, int BN, int WM_W, int WN_W, int NS, bool VEC, bool BT>
+static void launch_one(const vfm_gemm_desc* d, hipStream_t s) {
   using C = Cfg<BM, BN, WM_W, WN_W, NS>;
   const int tiles_m = cdiv(d->M, BM), tiles_n = cdiv(d->N, BN);
   const long batch = d->batch > 0 ? d->batch : 1;
-  static bool attr[2] = {false, false};
-  if (!attr[vec]) {
-    if (vec) (void)hipFuncSetAttribute((const void*)k_gemm_bf16<BM, BN, WM_W, WN_W, NS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-    else (void)hipFuncSetAttribute((const void*)k_gemm_bf16<BM, BN, WM_W, WN_W, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-    attr[vec] = true;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_gemm_bf16<BM, BN, WM_W, WN_W, NS, VEC, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+    attr = true;
   }
   dim3 grid(tiles_m * tiles_n, (unsigned)batch), blk(C::THREADS);
-  if (vec)
-    hipLaunchKernelGGL((k_gemm_bf16<BM, BN, WM_W, WN_W, NS, true>), grid, blk, C::SMEM, s, (const bf16_t*)d->A, d->sa_m, (const bf16_t*)d->B,
-                       d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c, tiles_m, tiles_n, make_epi(d));
-  else
-    hipLaunchKernelGGL((k_gemm_bf16<BM, BN, WM_W, WN_W, NS, false>), grid, blk, C::SMEM, s, (const bf16_t*)d->A, d->sa_m, (const bf16_t*)d->B,
-                       d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c, tiles_m, tiles_n, make_epi(d));
+  const long ldb = BT ? d->sb_k : d->sb_n;
+  const long kb_rows = d->kb_rows > 0 ? d->kb_rows : d->K;
+  hipLaunchKernelGGL((k_gemm_bf16<BM, BN, WM_W, WN_W, NS, VEC, BT>), grid, blk, C::SMEM, s, (const bf16_t*)d->A, d->sa_m,
+                     (const bf16_t*)d->B, ldb, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c, tiles_m, tiles_n, kb_rows,
+                     make_epi(d));
 }
 
+template <int BM, int BN, int WM_W, int WN_W, int NS>
+static void launch_cfg(const vfm_gemm_desc* d, hipStream_t s, bool vec) {
+  if (vec) launch_one<BM, BN, WM_W, WN_W, NS, true, false>(d, s);
+  else launch_one<BM, BN, WM_W, WN_W, NS, false, false>(d, s);
+}
+
+template <int BM, int WM_W, int WN_W>
+static void launch_bt(const vfm_gemm_desc* d, hipStream_t s, bool vec) {
+  if (vec) launch_one<BM, 128, WM_W, WN_W, 2, true, true>(d, s);
+  else launch_one<BM, 128, WM_W, WN_W, 2, false, true>(d, s);
+}
 
 // ------------------------------------------------------------------------------------------------ skinny tail
 // M <= 32 rows (the [cls] rows that follow the 128-aligned patch-token rows): one block = 32 rows x 32 columns, the 8
@@ -423,6 +480,8 @@ int vfm_gemm_bf16_impl(const vfm_gemm_desc* d0, hipStream_t s) {
   // A few rows past a 128-row boundary (M = B*1024 patch tokens + B [cls] tokens) would cost a whole extra row of
   // latency-bound tiles: peel them off into the skinny kernel.
   const long tail = d0->M % 128;
+  const bool bt = (d0->sb_n == 1 && d0->sb_k != 1);
+  if (bt) return gemm_main(d0, s);
   if (g_split_tail && d0->M > 512 && tail > 0 && tail <= 32 && (d0->batch <= 1)) {
     vfm_gemm_desc dm = *d0, dt = *d0;
     const long mm = d0->M - tail;
@@ -450,6 +509,11 @@ int vfm_gemm_bf16_impl(const vfm_gemm_desc* d0, hipStream_t s) {
 
 static int gemm_main(const vfm_gemm_desc* d, hipStream_t s) {
   const bool vec = vec_ok(d);
+  if (d->sb_n == 1 && d->sb_k != 1) {  // B given as [K, N]: transposed-B kernels (BN = 128)
+    if (d->M <= 64) launch_bt<64, 1, 4>(d, s, vec);
+    else launch_bt<128, 2, 4>(d, s, vec);
+    return VFM_OK;
+  }
   int cfg = g_force_cfg;
   if (cfg < 0) {
     // measured on MI355X (tools/bench_gemm.py): with ~one wave of tiles, occupancy (waves per SIMD) decides
@@ -481,6 +545,11 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s) {
     case 17: launch_cfg<128, 128, 2, 4, 2>(d, s, vec); break;
     case 18: launch_cfg<64, 128, 2, 2, 2>(d, s, vec); break;
     case 19: launch_cfg<128, 64, 2, 2, 2>(d, s, vec); break;
+    case 20: launch_cfg<256, 128, 4, 4, 3>(d, s, vec); break;
+    case 21: launch_cfg<128, 256, 4, 4, 3>(d, s, vec); break;
+    case 22: launch_cfg<256, 128, 4, 4, 2>(d, s, vec); break;
+    case 23: launch_cfg<128, 128, 4, 4, 3>(d, s, vec); break;
+    case 24: launch_cfg<128, 128, 4, 4, 2>(d, s, vec); break;
     default: VFM_FAIL(VFM_E_INVAL, "vfm_gemm(bf16): unknown config %d", cfg);
   }
   return VFM_OK;

@@ -74,18 +74,20 @@ def _unpack_grad(g2d, layout, w):
     return out
 
 
-def _splitk_wgrad(dyt, xt, out, kchunks):
-    """out[N,Kp] = dyt[N,Mp] @ xt[Kp,Mp]^T with the token reduction split into `kchunks` batched slices that are
-    then summed in a fixed order (deterministic split-K)."""
+def _splitk_wgrad(dyt, x, out, kchunks, m_rows):
+    """out[N,Kp] = dyt[N,Mp] @ x[M,Kp] (x consumed in place as the transposed-B operand) with the token reduction
+    split into `kchunks` batched slices that are then summed in a fixed order (deterministic split-K)."""
     n, mp = dyt.shape
-    kp = xt.shape[0]
+    kp = x.shape[1]
     if kchunks <= 1:
-        return ops.gemm(dyt, xt, out)
+        return ops.gemm(dyt, x, out, trans_b=True, kb_rows=m_rows)
     ck = mp // kchunks
     slabs = torch.empty(kchunks, n, kp, dtype=torch.float32, device=out.device)
     a = torch.as_strided(dyt, (kchunks, n, ck), (ck, mp, 1))
-    b = torch.as_strided(xt, (kchunks, kp, ck), (ck, mp, 1))
-    ops.gemm(a, b, slabs)
+    ld = x.stride(0)
+    # batch z covers token rows [z*ck, (z+1)*ck); rows >= m_rows are clamped in the kernel (A is zero there)
+    b = torch.as_strided(x, (kchunks, ck, kp), (ck * ld, ld, 1))
+    ops.gemm_batched_bt(a, b, slabs, m_rows)
     ops.colsum(slabs.view(kchunks, n * kp), out.view(n * kp))
     return out
 
@@ -189,10 +191,8 @@ class LinearFn(torch.autograd.Function):
                 while tiles * kch < 256 and (mp // (kch * 2)) % 64 == 0 and mp // (kch * 2) >= 256:
                     kch *= 2
                 dyt = torch.empty(N, mp, dtype=cd, device=dy.device)
-                xt = torch.empty(Kp, mp, dtype=cd, device=dy.device)
                 ops.transpose(gv, dyt, pad_rows=mp)
-                ops.transpose(x, xt, pad_rows=mp)
-                _splitk_wgrad(dyt, xt, gw, kch)
+                _splitk_wgrad(dyt, x, gw, kch, M)
             else:
                 ops.gemm(gv, x, gw, trans_a=True, trans_b=True)
             r0 = 0

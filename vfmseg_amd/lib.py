@@ -28,6 +28,7 @@ class GemmDesc(C.Structure):
         ("ep_mode", ci), ("aux", vp), ("aux_dt", ci), ("ld_aux", cl),
         ("C2", vp), ("c2_dt", ci), ("ldc2", cl),
         ("batch", cl), ("stride_a", cl), ("stride_b", cl), ("stride_c", cl),
+        ("kb_rows", cl),
     ]
 
 

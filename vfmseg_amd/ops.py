@@ -219,7 +219,7 @@ def bn_bwd_apply(dy, x, mean_var, w, b, eps, act, sums_dy, total_rows, dx):
 
 
 def gemm(a, b, c, *, alpha=1.0, bias=None, bias_mod=0, colscale=None, residual=None, ep_mode=EP_NONE, aux=None, c2=None,
-         trans_a=False, trans_b=False):
+         trans_a=False, trans_b=False, kb_rows=0):
     """c[M,N] = epilogue(alpha * A @ B^T).  a: [M,K] (or [K,M] if trans_a), b: [N,K] (or [K,N] if trans_b); 2-D views
     (or 3-D batched with equal batch).  bf16 inputs require K-contiguous operands with K % 64 == 0."""
     lib = L.load()
@@ -240,7 +240,11 @@ def gemm(a, b, c, *, alpha=1.0, bias=None, bias_mod=0, colscale=None, residual=N
     else:
         N, Kb = b2.shape
         d.sb_n, d.sb_k = b2.stride(0), b2.stride(1)
-    assert K == Kb, f"gemm K mismatch {K} vs {Kb}"
+    if kb_rows:
+        assert trans_b and Kb == kb_rows and K >= Kb, "kb_rows: b holds the first kb_rows of the K (token) dimension"
+        d.kb_rows = int(kb_rows)
+    else:
+        assert K == Kb, f"gemm K mismatch {K} vs {Kb}"
     assert a.dtype == b.dtype
     assert c2d.shape[0] == M and c2d.shape[1] == N and c2d.stride(1) == 1
     d.A, d.B, d.C = L.ptr(a), L.ptr(b), L.ptr(c)
@@ -262,6 +266,26 @@ def gemm(a, b, c, *, alpha=1.0, bias=None, bias_mod=0, colscale=None, residual=N
         d.batch, d.stride_a, d.stride_b, d.stride_c = a.shape[0], a.stride(0), b.stride(0), c.stride(0)
     else:
         d.batch = 1
+    L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
+    return c
+
+
+def gemm_batched_bt(a, b, c, kb_rows):
+    """Split-K helper: c[z] = a[z] @ b[z] with a [Z, N, ck] (K-contiguous) and b [Z, ck, Q] row slices of one [M, Q]
+    matrix (transposed-B operand); kb_rows = M valid token rows overall."""
+    lib = L.load()
+    d = L.GemmDesc()
+    Z, n, ck = a.shape
+    _, _, q = b.shape
+    d.A, d.B, d.C = L.ptr(a), L.ptr(b), L.ptr(c)
+    d.in_dt, d.c_dt = L.dt_of(a), L.dt_of(c)
+    d.M, d.N, d.K = n, q, ck
+    d.sa_m, d.sa_k = a.stride(1), a.stride(2)
+    d.sb_n, d.sb_k = b.stride(2), b.stride(1)
+    d.ldc = c.stride(1)
+    d.alpha = 1.0
+    d.batch, d.stride_a, d.stride_b, d.stride_c = Z, a.stride(0), b.stride(0), c.stride(0)
+    d.kb_rows = int(kb_rows)
     L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
     return c
 
