@@ -167,9 +167,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, Kp, dtype=cd, device=dy.device)
             if cd == torch.bfloat16:
-                wt = torch.zeros(Kp, npad, dtype=cd, device=dy.device) if npad > N else torch.empty(Kp, N, dtype=cd, device=dy.device)
-                ops.transpose(wp, wt, pad_rows=N)
-                ops.gemm(g, wt, dx)
+                ops.gemm(g, wp, dx, trans_b=True, kb_rows=N)   # dX = g @ W: the packed weight [N, Kp] is the [K, N'] operand
             else:
                 ops.gemm(gv, wp, dx, trans_b=True)
         dbias = None
