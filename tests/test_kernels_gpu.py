@@ -250,12 +250,12 @@ def test_gemm_bf16_transposed_b(P, M, Q):
         wide = torch.zeros(M, Q + 64, dtype=torch.bfloat16, device=DEV)
         wide[:, :Q] = y.to(DEV)
         kch = 4
-        ck = mp // kch
         slabs = torch.empty(kch, P, Q, device=DEV)
-        a = torch.as_strided(xt, (kch, P, ck), (ck, mp, 1))
-        yv = wide[:, :Q]
-        b = torch.as_strided(yv, (kch, ck, Q), (ck * yv.stride(0), yv.stride(0), 1))
-        ops.gemm_batched_bt(a, b, slabs, M)
+        ops.gemm_splitk_bt(xt, wide[:, :Q], slabs, kch)
+        assert relerr(slabs.sum(0), ref) < 2e-5
+    if M == 4100:   # ragged token count: 65 steps of 64 -> 13 slices, the last one clamps rows >= M
+        slabs = torch.empty(13, P, Q, device=DEV)
+        ops.gemm_splitk_bt(xt, y.to(DEV), slabs, 13)
         assert relerr(slabs.sum(0), ref) < 2e-5
 
 

@@ -480,7 +480,18 @@ def _wgrad_small_t(xs, y, out, alpha=1.0):
         mp = (M + 63) // 64 * 64
         xt = torch.empty(xs.shape[1], mp, dtype=xs.dtype, device=xs.device)
         ops.transpose(xs, xt, pad_rows=mp)
-        ops.gemm(xt, y, out, alpha=alpha, trans_b=True, kb_rows=M)
+        # few output tiles, long token reduction: split K into the largest divisor <= 16 of the 64-token steps
+        steps = mp // 64
+        kch = max(d for d in range(1, 17) if steps % d == 0)
+        if kch > 1:
+            P, Q = xt.shape[0], y.shape[1]
+            slabs = torch.empty(kch, P, Q, dtype=torch.float32, device=xs.device)
+            ops.gemm_splitk_bt(xt, y, slabs, kch)
+            ops.colsum(slabs.view(kch, P * Q), out.view(P * Q))
+            if alpha != 1.0:
+                ops.axpby(out.view(-1), alpha, out.view(-1), 0.0)
+        else:
+            ops.gemm(xt, y, out, alpha=alpha, trans_b=True, kb_rows=M)
     else:
         ops.gemm(xs, y, out, alpha=alpha, trans_a=True, trans_b=True)
     return out

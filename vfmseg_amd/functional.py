@@ -81,13 +81,8 @@ def _splitk_wgrad(dyt, x, out, kchunks, m_rows):
     kp = x.shape[1]
     if kchunks <= 1:
         return ops.gemm(dyt, x, out, trans_b=True, kb_rows=m_rows)
-    ck = mp // kchunks
     slabs = torch.empty(kchunks, n, kp, dtype=torch.float32, device=out.device)
-    a = torch.as_strided(dyt, (kchunks, n, ck), (ck, mp, 1))
-    ld = x.stride(0)
-    # batch z covers token rows [z*ck, (z+1)*ck); rows >= m_rows are clamped in the kernel (A is zero there)
-    b = torch.as_strided(x, (kchunks, ck, kp), (ck * ld, ld, 1))
-    ops.gemm_batched_bt(a, b, slabs, m_rows)
+    ops.gemm_splitk_bt(dyt, x, slabs, kchunks)
     ops.colsum(slabs.view(kchunks, n * kp), out.view(n * kp))
     return out
 

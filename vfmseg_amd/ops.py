@@ -270,24 +270,27 @@ def gemm(a, b, c, *, alpha=1.0, bias=None, bias_mod=0, colscale=None, residual=N
     return c
 
 
-def gemm_batched_bt(a, b, c, kb_rows):
-    """Split-K helper: c[z] = a[z] @ b[z] with a [Z, N, ck] (K-contiguous) and b [Z, ck, Q] row slices of one [M, Q]
-    matrix (transposed-B operand); kb_rows = M valid token rows overall."""
+def gemm_splitk_bt(at, y, slabs, kch):
+    """Split-K weight gradient: slabs[z] = at[:, z*ck:(z+1)*ck] @ y[z*ck:(z+1)*ck, :]  (z < kch, ck = at.shape[1] / kch).
+    at [P, Mp] bf16 (tokens zero-padded to Mp), y [M, Q] bf16 consumed in place as the [K, N] operand (rows >= M are
+    clamped in the kernel - `at` is zero there), slabs fp32 [kch, P, Q]."""
     lib = L.load()
     d = L.GemmDesc()
-    Z, n, ck = a.shape
-    _, _, q = b.shape
-    d.A, d.B, d.C = L.ptr(a), L.ptr(b), L.ptr(c)
-    d.in_dt, d.c_dt = L.dt_of(a), L.dt_of(c)
-    d.M, d.N, d.K = n, q, ck
-    d.sa_m, d.sa_k = a.stride(1), a.stride(2)
-    d.sb_n, d.sb_k = b.stride(2), b.stride(1)
-    d.ldc = c.stride(1)
+    P, mp = at.shape
+    M, Q = y.shape
+    ck = mp // kch
+    assert ck * kch == mp and ck % 64 == 0 and slabs.shape == (kch, P, Q)
+    d.A, d.B, d.C = L.ptr(at), L.ptr(y), L.ptr(slabs)
+    d.in_dt, d.c_dt = L.dt_of(at), L.dt_of(slabs)
+    d.M, d.N, d.K = P, Q, ck
+    d.sa_m, d.sa_k = at.stride(0), 1
+    d.sb_n, d.sb_k = 1, y.stride(0)
+    d.ldc = slabs.stride(1)
     d.alpha = 1.0
-    d.batch, d.stride_a, d.stride_b, d.stride_c = Z, a.stride(0), b.stride(0), c.stride(0)
-    d.kb_rows = int(kb_rows)
+    d.batch, d.stride_a, d.stride_b, d.stride_c = kch, ck, ck * y.stride(0), slabs.stride(0)
+    d.kb_rows = int(M)
     L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
-    return c
+    return slabs
 
 
 def tune(key, value):
