@@ -455,9 +455,18 @@ class DinoEngine:
                 gAp = torch.empty(R_PAD, A.shape[1], dtype=torch.float32, device=dev)
                 _wgrad_small_t(a1[:, D:D + R_PAD], dqkv, gBt)
                 _wgrad_small_t(da1[:, D:D + R_PAD], xd, gAp, alpha=q.scaling)
-                gB = torch.empty_like(Bm, dtype=torch.float32)
-                ops.strided_copy(gBt, gB, (Bm.shape[0], r), (1, gBt.stride(0)), (r, 1))
-                grads[2 * li], grads[2 * li + 1] = gAp[:r], gB
+                from .functional import direct_grad_target
+                tB, tA = direct_grad_target(Bm), direct_grad_target(A)
+                if tB is not None:
+                    ops.strided_copy(gBt, tB, (Bm.shape[0], r), (1, gBt.stride(0)), (r, 1), accumulate=True)
+                else:
+                    gB = torch.empty_like(Bm, dtype=torch.float32)
+                    ops.strided_copy(gBt, gB, (Bm.shape[0], r), (1, gBt.stride(0)), (r, 1))
+                    grads[2 * li + 1] = gB
+                if tA is not None:
+                    ops.axpby(gAp[:r].reshape(-1), 1.0, tA.view(-1), 1.0)
+                else:
+                    grads[2 * li] = gAp[:r]
                 # d LN1(x) = da1[:, :D] + mask * (s * dT @ A)
                 ep = dict(ep_mode=ops.EP_MUL, aux=S["mask"]) if S["mask"] is not None else {}
                 ops.gemm(da1[:, D:D + R_PAD], Lp["at"], da1[:, :D], alpha=q.scaling, residual=da1[:, :D], **ep)

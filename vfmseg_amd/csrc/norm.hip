@@ -45,12 +45,116 @@ __global__ void k_ln_fwd(const float* __restrict__ x, long ld_x, const float* __
   }
 }
 
+
+// ---- vectorised LayerNorm (C % 256 == 0): each lane owns float4 chunks -> 16-byte loads/stores (Guideline 13)
+template <typename TO, int NV>
+__global__ void k_ln_fwd_v4(const float* __restrict__ x, long ld_x, const float* __restrict__ w, const float* __restrict__ b,
+                            float eps, TO* __restrict__ y, long ld_y, float* __restrict__ stats, long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ld_x;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = *reinterpret_cast<const float4*>(xr + (i * 64 + lane) * 4);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float a = v[i].x - mean, bb = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+    q += (a * a + bb * bb) + (c * c + d * d);
+  }
+  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+  if (stats && lane == 0) {
+    stats[row * 2] = mean;
+    stats[row * 2 + 1] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c0 = (i * 64 + lane) * 4;
+    const float4 ww = *reinterpret_cast<const float4*>(w + c0);
+    const float4 bv = *reinterpret_cast<const float4*>(b + c0);
+    float4 o;
+    o.x = (v[i].x - mean) * rstd * ww.x + bv.x;
+    o.y = (v[i].y - mean) * rstd * ww.y + bv.y;
+    o.z = (v[i].z - mean) * rstd * ww.z + bv.z;
+    o.w = (v[i].w - mean) * rstd * ww.w + bv.w;
+    if constexpr (sizeof(TO) == 2) {
+      ushort4 p = {f32_to_bf16(o.x), f32_to_bf16(o.y), f32_to_bf16(o.z), f32_to_bf16(o.w)};
+      *reinterpret_cast<ushort4*>(y + row * ld_y + c0) = p;
+    } else {
+      *reinterpret_cast<float4*>(y + row * ld_y + c0) = o;
+    }
+  }
+}
+
+template <typename TD, int NV>
+__global__ void k_ln_bwd_v4(const TD* __restrict__ dy, long ld_dy, const float* __restrict__ x, long ld_x,
+                            const float* __restrict__ w, const float* __restrict__ stats, float* __restrict__ dx, long ld_dx,
+                            int accumulate_dx, long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+  float4 g[NV], xh[NV];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c0 = (i * 64 + lane) * 4;
+    float4 d;
+    if constexpr (sizeof(TD) == 2) {
+      const ushort4 p = *reinterpret_cast<const ushort4*>(dy + row * ld_dy + c0);
+      d = make_float4(bf16_to_f32(p.x), bf16_to_f32(p.y), bf16_to_f32(p.z), bf16_to_f32(p.w));
+    } else {
+      d = *reinterpret_cast<const float4*>(dy + row * ld_dy + c0);
+    }
+    const float4 xv = *reinterpret_cast<const float4*>(x + row * ld_x + c0);
+    const float4 ww = *reinterpret_cast<const float4*>(w + c0);
+    xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+    g[i] = make_float4(d.x * ww.x, d.y * ww.y, d.z * ww.z, d.w * ww.w);
+    s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+    s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+  }
+  s1 = wave_sum(s1) / C;
+  s2 = wave_sum(s2) / C;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c0 = (i * 64 + lane) * 4;
+    float4 o = make_float4(rstd * (g[i].x - s1 - xh[i].x * s2), rstd * (g[i].y - s1 - xh[i].y * s2),
+                           rstd * (g[i].z - s1 - xh[i].z * s2), rstd * (g[i].w - s1 - xh[i].w * s2));
+    float4* p = reinterpret_cast<float4*>(dx + row * ld_dx + c0);
+    if (accumulate_dx) {
+      const float4 old = *p;
+      o.x += old.x, o.y += old.y, o.z += old.z, o.w += old.w;
+    }
+    *p = o;
+  }
+}
+
 extern "C" int vfm_layernorm_fwd(const float* x, long ld_x, const float* w, const float* b, float eps, void* y, int y_dt,
                                  long ld_y, float* stats, long rows, long C, void* stream) {
   VFM_CHECK(C > 0 && C <= 2048 && ld_x >= C && ld_y >= C, VFM_E_SHAPE, "vfm_layernorm_fwd: C=%ld unsupported", C);
   if (rows == 0) return VFM_OK;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(cdiv(rows, 4)), blk(256);
+  const int nvq = (int)(C / 256);
+  const bool v4 = (C % 256 == 0) && (nvq == 1 || nvq == 2 || nvq == 4 || nvq == 5 || nvq == 8) && (ld_x % 4 == 0) && (ld_y % 4 == 0) && ((uintptr_t)x % 16 == 0) &&
+                  ((uintptr_t)y % 8 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)b % 16 == 0);
+  if (v4) {
+#define LV(TO, NV) hipLaunchKernelGGL((k_ln_fwd_v4<TO, NV>), grid, blk, 0, s, x, ld_x, w, b, eps, (TO*)y, ld_y, stats, rows, (int)C)
+    const int nv = (int)(C / 256);
+    if (y_dt == VFM_BF16) { if (nv == 1) LV(bf16_t, 1); else if (nv == 4) LV(bf16_t, 4); else if (nv == 5) LV(bf16_t, 5); else if (nv == 2) LV(bf16_t, 2); else LV(bf16_t, 8); }
+    else if (y_dt == VFM_F32) { if (nv == 1) LV(float, 1); else if (nv == 4) LV(float, 4); else if (nv == 5) LV(float, 5); else if (nv == 2) LV(float, 2); else LV(float, 8); }
+    else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_fwd: dtype");
+#undef LV
+    if (!(nv == 1 || nv == 2 || nv == 4 || nv == 5 || nv == 8)) VFM_FAIL(VFM_E_SHAPE, "vfm_layernorm_fwd: C=%ld", C);
+    VFM_LAUNCH_CHECK();
+    return VFM_OK;
+  }
 #define L(TO, PL) hipLaunchKernelGGL((k_ln_fwd<TO, PL>), grid, blk, 0, s, x, ld_x, w, b, eps, (TO*)y, ld_y, stats, rows, (int)C)
   const int pl = (int)((C + 63) / 64);
   if (y_dt == VFM_BF16) { if (pl <= 4) L(bf16_t, 4); else if (pl <= 16) L(bf16_t, 16); else L(bf16_t, 32); }
@@ -140,6 +244,20 @@ extern "C" int vfm_layernorm_bwd(const void* dy, int dy_dt, long ld_dy, const fl
   if (rows == 0) return VFM_OK;
   hipStream_t s = (hipStream_t)stream;
   const bool need_w = (dw || db);
+  const int nv = (int)(C / 256);
+  const bool v4 = !need_w && (C % 256 == 0) && (nv == 1 || nv == 2 || nv == 4 || nv == 5) && (ld_x % 4 == 0) && (ld_dx % 4 == 0) &&
+                  (ld_dy % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dx % 16 == 0) && ((uintptr_t)dy % 8 == 0) &&
+                  ((uintptr_t)w % 16 == 0);
+  if (v4) {
+    dim3 grid(cdiv(rows, 4)), blk(256);
+#define LV(TD, NV) hipLaunchKernelGGL((k_ln_bwd_v4<TD, NV>), grid, blk, 0, s, (const TD*)dy, ld_dy, x, ld_x, w, stats, dx, ld_dx, accumulate_dx, rows, (int)C)
+    if (dy_dt == VFM_BF16) { if (nv == 1) LV(bf16_t, 1); else if (nv == 2) LV(bf16_t, 2); else if (nv == 4) LV(bf16_t, 4); else LV(bf16_t, 5); }
+    else if (dy_dt == VFM_F32) { if (nv == 1) LV(float, 1); else if (nv == 2) LV(float, 2); else if (nv == 4) LV(float, 4); else LV(float, 5); }
+    else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_bwd: dtype");
+#undef LV
+    VFM_LAUNCH_CHECK();
+    return VFM_OK;
+  }
   const int parts = need_w ? 128 : cdiv(rows, 4);
   const size_t shm = need_w ? (size_t)4 * 2 * C * sizeof(float) : 0;
   float* wsp = need_w ? ws : nullptr;

@@ -260,12 +260,16 @@ extern "C" int vfm_unblock(const float* x, float* y, int B, int H, int W, int C,
 // recomputes that pixel's interpolated logits / softmax in registers, and gathers its own share of the gradient
 // (no atomics on floats, bitwise reproducible).  The owner (y0==y && x0==x) also accounts loss / accuracy.
 #define CE_CMAX 32
+// WPP = waves per low-res pixel: 1 (small footprints, 4 pixels per block) or 4 (large footprints: the block's four waves
+// split one pixel's candidates and meet in LDS)
+template <int WPP>
 __global__ void __launch_bounds__(256) k_upsample_ce(const float* __restrict__ lg, const int64_t* __restrict__ label, int B, int h,
                                                       int w, int C, int H, int W, int ignore, float sy, float sx,
                                                       float inv_total, float* __restrict__ loss_parts,
                                                       int32_t* __restrict__ counts, float* __restrict__ dlogits) {
-  const int lane = threadIdx.x & 63;
-  const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ float red[4][CE_CMAX + 4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long pix = WPP == 1 ? (long)blockIdx.x * 4 + wv : (long)blockIdx.x;
   if (pix >= (long)B * h * w) return;
   const int x = (int)(pix % w);
   const long t = pix / w;
@@ -284,7 +288,7 @@ __global__ void __launch_bounds__(256) k_upsample_ce(const float* __restrict__ l
   float loss = 0.f;
   int hits = 0, valid = 0;
   const float* lb = lg + b * (long)h * w * C;
-  for (int i = lane; i < nx * ny; i += 64) {
+  for (int i = (WPP == 1 ? lane : (int)threadIdx.x); i < nx * ny; i += 64 * WPP) {
     const int hy = hy0 + i / nx, hx = hx0 + i % nx;
     const Lerp ly = lerp_idx(hy, sy, h), lx = lerp_idx(hx, sx, w);
     const float wy = (ly.i0 == y ? ly.l0 : 0.f) + (ly.i1 == y ? ly.l1 : 0.f);
@@ -336,25 +340,55 @@ __global__ void __launch_bounds__(256) k_upsample_ce(const float* __restrict__ l
       }
     }
   }
-  if (dlogits) {
-#pragma unroll
-    for (int c = 0; c < CE_CMAX; ++c) {
-      if (c < C) {
-        const float s = wave_sum(acc[c]);
-        if (lane == 0) dlogits[pix * C + c] = s;
-      }
-    }
-  }
   loss = wave_sum(loss);
   for (int o = 32; o > 0; o >>= 1) {
     hits += __shfl_xor(hits, o, 64);
     valid += __shfl_xor(valid, o, 64);
   }
-  if (lane == 0) {
-    loss_parts[pix] = loss;
-    if (valid) {
-      atomicAdd(&counts[0], hits);
-      atomicAdd(&counts[1], valid);
+  if constexpr (WPP == 1) {
+    if (dlogits) {
+#pragma unroll
+      for (int c = 0; c < CE_CMAX; ++c) {
+        if (c < C) {
+          const float s = wave_sum(acc[c]);
+          if (lane == 0) dlogits[pix * C + c] = s;
+        }
+      }
+    }
+    if (lane == 0) {
+      loss_parts[pix] = loss;
+      if (valid) {
+        atomicAdd(&counts[0], hits);
+        atomicAdd(&counts[1], valid);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < CE_CMAX; ++c) {
+      if (c < C) {
+        const float s = wave_sum(acc[c]);
+        if (lane == 0) red[wv][c] = s;
+      }
+    }
+    if (lane == 0) {
+      red[wv][CE_CMAX] = loss;
+      red[wv][CE_CMAX + 1] = __int_as_float(hits);
+      red[wv][CE_CMAX + 2] = __int_as_float(valid);
+    }
+    __syncthreads();
+    if (threadIdx.x < C && dlogits)
+      dlogits[pix * C + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x == 0) {
+      loss_parts[pix] = (red[0][CE_CMAX] + red[1][CE_CMAX]) + (red[2][CE_CMAX] + red[3][CE_CMAX]);
+      int hsum = 0, vsum = 0;
+      for (int k = 0; k < 4; ++k) {
+        hsum += __float_as_int(red[k][CE_CMAX + 1]);
+        vsum += __float_as_int(red[k][CE_CMAX + 2]);
+      }
+      if (vsum) {
+        atomicAdd(&counts[0], hsum);
+        atomicAdd(&counts[1], vsum);
+      }
     }
   }
 }
@@ -364,9 +398,15 @@ extern "C" int vfm_upsample_ce(const float* logits_low, const int64_t* label, in
   VFM_CHECK(H >= h && W >= w, VFM_E_SHAPE, "vfm_upsample_ce: only up-sampling is supported");
   const long npix = (long)B * h * w;
   if (npix == 0) return VFM_OK;
-  hipLaunchKernelGGL(k_upsample_ce, dim3(cdiv(npix, 4)), dim3(256), 0, (hipStream_t)stream, logits_low, label, B, h, w, C, H, W,
-                     ignore_index, (float)h / (float)H, (float)w / (float)W, 1.0f / ((float)B * H * W), loss_parts, counts,
-                     dlogits);
+  const bool big = ((long)H * W) >= 64L * h * w;  // footprint (2*scale)^2 >= 256 candidates per low-res pixel
+  if (big)
+    hipLaunchKernelGGL(k_upsample_ce<4>, dim3((unsigned)npix), dim3(256), 0, (hipStream_t)stream, logits_low, label, B, h, w, C, H, W,
+                       ignore_index, (float)h / (float)H, (float)w / (float)W, 1.0f / ((float)B * H * W), loss_parts, counts,
+                       dlogits);
+  else
+    hipLaunchKernelGGL(k_upsample_ce<1>, dim3(cdiv(npix, 4)), dim3(256), 0, (hipStream_t)stream, logits_low, label, B, h, w, C, H, W,
+                       ignore_index, (float)h / (float)H, (float)w / (float)W, 1.0f / ((float)B * H * W), loss_parts, counts,
+                       dlogits);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }

@@ -58,20 +58,33 @@ def _pack(w, layout, dst):
     return dst
 
 
+def direct_grad_target(p):
+    """The optimiser (optim.FusedAdamW) pre-points every trainable parameter's .grad into one flat fp32 buffer that
+    is zeroed each step.  Backward kernels then accumulate straight into it (and hand autograd `None`), which removes
+    one allocation and one add-kernel per parameter per step."""
+    g = p.grad
+    if g is not None and g.dtype == torch.float32 and g.is_contiguous() and getattr(p, "_vfm_direct_grad", False):
+        return g
+    return None
+
+
 def _unpack_grad(g2d, layout, w):
-    """fp32 grad in param layout from the [N, >=K] GEMM-layout gradient."""
-    out = torch.empty_like(w, dtype=torch.float32)
+    """fp32 grad in param layout from the [N, >=K] GEMM-layout gradient (accumulated in place when the optimiser
+    exposes a flat gradient buffer; returns None in that case)."""
+    tgt = direct_grad_target(w)
+    acc = tgt is not None
+    out = tgt if acc else torch.empty_like(w, dtype=torch.float32)
     ld = g2d.stride(0)
     if layout in ("linear", "conv1x1"):
         n, k = _layout_dims(w, layout)
-        ops.strided_copy(g2d, out, (n, k), (ld, 1), (k, 1))
+        ops.strided_copy(g2d, out, (n, k), (ld, 1), (k, 1), accumulate=acc)
     elif layout == "conv2x2s2":
         co, ci = w.shape[0], w.shape[1]
-        ops.strided_copy(g2d, out, (co, 4, ci), (ld, ci, 1), (ci * 4, 1, 4))
+        ops.strided_copy(g2d, out, (co, 4, ci), (ld, ci, 1), (ci * 4, 1, 4), accumulate=acc)
     elif layout == "convT2x2":
         ci, co = w.shape[0], w.shape[1]
-        ops.strided_copy(g2d, out, (4, co, ci), (co * ld, ld, 1), (1, 4, co * 4))
-    return out
+        ops.strided_copy(g2d, out, (4, co, ci), (co * ld, ld, 1), (1, 4, co * 4), accumulate=acc)
+    return None if acc else out
 
 
 def _splitk_wgrad(dyt, x, out, kchunks, m_rows):
@@ -131,6 +144,7 @@ class LinearFn(torch.autograd.Function):
                  aux=aux, c2=pre)
         ctx.save_for_backward(x, wp, pre if pre is not None else (y if act == "relu" else None), mask, *weights)
         ctx.opts, ctx.dims, ctx.has_res, ctx.has_bias = opts, dims, residual is not None, bias is not None
+        ctx.bias_param = bias
         ctx.res_dtype = residual.dtype if residual is not None else None
         return y
 
@@ -167,13 +181,20 @@ class LinearFn(torch.autograd.Function):
                 ops.gemm(gv, wp, dx, trans_b=True)
         dbias = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            full = torch.empty(N, dtype=torch.float32, device=dy.device)
-            ops.colsum(gv, full)
+            btgt = direct_grad_target(ctx.bias_param) if ctx.bias_param is not None else None
             if bias_tile > 1:
-                dbias = torch.empty(N // bias_tile, dtype=torch.float32, device=dy.device)
-                ops.colsum(full.view(bias_tile, N // bias_tile), dbias)
+                full = torch.empty(N, dtype=torch.float32, device=dy.device)
+                ops.colsum(gv, full)
+                if btgt is not None:
+                    ops.colsum(full.view(bias_tile, N // bias_tile), btgt.view(-1), accumulate=True)
+                else:
+                    dbias = torch.empty(N // bias_tile, dtype=torch.float32, device=dy.device)
+                    ops.colsum(full.view(bias_tile, N // bias_tile), dbias)
+            elif btgt is not None:
+                ops.colsum(gv, btgt.view(-1), accumulate=True)
             else:
-                dbias = full
+                dbias = torch.empty(N, dtype=torch.float32, device=dy.device)
+                ops.colsum(gv, dbias)
         dws = [None] * len(weights)
         if any(ctx.needs_input_grad[4:]):
             gw = torch.empty(N, Kp, dtype=torch.float32, device=dy.device)

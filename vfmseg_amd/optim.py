@@ -105,6 +105,7 @@ class FusedAdamW:
                 ops.cast(p.detach().reshape(1, -1).contiguous(), self.flat[a:b].view(1, -1))
                 p.data = view
                 p.grad = self.gflat[a:b].view(p.shape)
+                p._vfm_direct_grad = True   # backward kernels accumulate straight into the flat buffer
         self.seg_start = torch.tensor(self.offsets[:-1], dtype=torch.int64, device=dev)
         self.seg_lr = torch.tensor([opts[nm][0] for nm in self.names], dtype=torch.float32, device=dev)
         self.seg_wd = torch.tensor([opts[nm][1] for nm in self.names], dtype=torch.float32, device=dev)
