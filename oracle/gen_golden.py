@@ -268,17 +268,68 @@ def gen_ms_inference(model):
     print("ms_inference refined", len(refined), "of 9;", out["pred_sha256"], out["pred_hist"])
 
 
+def gen_eva02(_model=None):
+    """EVA02-L + LoRA (q/k/v/attn.proj targets; only attn.proj is live): taps and LoRA gradients."""
+    M = ref_shim.load_eva02()
+    depth = 24
+    bcfg = presets.eva02_backbone(depth=depth)
+    bb = M.build(bcfg)
+    base_sd = {k: v for k, v in synth_like(bb.state_dict()).items() if "rope." not in k}  # keep the real cos/sin tables
+    out_rope = {"rope_cos": bb.rope.freqs_cos.numpy().copy(), "rope_sin": bb.rope.freqs_sin.numpy().copy()}
+    del bb
+    with tempfile.NamedTemporaryFile(suffix=".pth", delete=False) as f:
+        torch.save(base_sd, f.name)
+        ck = f.name
+    model = M.build(dict(type="LoRABackbone", backbone=bcfg, checkpoint=ck, Lora_config=presets.eva02_lora_cfg(dropout=0.0)))
+    os.unlink(ck)
+    sd = model.state_dict()
+    new = synth_like(sd)
+    for k in sd:
+        if "lora_" not in k:
+            new[k] = sd[k]
+    model.load_state_dict(new)
+    model.train()
+    x = synth_image(1, 512, seed=31)
+    taps = model(x)
+    out = {"rope_cos_slice": out_rope["rope_cos"][::97, ::5].copy(), "rope_sin_slice": out_rope["rope_sin"][::97, ::5].copy()}
+    gen = torch.Generator().manual_seed(6)
+    loss = 0
+    for i, t in enumerate(taps):
+        out[f"tap{i}_stats"] = stats(t)
+        out[f"tap{i}_slice"] = sl(t)
+        loss = loss + (t * torch.randn(t.shape, generator=gen)).sum()
+    loss.backward()
+    named = dict(model.named_parameters())
+    pre = "model.base_model.model.blocks."
+    live, inert = 0.0, 0
+    for k, p in named.items():
+        if "lora_" in k:
+            if p.grad is None or float(p.grad.abs().max()) == 0.0:
+                inert += 1
+            else:
+                live += p.grad.double().pow(2).sum().item()
+    out["lora_live_grad_norm"] = np.array([live ** 0.5])
+    out["lora_inert_count"] = np.array([inert])
+    for k in (pre + "0.attn.proj.lora_A.default.weight", pre + "0.attn.proj.lora_B.default.weight",
+              pre + "23.attn.proj.lora_A.default.weight", pre + "23.attn.proj.lora_B.default.weight"):
+        out["grad_slice::" + k] = sl(named[k].grad)
+    np.savez_compressed(os.path.join(GOLD, "eva02.npz"), **out)
+    print("eva02", {k: v[:2] for k, v in out.items() if k.endswith("stats")}, out["lora_live_grad_norm"], out["lora_inert_count"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    model = build_reference_model()
     steps = dict(dinov2=gen_dinov2, heads=gen_heads, train_step=gen_train_step, ms_inference=gen_ms_inference)
+    model = build_reference_model() if a.only in (None,) + tuple(steps) else None
     for name, fn in steps.items():
         if a.only in (None, name):
             fn(model)
+    if a.only in (None, "eva02"):
+        gen_eva02()
 
 
 if __name__ == "__main__":

@@ -142,6 +142,25 @@ def build_norm_layer(cfg, num_features, postfix=""):
     raise NotImplementedError(t)
 
 
+def _xformers_mea(q, k, v, attn_bias=None, p=0.0, scale=None):
+    """xformers.ops.memory_efficient_attention on (B, N, H, D) tensors == exact softmax attention, scale D^-0.5."""
+    assert attn_bias is None and p == 0.0
+    o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), scale=scale)
+    return o.transpose(1, 2)
+
+
+def _to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+def _drop_path(x, drop_prob=0.0, training=False):
+    if drop_prob == 0.0 or not training:
+        return x
+    keep = 1 - drop_prob
+    mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+    return x * mask / keep
+
+
 class BaseDecodeHead(BaseModule):
     def __init__(self, in_channels, channels, *, num_classes=None, out_channels=None, threshold=None,
                  dropout_ratio=0.1, conv_cfg=None, norm_cfg=None, act_cfg=dict(type="ReLU"), in_index=-1,
@@ -367,6 +386,12 @@ def install():
     _mod("mmseg.utils", SampleList=list, add_prefix=add_prefix)
     _mod("mmseg.structures", SegDataSample=SegDataSample)
     _mod("peft", LoraConfig=LoraConfig, get_peft_model=get_peft_model)
+    _mod("timm"), _mod("timm.models")
+    _mod("timm.models.layers", drop_path=_drop_path, to_2tuple=_to_2tuple, trunc_normal_=nn.init.trunc_normal_)
+    _mod("xformers")
+    _mod("xformers.ops", memory_efficient_attention=_xformers_mea)
+    sys.modules["xformers"].ops = sys.modules["xformers.ops"]
+    _mod(PKG + ".models.backbones.beit", load_checkpoint=lambda *a, **k: None)
     # synthetic parent packages: real directories on __path__, their __init__.py NOT executed
     rein = os.path.join(REF_ROOT, "rein")
     for name, path in [
@@ -397,4 +422,10 @@ def load_all():
     ref_import("models.heads.linear_head")
     ref_import("models.heads.VFMHead")
     ref_import("models.segmentors.Ms_VFM_encoder_decoder")
+    return MODELS
+
+
+def load_eva02():
+    load_all()
+    ref_import("models.backbones.eva_02")
     return MODELS

@@ -100,6 +100,66 @@ def dinov2_forward(sd, x, depth=24, heads=16, out_indices=(7, 11, 15, 23), patch
     return outs
 
 
+# =============================================================================== EVA02 backbone
+def eva_rope_tables(half_head_dim=32, pt_seq_len=16, ft_seq_len=32, theta=10000.0):
+    """VisionRotaryEmbeddingFast.__init__ (eva_02.py:119-157, freqs_for='lang'): cos/sin tables [ft*ft, 2*half_head_dim];
+    first half of the channels rotates with the row index, second half with the column index, pairs interleaved."""
+    freqs = 1.0 / (theta ** (torch.arange(0, half_head_dim, 2)[: half_head_dim // 2].float() / half_head_dim))
+    t = torch.arange(ft_seq_len) / ft_seq_len * pt_seq_len
+    f = torch.einsum("i,f->if", t, freqs).repeat_interleave(2, dim=-1)           # [ft, half]
+    fy = f[:, None, :].expand(ft_seq_len, ft_seq_len, -1)
+    fx = f[None, :, :].expand(ft_seq_len, ft_seq_len, -1)
+    fr = torch.cat((fy, fx), dim=-1).reshape(ft_seq_len * ft_seq_len, -1)
+    return fr.cos(), fr.sin()
+
+
+def rotate_half(x):
+    """eva_02.py:54-58: (x0, x1, x2, x3, ...) -> (-x1, x0, -x3, x2, ...)"""
+    x1, x2 = x[..., 0::2], x[..., 1::2]
+    return torch.stack((-x2, x1), dim=-1).flatten(-2)
+
+
+def eva02_block(sd, x, i, heads, cos, sin, lora=True, p=BB):
+    """eva_02.py:479-489 (init_values=None) with Attention.forward :333-379 (subln, rope, xattn) and SwiGLU :235-242.
+    q/k/v go through F.linear on the *base* weights, so LoRA on q_proj/k_proj/v_proj never enters the graph (Q1);
+    LoRA on attn.proj is live.  LayerNorm eps is nn.LayerNorm's default 1e-5 (the cfg norm_layer is ignored, :719)."""
+    q_ = f"{p}blocks.{i}."
+    b, n, c = x.shape
+    d = c // heads
+    h = F.layer_norm(x, (c,), sd[q_ + "norm1.weight"], sd[q_ + "norm1.bias"], 1e-5)
+    wkey = lambda nm: sd.get(q_ + f"attn.{nm}.base_layer.weight", sd.get(q_ + f"attn.{nm}.weight"))
+    q = F.linear(h, wkey("q_proj"), sd[q_ + "attn.q_bias"])
+    k = F.linear(h, wkey("k_proj"))
+    v = F.linear(h, wkey("v_proj"), sd[q_ + "attn.v_bias"])
+    sp = lambda t: t.reshape(b, n, heads, d).permute(0, 2, 1, 3)
+    q, k, v = sp(q), sp(k), sp(v)
+    rope = lambda t: torch.cat((t[:, :, :1], t[:, :, 1:] * cos + rotate_half(t[:, :, 1:]) * sin), dim=2)
+    q, k = rope(q), rope(k)
+    o = attention(q, k, v, d ** -0.5).transpose(1, 2).reshape(b, n, c)
+    o = lora_linear(sd, q_ + "attn.proj.", o, lora)
+    x = x + o
+    h = F.layer_norm(x, (c,), sd[q_ + "norm2.weight"], sd[q_ + "norm2.bias"], 1e-5)
+    x1 = F.linear(h, sd[q_ + "mlp.w1.weight"], sd[q_ + "mlp.w1.bias"])
+    x2 = F.linear(h, sd[q_ + "mlp.w2.weight"], sd[q_ + "mlp.w2.bias"])
+    hid = F.silu(x1) * x2
+    hid = F.layer_norm(hid, (hid.shape[-1],), sd[q_ + "mlp.ffn_ln.weight"], sd[q_ + "mlp.ffn_ln.bias"], 1e-5)
+    return x + F.linear(hid, sd[q_ + "mlp.w3.weight"], sd[q_ + "mlp.w3.bias"])
+
+
+def eva02_forward(sd, x, depth=24, heads=16, out_indices=(7, 11, 15, 23), patch=16, lora=True, p=BB, rope=None):
+    """EVA2.forward_features (eva_02.py:816-849): fixed abs pos-embed (input must be img_size), no final norm."""
+    b, _, hh, ww = x.shape
+    t = F.conv2d(x, sd[p + "patch_embed.proj.weight"], sd[p + "patch_embed.proj.bias"], stride=patch).flatten(2).transpose(1, 2)
+    t = torch.cat((sd[p + "cls_token"].expand(b, -1, -1), t), dim=1) + sd[p + "pos_embed"]
+    cos, sin = rope if rope is not None else eva_rope_tables(t.shape[-1] // heads // 2, 16, hh // patch)
+    outs = []
+    for i in range(depth):
+        t = eva02_block(sd, t, i, heads, cos, sin, lora, p)
+        if i in out_indices:
+            outs.append(t[:, 1:].permute(0, 2, 1).reshape(b, -1, hh // patch, ww // patch).contiguous())
+    return outs
+
+
 # =============================================================================== heads
 def batch_norm_train(x, w, b, running_mean, running_var, momentum=0.1, eps=1e-5, stats=None):
     """nn.SyncBatchNorm without a process group == BatchNorm2d (linear_head.py:44). Returns y and new running stats.

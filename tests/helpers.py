@@ -128,3 +128,53 @@ def rel_err(a, b):
     a = torch.as_tensor(a).double().cpu()
     b = torch.as_tensor(b).double().cpu()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def eva02_shapes(depth=24, dim=1024, r=32, hidden=2730, n_pos=1025):
+    """state_dict key -> shape of LoRABackbone(EVA2) under the 'backbone.' prefix (rope cos/sin buffers excluded:
+    they are deterministic tables, rebuilt by both sides)."""
+    s = {}
+    bb = "backbone.model.base_model.model."
+    s[bb + "cls_token"] = (1, 1, dim)
+    s[bb + "pos_embed"] = (1, n_pos, dim)
+    s[bb + "patch_embed.proj.weight"] = (dim, 3, 16, 16)
+    s[bb + "patch_embed.proj.bias"] = (dim,)
+    for i in range(depth):
+        q = f"{bb}blocks.{i}."
+        for n in ("norm1", "norm2"):
+            s[q + n + ".weight"] = (dim,)
+            s[q + n + ".bias"] = (dim,)
+        for nm in ("q_proj", "k_proj", "v_proj"):
+            s[q + f"attn.{nm}.base_layer.weight"] = (dim, dim)
+            s[q + f"attn.{nm}.lora_A.default.weight"] = (r, dim)
+            s[q + f"attn.{nm}.lora_B.default.weight"] = (dim, r)
+        s[q + "attn.q_bias"] = (dim,)
+        s[q + "attn.v_bias"] = (dim,)
+        s[q + "attn.proj.base_layer.weight"] = (dim, dim)
+        s[q + "attn.proj.base_layer.bias"] = (dim,)
+        s[q + "attn.proj.lora_A.default.weight"] = (r, dim)
+        s[q + "attn.proj.lora_B.default.weight"] = (dim, r)
+        s[q + "mlp.w1.weight"] = (hidden, dim)
+        s[q + "mlp.w1.bias"] = (hidden,)
+        s[q + "mlp.w2.weight"] = (hidden, dim)
+        s[q + "mlp.w2.bias"] = (hidden,)
+        s[q + "mlp.ffn_ln.weight"] = (hidden,)
+        s[q + "mlp.ffn_ln.bias"] = (hidden,)
+        s[q + "mlp.w3.weight"] = (dim, hidden)
+        s[q + "mlp.w3.bias"] = (dim,)
+    return s
+
+
+def eva02_state_dict(depth=24, dim=1024):
+    """Same construction as the reference loader path: base weights = synth of the un-renamed bare-backbone key,
+    LoRA factors = synth of the wrapped key (without the 'backbone.' prefix, as gen_golden builds a bare LoRABackbone)."""
+    shapes = eva02_shapes(depth, dim)
+    bb = "backbone.model.base_model.model."
+    wrapped = {k[len("backbone."):]: v for k, v in shapes.items()}
+    sd = {"backbone." + k: v for k, v in synth_state_dict(wrapped).items()}
+    bare = {k[len(bb):].replace(".base_layer", ""): v for k, v in shapes.items() if "lora_" not in k}
+    bare_sd = synth_state_dict(bare)
+    for k in list(sd):
+        if "lora_" not in k:
+            sd[k] = bare_sd[k[len(bb):].replace(".base_layer", "")]
+    return sd

@@ -113,6 +113,34 @@ def test_ms_inference_mask(golden_dir):
         assert np.abs(hist - G["pred_hist"]).sum() < 64
 
 
+@pytest.mark.slow
+def test_eva02_taps_and_lora_grads(golden_dir):
+    from tests.helpers import eva02_state_dict
+    G = _g(golden_dir, "eva02.npz")
+    sd = dict(eva02_state_dict())
+    cos, sin = R.eva_rope_tables(32, 16, 32)
+    assert rel_err(cos[::97, ::5], G["rope_cos_slice"]) < 1e-6 and rel_err(sin[::97, ::5], G["rope_sin_slice"]) < 1e-6
+    tk = [k for k in sd if "lora_" in k]
+    for k in tk:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    taps = R.eva02_forward(sd, synth_image(1, 512, seed=31))
+    gen = torch.Generator().manual_seed(6)
+    loss = 0
+    for i, t in enumerate(taps):
+        assert rel_err(sl(t), G[f"tap{i}_slice"]) < TOL
+        np.testing.assert_allclose(stats(t), G[f"tap{i}_stats"], rtol=1e-3, atol=1e-5)
+        loss = loss + (t * torch.randn(t.shape, generator=gen)).sum()
+    grads = dict(zip(tk, torch.autograd.grad(loss, [sd[k] for k in tk], allow_unused=True)))
+    inert = sum(1 for g in grads.values() if g is None or float(g.abs().max()) == 0.0)
+    assert inert == int(G["lora_inert_count"][0])          # q/k/v LoRA never enters the graph
+    live = sum(g.double().pow(2).sum().item() for g in grads.values() if g is not None) ** 0.5
+    np.testing.assert_allclose(live, G["lora_live_grad_norm"][0], rtol=1e-3)
+    for name in G.files:
+        if name.startswith("grad_slice::"):
+            k = "backbone." + name.split("::", 1)[1]
+            assert rel_err(sl(grads[k]), G[name]) < 2e-3, k
+
+
 def test_optimizer_rules():
     ck = {"norm": dict(decay_mult=0.0), "query_embed": dict(lr_mult=1.0, decay_mult=0.0)}
     assert R.param_group_options("aux_decoder.transformer_decoder.norm.weight", True, custom_keys=ck) == (1e-4, 0.0)

@@ -129,3 +129,17 @@ def optim_cfg():
         ),
         param_scheduler=[dict(type="PolyLR", eta_min=0, power=0.9, begin=0, end=40000, by_epoch=False)],
     )
+
+
+def eva02_backbone(depth=24, embed_dim=1024, num_heads=16, img_size=512):
+    """configs/_base_/models/lora_eva02_ms_masked.py:25-49"""
+    return dict(type="EVA2", depth=depth, drop_path_rate=0.1, embed_dim=embed_dim, img_size=img_size, in_chans=3,
+                init_values=None, intp_freq=True, mlp_ratio=2.6666666666666665, naiveswiglu=True,
+                norm_layer=dict(eps=1e-06, requires_grad=True, type="LN"), num_heads=num_heads,
+                out_indices=[7, 11, 15, 23], patch_size=16, pt_hw_seq_len=16, qkv_bias=True, rope=True, subln=True,
+                use_abs_pos_emb=True, use_checkpoint=False, use_rel_pos_bias=False, use_shared_rel_pos_bias=False, xattn=True)
+
+
+def eva02_lora_cfg(dropout=0.1):
+    """configs/_base_/models/lora_eva02_ms_masked.py:17-23"""
+    return dict(r=32, lora_alpha=32, target_modules=["q_proj", "k_proj", "v_proj", "attn.proj"], lora_dropout=dropout)
