@@ -59,6 +59,14 @@ int vfm_mul_mask(const void* src, int src_dt, long ld_src, const void* mask, int
 int vfm_geglu_fwd(const void* h, int h_dt, long ld_h, void* out, int out_dt, long ld_out, long rows, long C, void* stream);
 int vfm_geglu_bwd(const void* h, int h_dt, long ld_h, const void* dout, int do_dt, long ld_do, void* dh, int dh_dt,
                   long ld_dh, long rows, long C, void* stream);
+/* SwiGLU (eva_02.py:235-242): out[r,c] = silu(h[r,c]) * h[r, C+c],  h is [rows, 2C] */
+int vfm_swiglu_fwd(const void* h, int h_dt, long ld_h, void* out, int out_dt, long ld_out, long rows, long C, void* stream);
+int vfm_swiglu_bwd(const void* h, int h_dt, long ld_h, const void* dout, int do_dt, long ld_do, void* dh, int dh_dt,
+                   long ld_dh, long rows, long C, void* stream);
+/* 2-D rotary embedding in place (eva_02.py:119-160, 362-369): y = x*cos + rotate_half(x)*sin on columns [0,ncols) = heads
+ * of width d of rows whose token index is row % np; cos/sin fp32 [np, d]; inverse=1 applies the transpose (backward) */
+int vfm_rope(void* x, int dt, long ld, long rows, int np, int ncols, int d, const float* cos_t, const float* sin_t,
+             int inverse, void* stream);
 /* out[r,c] = dy[r,c] * act'(pre[r,c])  (act: VFM_ACT_GELU on the saved pre-activation; VFM_ACT_RELU may be given the
  * post-activation, the sign test is identical) */
 int vfm_act_grad_mul(const void* dy, int dy_dt, long ld_dy, const void* pre, int pre_dt, long ld_pre, void* out, int out_dt,

@@ -72,3 +72,48 @@ def test_api_views_match_reference_layout():
         assert rel_err(feats[3].cpu(), ref[3]) < 2e-4
     finally:
         set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("mode,tol,gtol", [("f32", 3e-4, 3e-3), ("bf16", 3e-2, 1e-1)])
+def test_eva02_taps_and_lora_grads(mode, tol, gtol):
+    """EVA02 (rope, SwiGLU with inner LN, LoRA on attn.proj; q/k/v adapters inert) vs the CPU oracle, depth 4."""
+    from tests.helpers import eva02_state_dict
+    import vfmseg_amd.eva  # noqa: F401
+    set_compute_dtype(mode)
+    try:
+        sd = eva02_state_dict(depth=DEPTH)
+        cfg = dict(type="LoRABackbone", backbone=dict(presets.eva02_backbone(depth=DEPTH), out_indices=list(OUT)),
+                   Lora_config=presets.eva02_lora_cfg(dropout=0.0))
+        m = MODELS.build(cfg)
+        bsd = {k[len("backbone."):]: v for k, v in sd.items()}
+        missing, unexpected = m.load_state_dict(bsd, strict=False)
+        assert not unexpected and all("rope" in k for k in missing), (missing, unexpected)
+        m = m.cuda()
+        img = synth_image(1, 512, seed=23)
+        sdo = dict(sd)
+        tk = [k for k in sd if "attn.proj.lora_" in k]
+        for k in tk:
+            sdo[k] = sd[k].clone().requires_grad_(True)
+        taps = R.eva02_forward(sdo, img, depth=DEPTH, out_indices=OUT)
+        gen = torch.Generator().manual_seed(5)
+        dts = [torch.randn(t.shape, generator=gen) for t in taps]
+        loss = sum((t * d).sum() for t, d in zip(taps, dts))
+        og = dict(zip(tk, torch.autograd.grad(loss, [sdo[k] for k in tk])))
+        xcat, (hp, wp) = m.forward_tokens([(img.cuda(), None)])
+        v = xcat.float().view(1, 32, 32, 4, 1024)
+        for i, t in enumerate(taps):
+            e = rel_err(v[:, :, :, i].permute(0, 3, 1, 2).cpu(), t.detach())
+            assert e < tol, (i, e)
+        dx = torch.stack([d.permute(0, 2, 3, 1) for d in dts], dim=3).reshape(1024, 4 * 1024).to(xcat.dtype).cuda()
+        xcat.backward(dx)
+        n_live = 0
+        for n, p in m.named_parameters():
+            if "attn.proj.lora_" in n:
+                e = rel_err(p.grad.cpu(), og["backbone." + n])
+                assert e < gtol, (n, e)
+                n_live += 1
+            elif "lora_" in n:
+                assert not p.requires_grad and p.grad is None   # inert adapters (SURVEY Q1)
+        assert n_live == 2 * DEPTH
+    finally:
+        set_compute_dtype("bf16")

@@ -152,10 +152,16 @@ class LoRABackbone(nn.Module):
         vit = MODELS.build(backbone)
         cfg = Lora_config or {}
         self.lora_targets = list(cfg.get("target_modules", ["qkv"]))
-        if self.lora_targets != ["qkv"]:
-            raise NotImplementedError("HIP path fuses LoRA into the qkv projection (target_modules=['qkv'])")
-        for blk in vit.blocks:
-            blk.attn.qkv = LoraLinear(blk.attn.qkv, cfg.get("r", 32), cfg.get("lora_alpha", 32), cfg.get("lora_dropout", 0.0))
+        # peft: a module is wrapped when its dotted name equals a target or ends with '.' + target
+        for name, mod in list(vit.named_modules()):
+            if isinstance(mod, _Lin) and any(name == t or name.endswith("." + t) for t in self.lora_targets):
+                parent = vit
+                parts = name.split(".")
+                for p_ in parts[:-1]:
+                    parent = getattr(parent, p_)
+                setattr(parent, parts[-1], LoraLinear(mod, cfg.get("r", 32), cfg.get("lora_alpha", 32), cfg.get("lora_dropout", 0.0)))
+        if not vit.engine().lora_on():
+            raise NotImplementedError(f"target_modules={self.lora_targets}: no adapter site the {type(vit).__name__} HIP engine fuses")
         self.model = _PeftModel(vit)
         self._lora_train = False
         if checkpoint is not None:
@@ -184,6 +190,11 @@ class LoRABackbone(nn.Module):
         self._lora_train = bool(mode)
         for n, p in self.named_parameters():
             p.requires_grad = ("lora" in n) if mode else p.requires_grad
+        if mode:
+            # adapters that never enter the graph (EVA02 q/k/v) would only ever see weight decay here;
+            # torch's AdamW skips grad-less parameters, so they are simply kept frozen
+            for p in getattr(self.vit.engine(), "inert_params", lambda: [])():
+                p.requires_grad = False
         return self
 
     def forward_tokens(self, jobs, seed=0):

@@ -278,6 +278,87 @@ extern "C" int vfm_geglu_bwd(const void* h, int h_dt, long ld_h, const void* dou
   return VFM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ SwiGLU
+// eva_02.py:235-242: hidden = silu(x1) * x2 with h = [x1 | x2] ([rows, 2C])
+__global__ void k_swiglu_fwd(const void* __restrict__ h, int h_dt, long ld_h, void* __restrict__ out, int out_dt, long ld_out,
+                             long rows, long C) {
+  const long total = rows * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C, c = i - r * C;
+    const float a = ld_any(h, r * ld_h + c, h_dt), g = ld_any(h, r * ld_h + C + c, h_dt);
+    st_any(out, r * ld_out + c, out_dt, a / (1.f + __expf(-a)) * g);
+  }
+}
+__global__ void k_swiglu_bwd(const void* __restrict__ h, int h_dt, long ld_h, const void* __restrict__ dout, int do_dt,
+                             long ld_do, void* __restrict__ dh, int dh_dt, long ld_dh, long rows, long C) {
+  const long total = rows * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / C, c = i - r * C;
+    const float a = ld_any(h, r * ld_h + c, h_dt), g = ld_any(h, r * ld_h + C + c, h_dt);
+    const float d = ld_any(dout, r * ld_do + c, do_dt);
+    const float sg = 1.f / (1.f + __expf(-a));
+    st_any(dh, r * ld_dh + c, dh_dt, d * g * sg * (1.f + a * (1.f - sg)));
+    st_any(dh, r * ld_dh + C + c, dh_dt, d * a * sg);
+  }
+}
+extern "C" int vfm_swiglu_fwd(const void* h, int h_dt, long ld_h, void* out, int out_dt, long ld_out, long rows, long C,
+                              void* stream) {
+  const long total = rows * C;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_swiglu_fwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, h_dt, ld_h, out, out_dt, ld_out, rows, C);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+extern "C" int vfm_swiglu_bwd(const void* h, int h_dt, long ld_h, const void* dout, int do_dt, long ld_do, void* dh, int dh_dt,
+                              long ld_dh, long rows, long C, void* stream) {
+  const long total = rows * C;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_swiglu_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, h_dt, ld_h, dout, do_dt, ld_do, dh, dh_dt,
+                     ld_dh, rows, C);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ RoPE
+// eva_02.py:119-160 / 362-369: y = x*cos + rotate_half(x)*sin on the q and k heads of the patch tokens, in place.
+// x: [rows, ld], columns [0, ncols) are consecutive heads of width d; token t = row % np indexes the [np, d] tables.
+// inverse=1 applies the transpose (the gradient of the rotation).
+__global__ void k_rope(void* __restrict__ x, int dt, long ld, long rows, int np, int ncols, int d, const float* __restrict__ cs,
+                       const float* __restrict__ sn, int inverse) {
+  const long half = ncols / 2;
+  const long total = rows * half;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / half;
+    const int c0 = (int)(i - r * half) * 2;
+    const int t = (int)(r % np), dc = c0 % d;
+    const float x0 = ld_any(x, r * ld + c0, dt), x1 = ld_any(x, r * ld + c0 + 1, dt);
+    const float c_0 = cs[(long)t * d + dc], c_1 = cs[(long)t * d + dc + 1];
+    const float s_0 = sn[(long)t * d + dc], s_1 = sn[(long)t * d + dc + 1];
+    float y0, y1;
+    if (!inverse) {
+      y0 = x0 * c_0 - x1 * s_0;
+      y1 = x1 * c_1 + x0 * s_1;
+    } else {
+      y0 = x0 * c_0 + x1 * s_1;
+      y1 = x1 * c_1 - x0 * s_0;
+    }
+    st_any(x, r * ld + c0, dt, y0);
+    st_any(x, r * ld + c0 + 1, dt, y1);
+  }
+}
+extern "C" int vfm_rope(void* x, int dt, long ld, long rows, int np, int ncols, int d, const float* cos_t, const float* sin_t,
+                        int inverse, void* stream) {
+  VFM_CHECK(d % 2 == 0 && ncols % d == 0 && np > 0, VFM_E_SHAPE, "vfm_rope: shape");
+  const long total = rows * (ncols / 2);
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_rope, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, dt, ld, rows, np, ncols, d, cos_t, sin_t, inverse);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ act grad
 __global__ void k_act_grad_mul(const void* __restrict__ dy, int dy_dt, long ld_dy, const void* __restrict__ pre, int pre_dt,
                                long ld_pre, void* __restrict__ out, int out_dt, long ld_out, long rows, long cols, int act) {

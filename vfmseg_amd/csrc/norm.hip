@@ -137,7 +137,7 @@ __global__ void k_ln_bwd_v4(const TD* __restrict__ dy, long ld_dy, const float* 
 
 extern "C" int vfm_layernorm_fwd(const float* x, long ld_x, const float* w, const float* b, float eps, void* y, int y_dt,
                                  long ld_y, float* stats, long rows, long C, void* stream) {
-  VFM_CHECK(C > 0 && C <= 2048 && ld_x >= C && ld_y >= C, VFM_E_SHAPE, "vfm_layernorm_fwd: C=%ld unsupported", C);
+  VFM_CHECK(C > 0 && C <= 3072 && ld_x >= C && ld_y >= C, VFM_E_SHAPE, "vfm_layernorm_fwd: C=%ld unsupported", C);
   if (rows == 0) return VFM_OK;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(cdiv(rows, 4)), blk(256);
@@ -157,8 +157,8 @@ extern "C" int vfm_layernorm_fwd(const float* x, long ld_x, const float* w, cons
   }
 #define L(TO, PL) hipLaunchKernelGGL((k_ln_fwd<TO, PL>), grid, blk, 0, s, x, ld_x, w, b, eps, (TO*)y, ld_y, stats, rows, (int)C)
   const int pl = (int)((C + 63) / 64);
-  if (y_dt == VFM_BF16) { if (pl <= 4) L(bf16_t, 4); else if (pl <= 16) L(bf16_t, 16); else L(bf16_t, 32); }
-  else if (y_dt == VFM_F32) { if (pl <= 4) L(float, 4); else if (pl <= 16) L(float, 16); else L(float, 32); }
+  if (y_dt == VFM_BF16) { if (pl <= 4) L(bf16_t, 4); else if (pl <= 16) L(bf16_t, 16); else if (pl <= 32) L(bf16_t, 32); else L(bf16_t, 48); }
+  else if (y_dt == VFM_F32) { if (pl <= 4) L(float, 4); else if (pl <= 16) L(float, 16); else if (pl <= 32) L(float, 32); else L(float, 48); }
   else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_fwd: dtype");
 #undef L
   VFM_LAUNCH_CHECK();
@@ -166,14 +166,14 @@ extern "C" int vfm_layernorm_fwd(const float* x, long ld_x, const float* w, cons
 }
 
 // backward: one wave per row for dx; per-block partial dw/db in LDS -> ws[block][2][C]
-template <typename TD, int MAXPL>
+template <typename TD, int MAXPL, bool NEED_W>
 __global__ void k_ln_bwd(const TD* __restrict__ dy, long ld_dy, const float* __restrict__ x, long ld_x,
                          const float* __restrict__ w, const float* __restrict__ stats, float* __restrict__ dx, long ld_dx,
                          int accumulate_dx, float* __restrict__ ws, long rows, int C) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  float pdw[MAXPL], pdb[MAXPL];
+  float pdw[NEED_W ? MAXPL : 1], pdb[NEED_W ? MAXPL : 1];
 #pragma unroll
-  for (int i = 0; i < MAXPL; ++i) pdw[i] = pdb[i] = 0.f;
+  for (int i = 0; i < (NEED_W ? MAXPL : 1); ++i) pdw[i] = pdb[i] = 0.f;
   for (long row = (long)blockIdx.x * nw + wv; row < rows; row += (long)gridDim.x * nw) {
     const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
     float g[MAXPL], xh[MAXPL];
@@ -187,8 +187,10 @@ __global__ void k_ln_bwd(const TD* __restrict__ dy, long ld_dy, const float* __r
         g[i] = d * w[c];
         s1 += g[i];
         s2 += g[i] * xh[i];
-        pdw[i] += d * xh[i];
-        pdb[i] += d;
+        if constexpr (NEED_W) {
+          pdw[i] += d * xh[i];
+          pdb[i] += d;
+        }
       } else {
         g[i] = xh[i] = 0.f;
       }
@@ -205,7 +207,7 @@ __global__ void k_ln_bwd(const TD* __restrict__ dy, long ld_dy, const float* __r
       }
     }
   }
-  if (ws) {
+  if constexpr (NEED_W) {
     extern __shared__ float sh[];  // [nw][2][C]
 #pragma unroll
     for (int i = 0; i < MAXPL; ++i) {
@@ -239,7 +241,7 @@ __global__ void k_ln_bwd_fin(const float* __restrict__ ws, int parts, int C, flo
 extern "C" int vfm_layernorm_bwd(const void* dy, int dy_dt, long ld_dy, const float* x, long ld_x, const float* w,
                                  const float* stats, float* dx, long ld_dx, int accumulate_dx, float* dw, float* db,
                                  float* ws, long rows, long C, void* stream) {
-  VFM_CHECK(C > 0 && C <= 1024, VFM_E_SHAPE, "vfm_layernorm_bwd: C=%ld unsupported", C);
+  VFM_CHECK(C > 0 && (C <= 1024 || (C <= 3072 && !(dw || db))), VFM_E_SHAPE, "vfm_layernorm_bwd: C=%ld unsupported", C);
   VFM_CHECK(!(dw || db) || ws, VFM_E_INVAL, "vfm_layernorm_bwd: ws required for dw/db");
   if (rows == 0) return VFM_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -261,11 +263,17 @@ extern "C" int vfm_layernorm_bwd(const void* dy, int dy_dt, long ld_dy, const fl
   const int parts = need_w ? 128 : cdiv(rows, 4);
   const size_t shm = need_w ? (size_t)4 * 2 * C * sizeof(float) : 0;
   float* wsp = need_w ? ws : nullptr;
-#define L(TD, PL) hipLaunchKernelGGL((k_ln_bwd<TD, PL>), dim3(parts), dim3(256), shm, s, (const TD*)dy, ld_dy, x, ld_x, w, stats, dx, ld_dx, accumulate_dx, wsp, rows, (int)C)
+#define L(TD, PL, NW) hipLaunchKernelGGL((k_ln_bwd<TD, PL, NW>), dim3(parts), dim3(256), shm, s, (const TD*)dy, ld_dy, x, ld_x, w, stats, dx, ld_dx, accumulate_dx, wsp, rows, (int)C)
   const int pl = (int)((C + 63) / 64);
-  if (dy_dt == VFM_BF16) { if (pl <= 4) L(bf16_t, 4); else L(bf16_t, 16); }
-  else if (dy_dt == VFM_F32) { if (pl <= 4) L(float, 4); else L(float, 16); }
-  else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_bwd: dtype");
+  if (need_w) {
+    if (dy_dt == VFM_BF16) { if (pl <= 4) L(bf16_t, 4, true); else L(bf16_t, 16, true); }
+    else if (dy_dt == VFM_F32) { if (pl <= 4) L(float, 4, true); else L(float, 16, true); }
+    else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_bwd: dtype");
+  } else {
+    if (dy_dt == VFM_BF16) { if (pl <= 4) L(bf16_t, 4, false); else if (pl <= 16) L(bf16_t, 16, false); else L(bf16_t, 48, false); }
+    else if (dy_dt == VFM_F32) { if (pl <= 4) L(float, 4, false); else if (pl <= 16) L(float, 16, false); else L(float, 48, false); }
+    else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_bwd: dtype");
+  }
 #undef L
   if (need_w) hipLaunchKernelGGL(k_ln_bwd_fin, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, parts, (int)C, dw, db);
   VFM_LAUNCH_CHECK();

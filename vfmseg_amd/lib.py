@@ -58,6 +58,9 @@ SIGNATURES = {
     "vfm_mul_mask": [vp, ci, cl, vp, ci, cl, cl, vp, ci, cl, cl, cl, vp],
     "vfm_geglu_fwd": [vp, ci, cl, vp, ci, cl, cl, cl, vp],
     "vfm_geglu_bwd": [vp, ci, cl, vp, ci, cl, vp, ci, cl, cl, cl, vp],
+    "vfm_swiglu_fwd": [vp, ci, cl, vp, ci, cl, cl, cl, vp],
+    "vfm_swiglu_bwd": [vp, ci, cl, vp, ci, cl, vp, ci, cl, cl, cl, vp],
+    "vfm_rope": [vp, ci, cl, cl, ci, ci, ci, vp, vp, ci, vp],
     "vfm_act_grad_mul": [vp, ci, cl, vp, ci, cl, vp, ci, cl, cl, cl, ci, vp],
     "vfm_mask_token_fwd": [vp, vp, vp, vp, cl, cl, vp],
     "vfm_mask_token_bwd": [vp, vp, vp, vp, cl, cl, vp],

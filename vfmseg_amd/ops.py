@@ -121,6 +121,28 @@ def geglu_bwd(h, dout, dh):
     return dh
 
 
+def swiglu_fwd(h, out, C_):
+    lib = L.load()
+    L.check(lib.vfm_swiglu_fwd(L.ptr(h), L.dt_of(h), _ld(h), L.ptr(out), L.dt_of(out), _ld(out), h.shape[0], C_, L.stream()),
+            "vfm_swiglu_fwd")
+    return out
+
+
+def swiglu_bwd(h, dout, dh, C_):
+    lib = L.load()
+    L.check(lib.vfm_swiglu_bwd(L.ptr(h), L.dt_of(h), _ld(h), L.ptr(dout), L.dt_of(dout), _ld(dout), L.ptr(dh), L.dt_of(dh),
+                               _ld(dh), h.shape[0], C_, L.stream()), "vfm_swiglu_bwd")
+    return dh
+
+
+def rope(x, rows, np_, ncols, d, cos_t, sin_t, inverse=False):
+    """In place on columns [0, ncols) of the first `rows` rows of the 2-D view x."""
+    lib = L.load()
+    L.check(lib.vfm_rope(L.ptr(x), L.dt_of(x), _ld(x), rows, np_, ncols, d, L.ptr(cos_t), L.ptr(sin_t), int(inverse), L.stream()),
+            "vfm_rope")
+    return x
+
+
 def act_grad_mul(dy, pre, out, act):
     lib = L.load()
     L.check(lib.vfm_act_grad_mul(L.ptr(dy), L.dt_of(dy), _ld(dy), L.ptr(pre), L.dt_of(pre), _ld(pre), L.ptr(out),
