@@ -281,14 +281,19 @@ def get_crop_bbox(img_h, img_w, crop_size, divisible=1, rng=np.random):
 
 
 def forward_train(sd, img, label, hr_box, mask_keep, depth=24, heads=16, out_indices=(7, 11, 15, 23),
-                  lora_drop_masks=(None, None), drop2d=(None, None), detail_loss=1.0, bn_out=None, dec_depth=3):
+                  lora_drop_masks=(None, None), drop2d=(None, None), detail_loss=1.0, bn_out=None, dec_depth=3,
+                  backbone="dinov2"):
     """MsVFMEncoderDecoder.forward_train (Ms_VFM_encoder_decoder.py:125-200) with the RNG consumers made explicit
     (SURVEY App. B): hr_box = (y1,y2,x1,x2), mask_keep = bool [B,1,32,32], optional dropout multipliers."""
     y1, y2, x1, x2 = hr_box
     lr_img = F.interpolate(img, scale_factor=0.5, mode="bilinear", align_corners=False)  # scales sorted [0.5, 1] (:87)
     hr_img = img[:, :, y1:y2, x1:x2]
-    lr_feats = dinov2_forward(sd, lr_img, depth, heads, out_indices, drop_masks=lora_drop_masks[0])
-    hr_feats = dinov2_forward(sd, hr_img, depth, heads, out_indices, drop_masks=lora_drop_masks[1])
+    if backbone == "eva02":
+        lr_feats = eva02_forward(sd, lr_img, depth, heads, out_indices)
+        hr_feats = eva02_forward(sd, hr_img, depth, heads, out_indices)
+    else:
+        lr_feats = dinov2_forward(sd, lr_img, depth, heads, out_indices, drop_masks=lora_drop_masks[0])
+        hr_feats = dinov2_forward(sd, hr_img, depth, heads, out_indices, drop_masks=lora_drop_masks[1])
     lr_gt = F.interpolate(label.float(), scale_factor=0.5, mode="nearest").long()  # get_lr_seg (:148-153)
     hr_gt = label[:, :, y1:y2, x1:x2]  # get_hr_seg (:155-158)
     lr_logits = linear_head_forward(sd, lr_feats, training=True, drop2d=drop2d[0], bn_out=bn_out)

@@ -154,3 +154,38 @@ def test_ms_inference_matches_reference_golden(golden_dir):
             assert np.abs(hist - G["pred_hist"]).sum() < 200
     finally:
         set_compute_dtype("bf16")
+
+
+def test_eva02_train_step_matches_oracle():
+    """BASELINE config 4 (EVA02-L + LoRA + LinearHead + VFMHead), depth 4, full forward_train + backward vs the oracle."""
+    from tests.helpers import eva02_state_dict, full_state_dict
+    set_compute_dtype("f32")
+    try:
+        depth, out_idx = 4, [0, 1, 2, 3]
+        cfg = presets.eva02_ms_masked(depth=depth)
+        cfg["backbone"]["backbone"]["out_indices"] = out_idx
+        cfg["backbone"]["Lora_config"]["lora_dropout"] = 0.0
+        sd = {k: v for k, v in full_state_dict(depth=1).items() if not k.startswith("backbone.")}
+        sd.update(eva02_state_dict(depth=depth))
+        model = MODELS.build(cfg)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not unexpected and all("rope" in k for k in missing), (missing, unexpected)
+        model = model.cuda().train()
+        _zero_dropout(model)
+        box = (128, 640, 256, 768)
+        keep = torch.rand(2, 1, 32, 32, generator=torch.Generator().manual_seed(4)) > 0.2
+        model.fixed_crop_box, model.aux_decoder.transformer_decoder.fixed_keep = box, keep
+        img, lab = synth_image(2, 1024, seed=13), synth_label(2, 1024, seed=13)
+        losses = model.loss(img.cuda(), [SegDataSample(gt_sem_seg=lab[i]) for i in range(2)])
+        total, _ = model.parse_losses(losses)
+        total.backward()
+        key = "backbone.model.base_model.model.blocks.1.attn.proj.lora_B.default.weight"
+        sdo = {k: v.clone() for k, v in sd.items()}
+        sdo[key].requires_grad_(True)
+        lo = R.forward_train(sdo, img, lab, box, keep, depth=depth, out_indices=tuple(out_idx), backbone="eva02")
+        ref_g, = torch.autograd.grad(R.total_loss(lo), [sdo[key]])
+        for k in ("decode_lr.loss_ce", "decode_hr.loss_ce"):
+            assert abs(float(losses[k]) - float(lo[k])) <= 3e-4 * max(1.0, abs(float(lo[k]))), (k, float(losses[k]), float(lo[k]))
+        assert rel_err(dict(model.named_parameters())[key].grad.cpu(), ref_g) < 5e-3
+    finally:
+        set_compute_dtype("bf16")

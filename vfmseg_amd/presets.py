@@ -143,3 +143,11 @@ def eva02_backbone(depth=24, embed_dim=1024, num_heads=16, img_size=512):
 def eva02_lora_cfg(dropout=0.1):
     """configs/_base_/models/lora_eva02_ms_masked.py:17-23"""
     return dict(r=32, lora_alpha=32, target_modules=["q_proj", "k_proj", "v_proj", "attn.proj"], lora_dropout=dropout)
+
+
+def eva02_ms_masked(depth=24, checkpoint=None, work_dir="work_dirs/tmp"):
+    """configs/_base_/models/lora_eva02_ms_masked.py (BASELINE config 4): EVA02-L + LoRA, LinearHead + VFMHead."""
+    cfg = dinov2_ms_masked(work_dir=work_dir)
+    cfg["backbone"] = dict(type="LoRABackbone", backbone=eva02_backbone(depth), checkpoint=checkpoint, Lora_config=eva02_lora_cfg())
+    cfg["test_cfg"] = dict(mode="hr_slide_inference", stride=[320, 320], crop_size=[512, 512])  # fixed 512^2 grid (SURVEY Q3)
+    return cfg
