@@ -317,6 +317,37 @@ def gen_eva02(_model=None):
     print("eva02", {k: v[:2] for k, v in out.items() if k.endswith("stats")}, out["lora_live_grad_norm"], out["lora_inert_count"])
 
 
+def gen_sam(_model=None):
+    """SAM-ViT-H + LoRA(qkv): taps of one 512^2 crop (28 windowed + 4 global blocks, decomposed rel-pos with non-zero tables)."""
+    M = ref_shim.load_sam()
+    bcfg = presets.sam_backbone()
+    bb = M.build(bcfg)
+    base_sd = synth_like(bb.state_dict())
+    del bb
+    with tempfile.NamedTemporaryFile(suffix=".pth", delete=False) as f:
+        torch.save(base_sd, f.name)
+        ck = f.name
+    model = M.build(dict(type="LoRABackbone", backbone=bcfg, checkpoint=ck, Lora_config=presets.lora_cfg(dropout=0.0)))
+    os.unlink(ck)
+    sd = model.state_dict()
+    new = synth_like(sd)
+    for k in sd:
+        if "lora_" not in k:
+            new[k] = sd[k]
+    model.load_state_dict(new)
+    model.eval()
+    x = synth_image(1, 512, seed=41)
+    with torch.no_grad():
+        taps = model(x)
+    out = {}
+    for i, t in enumerate(taps):
+        out[f"tap{i}_stats"] = stats(t)
+        out[f"tap{i}_slice"] = sl(t)
+        out[f"tap{i}_tail"] = t[0, -4:, -3:, -5:].numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, "sam.npz"), **out)
+    print("sam", {k: v[:2] for k, v in out.items() if k.endswith("stats")})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -324,12 +355,14 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     steps = dict(dinov2=gen_dinov2, heads=gen_heads, train_step=gen_train_step, ms_inference=gen_ms_inference)
-    model = build_reference_model() if a.only in (None,) + tuple(steps) else None
+    model = build_reference_model() if a.only in (None,) + tuple(steps) else None  # noqa: E501
     for name, fn in steps.items():
         if a.only in (None, name):
             fn(model)
     if a.only in (None, "eva02"):
         gen_eva02()
+    if a.only in (None, "sam"):
+        gen_sam()
 
 
 if __name__ == "__main__":

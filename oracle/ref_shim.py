@@ -425,6 +425,12 @@ def load_all():
     return MODELS
 
 
+def load_sam():
+    load_all()
+    ref_import("models.backbones.sam_vit")
+    return MODELS
+
+
 def load_eva02():
     load_all()
     ref_import("models.backbones.eva_02")

@@ -160,6 +160,69 @@ def eva02_forward(sd, x, depth=24, heads=16, out_indices=(7, 11, 15, 23), patch=
     return outs
 
 
+# =============================================================================== SAM backbone
+def sam_rel_pos(q_size, k_size, rel_pos):
+    """sam_vit.py:359-389 get_rel_pos: (optionally linearly re-interpolated) table gathered at q - k + (k_size-1)."""
+    max_rel = int(2 * max(q_size, k_size) - 1)
+    if rel_pos.shape[0] != max_rel:
+        r = F.interpolate(rel_pos.reshape(1, rel_pos.shape[0], -1).permute(0, 2, 1), size=max_rel, mode="linear")
+        r = r.reshape(-1, max_rel).permute(1, 0)
+    else:
+        r = rel_pos
+    qc = torch.arange(q_size)[:, None] * max(k_size / q_size, 1.0)
+    kc = torch.arange(k_size)[None, :] * max(q_size / k_size, 1.0)
+    return r[((qc - kc) + (k_size - 1) * max(q_size / k_size, 1.0)).long()]
+
+
+def sam_attention(sd, q_, x, heads, lora=True):
+    """sam_vit.py:273-298 + add_decomposed_rel_pos :392-430. x: [B', H, W, C] (a window batch or the whole map)."""
+    b, hh, ww, c = x.shape
+    d = c // heads
+    qkv = lora_linear(sd, q_ + "attn.qkv.", x, lora).reshape(b, hh * ww, 3, heads, d).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv.reshape(3, b * heads, hh * ww, d).unbind(0)
+    attn = (q * d ** -0.5) @ k.transpose(-2, -1)
+    rh = sam_rel_pos(hh, hh, sd[q_ + "attn.rel_pos_h"])
+    rw = sam_rel_pos(ww, ww, sd[q_ + "attn.rel_pos_w"])
+    rq = q.reshape(b * heads, hh, ww, d)
+    rel_h = torch.einsum("bhwc,hkc->bhwk", rq, rh)
+    rel_w = torch.einsum("bhwc,wkc->bhwk", rq, rw)
+    attn = (attn.view(b * heads, hh, ww, hh, ww) + rel_h[:, :, :, :, None] + rel_w[:, :, :, None, :]).view(b * heads, hh * ww, hh * ww)
+    o = (attn.softmax(dim=-1) @ v).view(b, heads, hh, ww, d).permute(0, 2, 3, 1, 4).reshape(b, hh, ww, c)
+    return F.linear(o, sd[q_ + "attn.proj.weight"], sd[q_ + "attn.proj.bias"])
+
+
+def sam_block(sd, x, i, heads, window, lora=True, p=BB):
+    """sam_vit.py:201-217 Block.forward with window_partition / unpartition :301-356 (zero padding AFTER norm1; padded
+    tokens take part in the window's attention as keys)."""
+    q_ = f"{p}blocks.{i}."
+    b, hh, ww, c = x.shape
+    h = F.layer_norm(x, (c,), sd[q_ + "norm1.weight"], sd[q_ + "norm1.bias"], 1e-6)
+    if window > 0:
+        ph, pw = (window - hh % window) % window, (window - ww % window) % window
+        h = F.pad(h, (0, 0, 0, pw, 0, ph))
+        hp, wp = hh + ph, ww + pw
+        h = h.view(b, hp // window, window, wp // window, window, c).permute(0, 1, 3, 2, 4, 5).reshape(-1, window, window, c)
+    h = sam_attention(sd, q_, h, heads, lora)
+    if window > 0:
+        h = h.view(b, hp // window, wp // window, window, window, c).permute(0, 1, 3, 2, 4, 5).reshape(b, hp, wp, c)[:, :hh, :ww]
+    x = x + h
+    h = F.layer_norm(x, (c,), sd[q_ + "norm2.weight"], sd[q_ + "norm2.bias"], 1e-6)
+    h = F.linear(F.gelu(F.linear(h, sd[q_ + "mlp.lin1.weight"], sd[q_ + "mlp.lin1.bias"])), sd[q_ + "mlp.lin2.weight"], sd[q_ + "mlp.lin2.bias"])
+    return x + h
+
+
+def sam_forward(sd, x, depth=32, heads=16, window=14, global_idx=(7, 15, 23, 31), out_indices=(7, 15, 23, 31), patch=16, lora=True, p=BB):
+    """SAMViT.forward (sam_vit.py:127-148): NHWC tokens, no cls, fixed abs pos (input must be img_size), no neck."""
+    t = F.conv2d(x, sd[p + "patch_embed.proj.weight"], sd[p + "patch_embed.proj.bias"], stride=patch).permute(0, 2, 3, 1)
+    t = t + sd[p + "pos_embed"]
+    outs = []
+    for i in range(depth):
+        t = sam_block(sd, t, i, heads, 0 if i in global_idx else window, lora, p)
+        if i in out_indices:
+            outs.append(t.permute(0, 3, 1, 2))
+    return outs
+
+
 # =============================================================================== heads
 def batch_norm_train(x, w, b, running_mean, running_var, momentum=0.1, eps=1e-5, stats=None):
     """nn.SyncBatchNorm without a process group == BatchNorm2d (linear_head.py:44). Returns y and new running stats.

@@ -178,3 +178,44 @@ def eva02_state_dict(depth=24, dim=1024):
         if "lora_" not in k:
             sd[k] = bare_sd[k[len(bb):].replace(".base_layer", "")]
     return sd
+
+
+def sam_shapes(depth=32, dim=1280, heads=16, r=32, grid=32, window=14, global_idx=(7, 15, 23, 31)):
+    s = {}
+    bb = "backbone.model.base_model.model."
+    d = dim // heads
+    s[bb + "pos_embed"] = (1, grid, grid, dim)
+    s[bb + "patch_embed.proj.weight"] = (dim, 3, 16, 16)
+    s[bb + "patch_embed.proj.bias"] = (dim,)
+    for i in range(depth):
+        q = f"{bb}blocks.{i}."
+        for n in ("norm1", "norm2"):
+            s[q + n + ".weight"] = (dim,)
+            s[q + n + ".bias"] = (dim,)
+        s[q + "attn.qkv.base_layer.weight"] = (3 * dim, dim)
+        s[q + "attn.qkv.base_layer.bias"] = (3 * dim,)
+        s[q + "attn.qkv.lora_A.default.weight"] = (r, dim)
+        s[q + "attn.qkv.lora_B.default.weight"] = (3 * dim, r)
+        s[q + "attn.proj.weight"] = (dim, dim)
+        s[q + "attn.proj.bias"] = (dim,)
+        L = (4 * grid - 1) if i in global_idx else (2 * window - 1)
+        s[q + "attn.rel_pos_h"] = (L, d)
+        s[q + "attn.rel_pos_w"] = (L, d)
+        s[q + "mlp.lin1.weight"] = (4 * dim, dim)
+        s[q + "mlp.lin1.bias"] = (4 * dim,)
+        s[q + "mlp.lin2.weight"] = (dim, 4 * dim)
+        s[q + "mlp.lin2.bias"] = (dim,)
+    return s
+
+
+def sam_state_dict(depth=32, global_idx=(7, 15, 23, 31), **kw):
+    shapes = sam_shapes(depth, global_idx=global_idx, **kw)
+    bb = "backbone.model.base_model.model."
+    wrapped = {k[len("backbone."):]: v for k, v in shapes.items()}
+    sd = {"backbone." + k: v for k, v in synth_state_dict(wrapped).items()}
+    bare = {k[len(bb):].replace(".base_layer", ""): v for k, v in shapes.items() if "lora_" not in k}
+    bare_sd = synth_state_dict(bare)
+    for k in list(sd):
+        if "lora_" not in k:
+            sd[k] = bare_sd[k[len(bb):].replace(".base_layer", "")]
+    return sd

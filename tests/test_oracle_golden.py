@@ -141,6 +141,19 @@ def test_eva02_taps_and_lora_grads(golden_dir):
             assert rel_err(sl(grads[k]), G[name]) < 2e-3, k
 
 
+@pytest.mark.slow
+def test_sam_taps(golden_dir):
+    from tests.helpers import sam_state_dict
+    G = _g(golden_dir, "sam.npz")
+    sd = sam_state_dict()
+    with torch.no_grad():
+        taps = R.sam_forward(sd, synth_image(1, 512, seed=41))
+    for i, t in enumerate(taps):
+        assert rel_err(sl(t), G[f"tap{i}_slice"]) < TOL
+        assert rel_err(t[0, -4:, -3:, -5:], G[f"tap{i}_tail"]) < TOL
+        np.testing.assert_allclose(stats(t), G[f"tap{i}_stats"], rtol=1e-3, atol=1e-5)
+
+
 def test_optimizer_rules():
     ck = {"norm": dict(decay_mult=0.0), "query_embed": dict(lr_mult=1.0, decay_mult=0.0)}
     assert R.param_group_options("aux_decoder.transformer_decoder.norm.weight", True, custom_keys=ck) == (1e-4, 0.0)

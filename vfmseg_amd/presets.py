@@ -151,3 +151,21 @@ def eva02_ms_masked(depth=24, checkpoint=None, work_dir="work_dirs/tmp"):
     cfg["backbone"] = dict(type="LoRABackbone", backbone=eva02_backbone(depth), checkpoint=checkpoint, Lora_config=eva02_lora_cfg())
     cfg["test_cfg"] = dict(mode="hr_slide_inference", stride=[320, 320], crop_size=[512, 512])  # fixed 512^2 grid
     return cfg
+
+
+def sam_backbone(depth=32, embed_dim=1280, num_heads=16, img_size=512, global_idx=(7, 15, 23, 31), out_indices=(7, 15, 23, 31)):
+    """configs/_base_/models/lora_sam_linear.py:16-27"""
+    return dict(type="SAMViT", img_size=img_size, embed_dim=embed_dim, depth=depth, num_heads=num_heads,
+                global_attn_indexes=list(global_idx), out_indices=list(out_indices), window_size=14, use_rel_pos=True)
+
+
+def sam_linear(depth=32, checkpoint=None):
+    """configs/_base_/models/lora_sam_linear.py (BASELINE config 5): EncoderDecoder, LoRA SAM-H, LinearHead, slide test."""
+    return dict(
+        type="EncoderDecoder",
+        data_preprocessor=dict(_PREPROC, size=(512, 512)),
+        backbone=dict(type="LoRABackbone", backbone=sam_backbone(depth), checkpoint=checkpoint, Lora_config=lora_cfg()),
+        decode_head=dict(linear_head(1280, 320), in_channels=[1280] * 4),
+        train_cfg=dict(),
+        test_cfg=dict(mode="slide", stride=[320, 320], crop_size=[512, 512]),
+    )
