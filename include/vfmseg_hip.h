@@ -157,6 +157,19 @@ typedef struct vfm_attn_desc {
 int vfm_attn_fwd(const vfm_attn_desc* d, void* stream);
 int vfm_attn_bwd(const vfm_attn_desc* d, void* stream);
 
+/* ---- SAM (ViTDet) windowed attention with decomposed relative-position bias (sam_vit.py:273-430) --------------
+ * The bias q.Rh[qh,kh] + q.Rw[qw,kw] is folded into augmented operands so the attention is batched GEMMs + softmax:
+ *   q_aug = [scale*q | q.Rh[qh,:] | q.Rw[qw,:] | 0],  k_aug = [k | onehot(kh) | onehot(kw) | 0]   (width Dq, multiple of 64)
+ * vfm_sam_relpos_table : get_rel_pos - (re-interpolated) table gathered at q-k+(S-1) -> fp32 [S,S,d]
+ * vfm_sam_attn_prep    : window_partition (padded tokens = projection bias) + head split + augmentation
+ * vfm_softmax_rows     : fp32 scores -> probabilities (zero-padded columns)
+ * vfm_sam_attn_merge   : window_unpartition + head merge back to token-major */
+int vfm_sam_relpos_table(const float* rel_pos, int L, int d, int S, float* out, void* stream);
+int vfm_sam_attn_prep(const void* qkv, int dt, long ld, const float* bias, const float* rh, const float* rw, void* q_aug,
+                      void* k_aug, void* v_win, int nimg, int G, int S, int H, int d, int Dq, int NP, float scale, void* stream);
+int vfm_softmax_rows(const float* scores, long ld_s, void* out, int out_dt, long ld_o, long rows, int n, int npad, void* stream);
+int vfm_sam_attn_merge(const void* o_win, int dt, void* out, long ld, int nimg, int G, int S, int H, int d, int NP, void* stream);
+
 /* ---- ViT input / output ------------------------------------------------------------------------ */
 /* im2col of non-overlapping PxP patches (patch_embed.py:65-77): img fp32 NCHW [B,3,H,W] (crop window y0,x0,
  * row/plane strides in elements) -> A [B*(h/P)*(w/P), 3*P*P] in out_dt, k = c*P*P + py*P + px (conv weight order) */

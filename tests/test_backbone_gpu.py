@@ -117,3 +117,29 @@ def test_eva02_taps_and_lora_grads(mode, tol, gtol):
         assert n_live == 2 * DEPTH
     finally:
         set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", 3e-4), ("bf16", 4e-2)])
+def test_sam_taps(mode, tol):
+    """SAM-ViT-H widths, depth 8 (windowed blocks + 2 global blocks, non-zero rel-pos tables, LoRA on qkv) vs the oracle."""
+    from tests.helpers import sam_state_dict
+    import vfmseg_amd.sam  # noqa: F401
+    set_compute_dtype(mode)
+    try:
+        depth, gidx, oidx = 8, (3, 7), (1, 3, 5, 7)
+        sd = sam_state_dict(depth=depth, global_idx=gidx)
+        cfg = dict(type="LoRABackbone", backbone=presets.sam_backbone(depth=depth, global_idx=gidx, out_indices=oidx),
+                   Lora_config=presets.lora_cfg(dropout=0.0))
+        m = MODELS.build(cfg)
+        missing, unexpected = m.load_state_dict({k[len("backbone."):]: v for k, v in sd.items()}, strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        m = m.cuda().eval()
+        img = synth_image(1, 512, seed=43)
+        with torch.no_grad():
+            feats = m(img.cuda())
+            ref = R.sam_forward(sd, img, depth=depth, global_idx=gidx, out_indices=oidx)
+        for i, (f, r) in enumerate(zip(feats, ref)):
+            e = rel_err(f.float().cpu(), r)
+            assert e < tol, (i, e)
+    finally:
+        set_compute_dtype("bf16")

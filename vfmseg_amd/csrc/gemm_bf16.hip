@@ -149,9 +149,11 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   // BT: valid B rows of this batch slice (split-K batches slice the token dimension; the last slice may be short)
   long kb_valid = K;
   if constexpr (BT) {
-    kb_valid = kb_rows - (ldb > 0 ? z * (stride_b / ldb) : 0);
-    if (kb_valid > K) kb_valid = K;
-    if (kb_valid < 1) kb_valid = 1;
+    if (kb_rows > 0) {  // split-K slices of ONE [kb_rows, N] matrix; kb_rows == 0: independent batches, all K rows valid
+      kb_valid = kb_rows - (ldb > 0 ? z * (stride_b / ldb) : 0);
+      if (kb_valid > K) kb_valid = K;
+      if (kb_valid < 1) kb_valid = 1;
+    }
   }
 
   // ---- per-lane DMA sources (row clamp keeps every load in bounds; clamped rows are never stored)
@@ -335,7 +337,7 @@ static void launch_one(const vfm_gemm_desc* d, hipStream_t s) {
   }
   dim3 grid(tiles_m * tiles_n, (unsigned)batch), blk(C::THREADS);
   const long ldb = BT ? d->sb_k : d->sb_n;
-  const long kb_rows = d->kb_rows > 0 ? d->kb_rows : d->K;
+  const long kb_rows = d->kb_rows > 0 ? d->kb_rows : 0;
   hipLaunchKernelGGL((k_gemm_bf16<BM, BN, WM_W, WN_W, NS, VEC, BT>), grid, blk, C::SMEM, s, (const bf16_t*)d->A, d->sa_m,
                      (const bf16_t*)d->B, ldb, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c, tiles_m, tiles_n, kb_rows,
                      make_epi(d));

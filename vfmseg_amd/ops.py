@@ -351,6 +351,34 @@ def attn_bwd(q, k, v, o, lse, dout, dq, dk, dv, B, H, d, nq_main, nq_extra, nk_m
     L.check(lib.vfm_attn_bwd(C.byref(a), L.stream()), "vfm_attn_bwd")
 
 
+def sam_relpos_table(rel_pos, S, out):
+    lib = L.load()
+    L.check(lib.vfm_sam_relpos_table(L.ptr(rel_pos), rel_pos.shape[0], rel_pos.shape[1], S, L.ptr(out), L.stream()),
+            "vfm_sam_relpos_table")
+    return out
+
+
+def sam_attn_prep(qkv, bias, rh, rw, q_aug, k_aug, v_win, nimg, G, S, H, d, scale):
+    lib = L.load()
+    L.check(lib.vfm_sam_attn_prep(L.ptr(qkv), L.dt_of(qkv), _ld(qkv), L.ptr(bias), L.ptr(rh), L.ptr(rw), L.ptr(q_aug),
+                                  L.ptr(k_aug), L.ptr(v_win), nimg, G, S, H, d, q_aug.shape[-1], v_win.shape[1], float(scale),
+                                  L.stream()), "vfm_sam_attn_prep")
+
+
+def softmax_rows(scores2d, out2d, n):
+    lib = L.load()
+    L.check(lib.vfm_softmax_rows(L.ptr(scores2d), _ld(scores2d), L.ptr(out2d), L.dt_of(out2d), _ld(out2d), scores2d.shape[0], n,
+                                 out2d.shape[1], L.stream()), "vfm_softmax_rows")
+    return out2d
+
+
+def sam_attn_merge(o_win, out, nimg, G, S, H, d):
+    lib = L.load()
+    L.check(lib.vfm_sam_attn_merge(L.ptr(o_win), L.dt_of(o_win), L.ptr(out), _ld(out), nimg, G, S, H, d, o_win.shape[1],
+                                   L.stream()), "vfm_sam_attn_merge")
+    return out
+
+
 def patchify(img, out, box=None, patch=16):
     """img fp32 [B,3,H,W] (any strides with unit x-stride); box=(y0,y1,x0,x1) crop; out [B*nh*nw, >=3*P*P]."""
     lib = L.load()
