@@ -409,9 +409,10 @@ def grid_boxes(h_img, w_img, crop=(512, 512), stride=(320, 320)):
     return boxes
 
 
-def whole_inference(sd, img, out_size, **kw):
+def whole_inference(sd, img, out_size, backbone="dinov2", **kw):
     """mmseg whole_inference -> encode_decode -> LinearHead.forward -> predict_by_feat (bilinear to img_shape)."""
-    feats = dinov2_forward(sd, img, **kw)
+    fwd = {"dinov2": dinov2_forward, "eva02": eva02_forward, "sam": sam_forward}[backbone]
+    feats = fwd(sd, img, **kw)
     lg = linear_head_forward(sd, feats, training=False)
     return F.interpolate(lg, size=out_size, mode="bilinear", align_corners=False)
 

@@ -189,3 +189,36 @@ def test_eva02_train_step_matches_oracle():
         assert rel_err(dict(model.named_parameters())[key].grad.cpu(), ref_g) < 5e-3
     finally:
         set_compute_dtype("bf16")
+
+
+def test_sam_slide_inference_matches_oracle():
+    """BASELINE config 5 semantics (lora_sam_linear.py: EncoderDecoder, LoRA SAM + LinearHead, mode='slide', stride 320,
+    crop 512 -> 3x3 windows on a 1024^2 image), SAM-H widths at depth 8, fp32 parity mode: logits and argmax mask."""
+    from tests.helpers import full_state_dict, sam_state_dict
+    from vfmseg_amd.synth import synth_state_dict
+    set_compute_dtype("f32")
+    try:
+        depth, gidx, oidx = 8, (3, 7), (1, 3, 5, 7)
+        cfg = presets.sam_linear(depth=depth)
+        cfg["backbone"]["backbone"].update(global_attn_indexes=list(gidx), out_indices=list(oidx))
+        model = MODELS.build(cfg)
+        sd = sam_state_dict(depth=depth, global_idx=gidx)
+        head = {k: tuple(v.shape) if v.dtype != torch.int64 else ((), torch.int64) for k, v in model.state_dict().items() if k.startswith("decode_head.")}
+        sd.update(synth_state_dict(head))
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        model = model.cuda().eval()
+        img = synth_image(1, 1024, seed=47)
+        with torch.no_grad():
+            out = model.predict(img.cuda())
+            ref = R.slide_inference(sd, img, backbone="sam", depth=depth, global_idx=gidx, out_indices=oidx)
+        logits = out[0].seg_logits.data.unsqueeze(0).cpu()
+        assert rel_err(logits, ref) < 1e-3, rel_err(logits, ref)
+        pred = out[0].pred_sem_seg.data[0].cpu().long()
+        rp = ref.argmax(1)[0]
+        mism = (pred != rp)
+        top2 = ref[0].topk(2, dim=0)[0]
+        margin = (top2[0] - top2[1])
+        assert mism.float().mean().item() < 2e-4 and (mism.sum() == 0 or margin[mism].max().item() < 1e-3)
+    finally:
+        set_compute_dtype("bf16")
