@@ -150,10 +150,12 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local)
+    ndev = torch.cuda.device_count()
+    dev_index = local if local < ndev else local % max(ndev, 1)   # rehearsal: several gloo ranks may share one GPU
+    torch.cuda.set_device(dev_index)
     from vfmseg_amd import lib as _L
-    _L.set_device_index(local)
-    device = torch.device("cuda", local)
+    _L.set_device_index(dev_index)
+    device = torch.device("cuda", dev_index)
     set_compute_dtype(a.dtype)
     np.random.seed(rank)
 

@@ -22,6 +22,11 @@ from .registry import MODELS
 
 R_PAD = 64  # LoRA rank padded to one MFMA K-block
 
+# Data-parallel overlap (vfmseg_amd.parallel): the backbone backward is the last and longest autograd node, so it tells
+# the gradient synchroniser when buckets become final: "heads" when it starts (all decoder gradients are done) and
+# "lora" (with the block index just finished) as it walks the blocks from the last to the first.
+BACKWARD_EVENTS = {"heads_done": None, "block_done": None}
+
 
 # ------------------------------------------------------------------------------------------ parameter containers
 class _Lin(nn.Module):
@@ -483,6 +488,8 @@ class DinoEngine:
                 ops.gemm(da1[:, D:D + R_PAD], Lp["at"], da1[:, :D], alpha=q.scaling, residual=da1[:, :D], **ep)
             ops.layernorm_bwd(da1[:, :D], S["x_in"], Lp["n1w"], S["st1"], dx, accumulate_dx=True)
             ctx["saved"][li] = None
+            if BACKWARD_EVENTS["block_done"] is not None:
+                BACKWARD_EVENTS["block_done"](li)
         return grads
 
 
@@ -539,6 +546,8 @@ class _BackboneFn(torch.autograd.Function):
     def backward(ctx, dxcat, _):
         if dxcat is None:
             return (None, None, None, None) + (None,) * ctx.nparams
+        if BACKWARD_EVENTS["heads_done"] is not None:
+            BACKWARD_EVENTS["heads_done"]()
         grads = ctx.eng.backward(ctx.c, dxcat.contiguous())
         return (None, None, None, None) + tuple(grads)
 

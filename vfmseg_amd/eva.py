@@ -350,4 +350,7 @@ class EvaEngine:
             Lp["qkv"].dgrad(dqkv, dn1)
             ops.layernorm_bwd(dn1, S["x_in"], Lp["n1w"], S["st1"], dx, accumulate_dx=True)
             ctx["saved"][li] = None
+            from .backbones import BACKWARD_EVENTS
+            if BACKWARD_EVENTS["block_done"] is not None:
+                BACKWARD_EVENTS["block_done"](li)
         return grads

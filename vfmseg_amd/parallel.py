@@ -21,6 +21,7 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        backend = os.environ.get("VFMSEG_DIST_BACKEND", backend)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -129,14 +130,36 @@ def bn_sync_fn(group=None):
 
 
 def attach(model, optim_wrapper, group=None):
-    """Wire DP into a built model + OptimWrapper: parameter broadcast, gradient buckets, SyncBN exchange."""
+    """Wire DP into a built model + OptimWrapper: parameter broadcast, gradient buckets, SyncBN exchange, and the
+    backward-time bucket launches (heads' buckets when the backbone backward starts, the first LoRA bucket once the
+    blocks it covers are done; GradSync.finish() sends the rest and joins the side stream)."""
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     if world == 1:
         return None
     broadcast_params(model)
     opt = optim_wrapper.optimizer
-    gs = GradSync(opt.gflat, make_buckets(opt.names, opt.offsets), group)
+    buckets = make_buckets(opt.names, opt.offsets)
+    gs = GradSync(opt.gflat, buckets, group)
     optim_wrapper.grad_sync = gs
+    from . import backbones
+    head_ids = [i for i, b in enumerate(buckets) if not b[0].startswith("lora")]
+    lora_ids = [i for i, b in enumerate(buckets) if b[0].startswith("lora")]
+    # block index whose completion finalises LoRA bucket k: the smallest block number among the parameters it holds
+    last_block = {}
+    for i in lora_ids:
+        _, a, b = buckets[i]
+        blks = [int(nm.split("blocks.")[1].split(".")[0]) for nm, o in zip(opt.names, opt.offsets[:-1]) if a <= o < b and "lora_" in nm]
+        last_block[min(blks)] = i
+
+    def heads_done():
+        for i in head_ids:
+            gs.ready(i)
+
+    def block_done(li):
+        if li in last_block:
+            gs.ready(last_block[li])
+
+    backbones.BACKWARD_EVENTS["heads_done"], backbones.BACKWARD_EVENTS["block_done"] = heads_done, block_done
     head = getattr(model, "decode_head", None)
     if head is not None and hasattr(head, "bn_sync"):
         head.bn_sync, head.bn_world = bn_sync_fn(group), world
