@@ -169,10 +169,14 @@ class EncoderDecoder(nn.Module):
         B, _, H, W = inputs.shape
         preds = torch.zeros(B, self.out_channels, H, W, dtype=torch.float32, device=inputs.device)
         count = torch.zeros(B, 1, H, W, dtype=torch.float32, device=inputs.device)
-        for (y1, y2, x1, x2) in grid_boxes(H, W, self.test_cfg.crop_size, self.test_cfg.stride):
-            xcat, hp, wp = self._tokens([(inputs, (y1, y2, x1, x2))])
-            lg = self.decode_head.forward_tokens(FeatPack(xcat, B, hp, wp))  # NHWC low-res
-            ops.slide_accumulate(lg, False, B, lg.shape[1], lg.shape[2], lg.shape[3], preds, count, (y1, x1, y2 - y1, x2 - x1))
+        # the windows are independent: ONE batched backbone + head pass over all of them (rows = window-major), then the
+        # per-window resize-and-accumulate.  Same arithmetic as mmseg's sequential loop, far better GEMM shapes.
+        boxes = grid_boxes(H, W, self.test_cfg.crop_size, self.test_cfg.stride)
+        xcat, hp, wp = self._tokens([(inputs, b) for b in boxes])
+        lg = self.decode_head.forward_tokens(FeatPack(xcat, B * len(boxes), hp, wp))  # NHWC low-res, [nwin*B, h, w, C]
+        for j, (y1, y2, x1, x2) in enumerate(boxes):
+            ops.slide_accumulate(lg[j * B:(j + 1) * B], False, B, lg.shape[1], lg.shape[2], lg.shape[3], preds, count,
+                                 (y1, x1, y2 - y1, x2 - x1))
         ops.slide_finalize(preds, count)
         return preds
 
@@ -311,25 +315,35 @@ class MsVFMEncoderDecoder(EncoderDecoder):
             dec.mask_enable = False
         preds = torch.zeros(B, C, H, W, dtype=torch.float32, device=dev)
         count = torch.zeros(B, 1, H, W, dtype=torch.float32, device=dev)
-        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        boxes = grid_boxes(H, W, self.test_cfg.crop_size, self.test_cfg.stride)
+        cnt = torch.zeros(len(boxes), dtype=torch.int32, device=dev)
         self.last_refined = []
         try:
-            for (y1, y2, x1, x2) in grid_boxes(H, W, self.test_cfg.crop_size, self.test_cfg.stride):
-                hc, wc = y2 - y1, x2 - x1
-                self.hr_crop_box = (y1, y2, x1, x2)
-                cnt.zero_()
-                ops.conf_gate_count(seg, (y1, x1, hc, wc), thr, cnt)
-                frac = cnt.item() / float(B * hc * wc)              # data-dependent control flow: host sync
-                ctx = torch.empty(B, C, hc, wc, dtype=torch.float32, device=dev)
+            # all gates depend only on the coarse logits: evaluate them together (ONE device->host sync instead of one
+            # per window), then refine the selected windows in one batched backbone + VFMHead pass
+            for j, (y1, y2, x1, x2) in enumerate(boxes):
+                ops.conf_gate_count(seg, (y1, x1, y2 - y1, x2 - x1), thr, cnt[j:j + 1])
+            fracs = [c / float(B * (b[1] - b[0]) * (b[3] - b[2])) for c, b in zip(cnt.tolist(), boxes)]
+            refine = [j for j, f in enumerate(fracs) if f < conf]
+            hc, wc = boxes[0][1] - boxes[0][0], boxes[0][3] - boxes[0][2]
+            assert all((b[1] - b[0], b[3] - b[2]) == (hc, wc) for b in boxes)
+            ctx = torch.empty(len(boxes) * B, C, hc, wc, dtype=torch.float32, device=dev)
+            for j, (y1, y2, x1, x2) in enumerate(boxes):
                 win = seg[:, :, y1:y2, x1:x2]
-                ops.strided_copy(win, ctx, (B, C, hc, wc), (win.stride(0), win.stride(1), win.stride(2), 1),
-                                 (C * hc * wc, hc * wc, wc, 1))
-                if frac < conf:
-                    lg = self.enc_dec(inputs, ctx, box=(y1, y2, x1, x2))   # [B, hp, wp, C]
-                    ops.slide_accumulate(lg, False, B, lg.shape[1], lg.shape[2], C, preds, count, (y1, x1, hc, wc))
+                dst = ctx[j * B:(j + 1) * B]
+                ops.strided_copy(win, dst, (B, C, hc, wc), (win.stride(0), win.stride(1), win.stride(2), 1), (C * hc * wc, hc * wc, wc, 1))
+            if refine:
+                xcat, hp, wp = self._tokens([(inputs, boxes[j]) for j in refine])
+                rctx = ctx if len(refine) == len(boxes) else torch.cat([ctx[j * B:(j + 1) * B] for j in refine], 0)
+                lg = self.aux_decoder.forward_tokens(FeatPack(xcat, B * len(refine), hp, wp), rctx)   # [nref*B, hp, wp, C]
+            for j, (y1, y2, x1, x2) in enumerate(boxes):
+                if j in refine:
+                    k = refine.index(j)
+                    ops.slide_accumulate(lg[k * B:(k + 1) * B], False, B, lg.shape[1], lg.shape[2], C, preds, count, (y1, x1, hc, wc))
                     self.last_refined.append((y1, y2, x1, x2))
                 else:
-                    ops.slide_accumulate(ctx, True, B, hc, wc, C, preds, count, (y1, x1, hc, wc))
+                    ops.slide_accumulate(ctx[j * B:(j + 1) * B], True, B, hc, wc, C, preds, count, (y1, x1, hc, wc))
+                self.hr_crop_box = (y1, y2, x1, x2)
         finally:
             if had_mask is not None:
                 dec.mask_enable = had_mask
