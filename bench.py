@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--tune", action="append", default=[], help="kernel tuning knob KEY=INT (vfm_tune), repeatable")
     a = ap.parse_args()
 
     from vfmseg_amd import parallel
@@ -158,6 +159,10 @@ def main():
     device = torch.device("cuda", dev_index)
     set_compute_dtype(a.dtype)
     np.random.seed(rank)
+    for kv in a.tune:
+        from vfmseg_amd import ops as _ops
+        k, v = kv.split("=")
+        _ops.tune(k, int(v))
 
     model, ow = build(device, a.batch)
     parallel.attach(model, ow)

@@ -7,95 +7,7 @@
 //     to the per-lane SOURCE address (the DMA destination is lane-linear) and again on the ds_read_b128 fragment reads
 //   epilogue through LDS: accumulators -> row-major fp32 tile -> 16-byte vector loads/stores of bias / residual / aux / C
 //   XCD-aware bijective tile mapping (blocks b, b+8 share an XCD's L2)
-#include "gemm_epilogue.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-#define BK 64
-
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-  else static_assert(N < 0, "add the vmcnt immediate");
-}
-
-// vector epilogue on 4 consecutive columns (all pointers/leading dims 16-byte compatible; checked on the host)
-__device__ __forceinline__ void epi_store4(const EpiParams& e, long zoff, long m, long n, float4 v) {
-  float x[4] = {v.x * e.alpha, v.y * e.alpha, v.z * e.alpha, v.w * e.alpha};
-  if (e.bias) {
-    const long bn = n % e.bias_mod;  // bias_mod % 4 == 0 on this path
-    const float4 b = *reinterpret_cast<const float4*>(e.bias + bn);
-    x[0] += b.x, x[1] += b.y, x[2] += b.z, x[3] += b.w;
-  }
-  if (e.C2) {
-    const long o = zoff + m * e.ldc2 + n;
-    if (e.c2_dt == VFM_BF16) {
-      ushort4 p = {f32_to_bf16(x[0]), f32_to_bf16(x[1]), f32_to_bf16(x[2]), f32_to_bf16(x[3])};
-      *reinterpret_cast<ushort4*>((bf16_t*)e.C2 + o) = p;
-    } else {
-      *reinterpret_cast<float4*>((float*)e.C2 + o) = make_float4(x[0], x[1], x[2], x[3]);
-    }
-  }
-  if (e.ep_mode == VFM_EP_GELU) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] = gelu_f(x[i]);
-  } else if (e.ep_mode == VFM_EP_RELU) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] = fmaxf(x[i], 0.f);
-  } else if (e.ep_mode == VFM_EP_MUL_GELU_GRAD || e.ep_mode == VFM_EP_MUL) {
-    float a[4];
-    const long o = m * e.ld_aux + n;
-    if (e.aux_dt == VFM_BF16) {
-      const ushort4 p = *reinterpret_cast<const ushort4*>((const bf16_t*)e.aux + o);
-      a[0] = bf16_to_f32(p.x), a[1] = bf16_to_f32(p.y), a[2] = bf16_to_f32(p.z), a[3] = bf16_to_f32(p.w);
-    } else {
-      const float4 p = *reinterpret_cast<const float4*>((const float*)e.aux + o);
-      a[0] = p.x, a[1] = p.y, a[2] = p.z, a[3] = p.w;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] *= (e.ep_mode == VFM_EP_MUL ? a[i] : gelu_grad_f(a[i]));
-  }
-  if (e.colscale) {
-    const float4 s = *reinterpret_cast<const float4*>(e.colscale + n);
-    x[0] *= s.x, x[1] *= s.y, x[2] *= s.z, x[3] *= s.w;
-  }
-  if (e.residual) {
-    const long o = zoff + m * e.ldr + n;
-    if (e.r_dt == VFM_BF16) {
-      const ushort4 p = *reinterpret_cast<const ushort4*>((const bf16_t*)e.residual + o);
-      x[0] += bf16_to_f32(p.x), x[1] += bf16_to_f32(p.y), x[2] += bf16_to_f32(p.z), x[3] += bf16_to_f32(p.w);
-    } else {
-      const float4 p = *reinterpret_cast<const float4*>((const float*)e.residual + o);
-      x[0] += p.x, x[1] += p.y, x[2] += p.z, x[3] += p.w;
-    }
-  }
-  const long o = zoff + m * e.ldc + n;
-  if (e.c_dt == VFM_BF16) {
-    ushort4 p = {f32_to_bf16(x[0]), f32_to_bf16(x[1]), f32_to_bf16(x[2]), f32_to_bf16(x[3])};
-    *reinterpret_cast<ushort4*>((bf16_t*)e.C + o) = p;
-  } else {
-    *reinterpret_cast<float4*>((float*)e.C + o) = make_float4(x[0], x[1], x[2], x[3]);
-  }
-}
+#include "gemm_dev.h"
 
 template <int BM, int BN, int WM_W, int WN_W, int NS>
 struct Cfg {
@@ -286,43 +198,10 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
 
   // ---- epilogue
   const long zoff = z * stride_c;
-  if constexpr (VEC) {
-    __syncthreads();  // all LDS reads of the last stage are done; the ring is reused as the epilogue image
-    float* img = reinterpret_cast<float*>(smem) + wave * 32 * C::EPI_LD;
-    constexpr int LANES_PER_ROW = C::WN / 4;          // float4 per lane
-    constexpr int ROWS_PER_PASS = 64 / LANES_PER_ROW;
-    const int rr = lane / LANES_PER_ROW, cc = (lane % LANES_PER_ROW) * 4;
-#pragma unroll
-    for (int i = 0; i < C::MI; ++i) {
-#pragma unroll
-      for (int j = 0; j < C::NI; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) img[((r & 3) + 8 * (r >> 2) + 4 * fh) * C::EPI_LD + j * 32 + fr] = acc[i][j][r];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int pass = 0; pass < 32 / ROWS_PER_PASS; ++pass) {
-        const int row = pass * ROWS_PER_PASS + rr;
-        const long m = m0 + wm * C::WM + i * 32 + row;
-        const long n = n0 + wn * C::WN + cc;
-        const float4 v = *reinterpret_cast<const float4*>(img + row * C::EPI_LD + cc);
-        if (m < M && n < N) epi_store4(e, zoff, m, n, v);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < C::MI; ++i)
-#pragma unroll
-      for (int j = 0; j < C::NI; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long m = m0 + wm * C::WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          const long n = n0 + wn * C::WN + j * 32 + fr;
-          if (m < M && n < N) epi_store(e, zoff, m, n, acc[i][j][r]);
-        }
-  }
+  __syncthreads();  // all LDS reads of the last stage are done; the ring is reused as the epilogue image
+  float* img = reinterpret_cast<float*>(smem) + wave * 32 * C::EPI_LD;
+  if constexpr (VEC) epi_wave_tile<C::MI, C::NI, 1>(e, zoff, acc, img, lane, m0 + wm * C::WM, n0 + wn * C::WN, M, N);
+  else epi_scalar<C::MI, C::NI, 1>(e, zoff, acc, img, lane, m0 + wm * C::WM, n0 + wn * C::WN, M, N);
 }
 
 template <int BM, int BN, int WM_W, int WN_W, int NS, bool VEC, bool BT>
@@ -447,9 +326,19 @@ static void launch_skinny(const vfm_gemm_desc* d, hipStream_t s) {
 
 static int g_force_cfg = -1;
 static int g_split_tail = 1;
+static int g_use_pp = 1;  // 256x256 tiles: the ping-pong kernel (gemm_pp.hip) instead of config 16
 extern "C" int vfm_tune(const char* key, int value) {
   if (key && strcmp(key, "gemm_cfg") == 0) {
     g_force_cfg = value;
+    return VFM_OK;
+  }
+  if (key && strcmp(key, "pp_dbg") == 0) {
+    extern int g_pp_dbg;
+    g_pp_dbg = value;
+    return VFM_OK;
+  }
+  if (key && strcmp(key, "gemm_use_pp") == 0) {
+    g_use_pp = value;
     return VFM_OK;
   }
   if (key && strcmp(key, "gemm_split_tail") == 0) {
@@ -477,6 +366,7 @@ static bool vec_ok(const vfm_gemm_desc* d) {
 //  10: 64x64 2x2 NS4    11: 256x64 4x2 NS3    12: 128x128 4x2 NS2  13: 128x128 4x2 NS3  14: 256x128 4x2 NS2
 //  15: 256x256 4x2 NS2  16: 256x256 4x4 NS2   17: 128x128 2x4 NS2  18: 64x128 2x2 NS2   19: 128x64 2x2 NS2
 static int gemm_main(const vfm_gemm_desc* d, hipStream_t s);
+void vfm_gemm_launch_pp256(const vfm_gemm_desc* d, hipStream_t s, bool vec);  // gemm_pp.hip
 
 int vfm_gemm_bf16_impl(const vfm_gemm_desc* d0, hipStream_t s) {
   // A few rows past a 128-row boundary (M = B*1024 patch tokens + B [cls] tokens) would cost a whole extra row of
@@ -523,7 +413,8 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s) {
     const long t256 = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
     if (d->N <= 32) cfg = 10;                                        // 64x64 tiles: many rows, few columns
     else if (t128 <= 160) cfg = 18;                                  // small problems: 64x128 tiles fill more CUs
-    else if (d->N >= 2048 && (t256 % 256 == 0 || t256 >= 768)) cfg = 16;  // 256x256, 16 waves: exact / many rounds
+    else if (d->N >= 2048 && (t256 % 256 == 0 || t256 >= 768))
+      cfg = (g_use_pp && d->K >= 128 && (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31)) ? 30 : 16;  // 256x256 tiles
     else cfg = 17;                                                   // 128x128, 8 waves, 2 blocks per CU
   }
   switch (cfg) {
@@ -552,6 +443,10 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s) {
     case 22: launch_cfg<256, 128, 4, 4, 2>(d, s, vec); break;
     case 23: launch_cfg<128, 128, 4, 4, 3>(d, s, vec); break;
     case 24: launch_cfg<128, 128, 4, 4, 2>(d, s, vec); break;
+    case 30:
+      VFM_CHECK(d->K >= 128, VFM_E_UNSUPPORTED, "vfm_gemm(bf16): the ping-pong kernel needs K >= 128");
+      vfm_gemm_launch_pp256(d, s, vec);
+      break;
     default: VFM_FAIL(VFM_E_INVAL, "vfm_gemm(bf16): unknown config %d", cfg);
   }
   return VFM_OK;

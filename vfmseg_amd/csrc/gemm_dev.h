@@ -1,0 +1,308 @@
+// Device helpers shared by the bf16 MFMA GEMM kernels (gemm_bf16.hip, gemm_pp.hip).
+#pragma once
+#include "gemm_epilogue.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define BK 64
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else static_assert(N < 0, "add the vmcnt immediate");
+}
+
+// vector epilogue on 4 consecutive columns (all pointers/leading dims 16-byte compatible; checked on the host)
+__device__ __forceinline__ void epi_store4(const EpiParams& e, long zoff, long m, long n, float4 v) {
+  float x[4] = {v.x * e.alpha, v.y * e.alpha, v.z * e.alpha, v.w * e.alpha};
+  if (e.bias) {
+    const long bn = n % e.bias_mod;  // bias_mod % 4 == 0 on this path
+    const float4 b = *reinterpret_cast<const float4*>(e.bias + bn);
+    x[0] += b.x, x[1] += b.y, x[2] += b.z, x[3] += b.w;
+  }
+  if (e.C2) {
+    const long o = zoff + m * e.ldc2 + n;
+    if (e.c2_dt == VFM_BF16) {
+      ushort4 p = {f32_to_bf16(x[0]), f32_to_bf16(x[1]), f32_to_bf16(x[2]), f32_to_bf16(x[3])};
+      *reinterpret_cast<ushort4*>((bf16_t*)e.C2 + o) = p;
+    } else {
+      *reinterpret_cast<float4*>((float*)e.C2 + o) = make_float4(x[0], x[1], x[2], x[3]);
+    }
+  }
+  if (e.ep_mode == VFM_EP_GELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = gelu_f(x[i]);
+  } else if (e.ep_mode == VFM_EP_RELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = fmaxf(x[i], 0.f);
+  } else if (e.ep_mode == VFM_EP_MUL_GELU_GRAD || e.ep_mode == VFM_EP_MUL) {
+    float a[4];
+    const long o = m * e.ld_aux + n;
+    if (e.aux_dt == VFM_BF16) {
+      const ushort4 p = *reinterpret_cast<const ushort4*>((const bf16_t*)e.aux + o);
+      a[0] = bf16_to_f32(p.x), a[1] = bf16_to_f32(p.y), a[2] = bf16_to_f32(p.z), a[3] = bf16_to_f32(p.w);
+    } else {
+      const float4 p = *reinterpret_cast<const float4*>((const float*)e.aux + o);
+      a[0] = p.x, a[1] = p.y, a[2] = p.z, a[3] = p.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] *= (e.ep_mode == VFM_EP_MUL ? a[i] : gelu_grad_f(a[i]));
+  }
+  if (e.colscale) {
+    const float4 s = *reinterpret_cast<const float4*>(e.colscale + n);
+    x[0] *= s.x, x[1] *= s.y, x[2] *= s.z, x[3] *= s.w;
+  }
+  if (e.residual) {
+    const long o = zoff + m * e.ldr + n;
+    if (e.r_dt == VFM_BF16) {
+      const ushort4 p = *reinterpret_cast<const ushort4*>((const bf16_t*)e.residual + o);
+      x[0] += bf16_to_f32(p.x), x[1] += bf16_to_f32(p.y), x[2] += bf16_to_f32(p.z), x[3] += bf16_to_f32(p.w);
+    } else {
+      const float4 p = *reinterpret_cast<const float4*>((const float*)e.residual + o);
+      x[0] += p.x, x[1] += p.y, x[2] += p.z, x[3] += p.w;
+    }
+  }
+  const long o = zoff + m * e.ldc + n;
+  if (e.c_dt == VFM_BF16) {
+    ushort4 p = {f32_to_bf16(x[0]), f32_to_bf16(x[1]), f32_to_bf16(x[2]), f32_to_bf16(x[3])};
+    *reinterpret_cast<ushort4*>((bf16_t*)e.C + o) = p;
+  } else {
+    *reinterpret_cast<float4*>((float*)e.C + o) = make_float4(x[0], x[1], x[2], x[3]);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Wave-tile epilogues.  A wave owns an (MI*32) x (NI*32) fp32 accumulator tile in MFMA layout; it is moved through a
+// per-wave LDS image (GROUP 32-row slabs at a time, row stride NI*32+4 floats) so that global traffic is 16-byte rows.
+//
+// epi_fast: one straight-line instance per (mode, C dtype, residual, C2) combination the backbones use.  gfx9 counts loads
+// and stores on ONE in-order counter (vmcnt), so a load issued after a store cannot be waited for without waiting for that
+// store's acknowledgement: every residual / aux load of the whole wave tile is therefore issued BEFORE the first store.
+// The code is kept small on purpose (fast erf, nothing data-type generic inside the unrolled passes): the generic
+// epi_store4 unrolled 32x was ~170 KB of cold, branchy code and cost more than the K=1024 main loop.
+template <int V>
+struct IC {
+  static constexpr int value = V;
+};
+
+__device__ __forceinline__ float erf_fast(float x) {  // Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  const float y = 1.0f - p * t * __expf(-ax * ax);
+  return copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return fmaf(x, pdf, cdf);
+}
+
+// RES: 0 none, 1 fp32 residual.  MODE: VFM_EP_*; modes 3/4 read a bf16 aux.  CDT: dtype of C.  HASC2: bf16 copy of the
+// pre-activation value.
+template <int MODE, int CDT, int RES, bool HASC2, int MI, int NI, int GROUP>
+__device__ __forceinline__ void epi_fast(const EpiParams& e, long zoff, f32x16 (&acc)[MI][NI], float* img, int lane, long m_base,
+                                         long n_base, long M, long N) {
+  constexpr int WN = NI * 32, LD = WN + 4, LPR = WN / 4, RPP = 64 / LPR, PPS = 32 / RPP, NP = MI * PPS, NG = MI / GROUP;
+  static_assert(MI % GROUP == 0 && NG <= 4, "slab grouping");
+  constexpr bool AUX = (MODE == VFM_EP_MUL_GELU_GRAD || MODE == VFM_EP_MUL);
+  const int fr = lane & 31, fh = lane >> 5;
+  const int rr = lane / LPR, cc = (lane % LPR) * 4;
+  const long n = n_base + cc;
+  const bool n_ok = n < N;  // N % 4 == 0 on the vector path
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (e.bias && n_ok) b4 = *reinterpret_cast<const float4*>(e.bias + n % e.bias_mod);
+  if (e.colscale && n_ok) s4 = *reinterpret_cast<const float4*>(e.colscale + n);
+  const float alpha = e.alpha;
+
+  auto dump = [&](auto Gc) {
+    constexpr int gi = decltype(Gc)::value;
+#pragma unroll
+    for (int s = 0; s < GROUP; ++s)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          img[(s * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LD + j * 32 + fr] = acc[gi * GROUP + s][j][r];
+  };
+  dump(IC<0>{});
+
+  // ---- every load of the wave tile, before any store
+  float4 res[RES == 1 ? NP : 1];
+  ushort4 aux[AUX ? NP : 1];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const long m = m_base + (p / PPS) * 32 + (p % PPS) * RPP + rr;
+    const bool ok = n_ok && m < M;
+    if constexpr (RES == 1) {
+      res[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) res[p] = *reinterpret_cast<const float4*>((const float*)e.residual + zoff + m * e.ldr + n);
+    }
+    if constexpr (AUX) {
+      aux[p] = make_ushort4(0, 0, 0, 0);
+      if (ok) aux[p] = *reinterpret_cast<const ushort4*>((const bf16_t*)e.aux + m * e.ld_aux + n);
+    }
+  }
+
+  auto group = [&](auto Gc) {
+    constexpr int gi = decltype(Gc)::value;
+    if constexpr (gi > 0) dump(Gc);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < GROUP * PPS; ++q) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int p = gi * GROUP * PPS + q;
+      const int irow = (q / PPS) * 32 + (q % PPS) * RPP + rr;
+      const long m = m_base + (p / PPS) * 32 + (p % PPS) * RPP + rr;
+      const float4 v = *reinterpret_cast<const float4*>(img + irow * LD + cc);
+      float x[4] = {fmaf(v.x, alpha, b4.x), fmaf(v.y, alpha, b4.y), fmaf(v.z, alpha, b4.z), fmaf(v.w, alpha, b4.w)};
+      const bool ok = n_ok && m < M;
+      if constexpr (HASC2) {
+        const ushort4 c2 = {f32_to_bf16(x[0]), f32_to_bf16(x[1]), f32_to_bf16(x[2]), f32_to_bf16(x[3])};
+        if (ok) *reinterpret_cast<ushort4*>((bf16_t*)e.C2 + zoff + m * e.ldc2 + n) = c2;
+      }
+      if constexpr (MODE == VFM_EP_GELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = gelu_fast(x[i]);
+      } else if constexpr (MODE == VFM_EP_RELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = fmaxf(x[i], 0.f);
+      } else if constexpr (MODE == VFM_EP_MUL_GELU_GRAD) {
+        x[0] *= gelu_grad_fast(bf16_to_f32(aux[p].x)), x[1] *= gelu_grad_fast(bf16_to_f32(aux[p].y));
+        x[2] *= gelu_grad_fast(bf16_to_f32(aux[p].z)), x[3] *= gelu_grad_fast(bf16_to_f32(aux[p].w));
+      } else if constexpr (MODE == VFM_EP_MUL) {
+        x[0] *= bf16_to_f32(aux[p].x), x[1] *= bf16_to_f32(aux[p].y), x[2] *= bf16_to_f32(aux[p].z), x[3] *= bf16_to_f32(aux[p].w);
+      }
+      x[0] *= s4.x, x[1] *= s4.y, x[2] *= s4.z, x[3] *= s4.w;
+      if constexpr (RES == 1) x[0] += res[p].x, x[1] += res[p].y, x[2] += res[p].z, x[3] += res[p].w;
+      if (ok) {
+        const long o = zoff + m * e.ldc + n;
+        if constexpr (CDT == VFM_BF16) {
+          const ushort4 pk = {f32_to_bf16(x[0]), f32_to_bf16(x[1]), f32_to_bf16(x[2]), f32_to_bf16(x[3])};
+          *reinterpret_cast<ushort4*>((bf16_t*)e.C + o) = pk;
+        } else {
+          *reinterpret_cast<float4*>((float*)e.C + o) = make_float4(x[0], x[1], x[2], x[3]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+  group(IC<0>{});
+  if constexpr (NG > 1) group(IC<1>{});
+  if constexpr (NG > 2) group(IC<2>{});
+  if constexpr (NG > 3) group(IC<3>{});
+}
+
+// any other combination: compact (rolled) pass loop around the generic epi_store4
+template <int MI, int NI, int GROUP>
+__device__ __forceinline__ void epi_generic(const EpiParams& e, long zoff, f32x16 (&acc)[MI][NI], float* img, int lane, long m_base,
+                                            long n_base, long M, long N) {
+  constexpr int WN = NI * 32, LD = WN + 4, LPR = WN / 4, RPP = 64 / LPR, PPS = 32 / RPP, NG = MI / GROUP;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int rr = lane / LPR, cc = (lane % LPR) * 4;
+  const long n = n_base + cc;
+  auto group = [&](auto Gc) {
+    constexpr int gi = decltype(Gc)::value;
+#pragma unroll
+    for (int s = 0; s < GROUP; ++s)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          img[(s * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LD + j * 32 + fr] = acc[gi * GROUP + s][j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int q = 0; q < GROUP * PPS; ++q) {
+      const int irow = (q / PPS) * 32 + (q % PPS) * RPP + rr;
+      const long m = m_base + gi * GROUP * 32 + irow;
+      const float4 v = *reinterpret_cast<const float4*>(img + irow * LD + cc);
+      if (m < M && n < N) epi_store4(e, zoff, m, n, v);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+  group(IC<0>{});
+  if constexpr (NG > 1) group(IC<1>{});
+  if constexpr (NG > 2) group(IC<2>{});
+  if constexpr (NG > 3) group(IC<3>{});
+}
+
+// wave-uniform selection of the epilogue instance
+template <int MI, int NI, int GROUP>
+__device__ __forceinline__ void epi_wave_tile(const EpiParams& e, long zoff, f32x16 (&acc)[MI][NI], float* img, int lane, long m_base,
+                                              long n_base, long M, long N) {
+  const int mode = e.ep_mode;
+  const bool plain = !e.C2 && !e.residual;
+  if (mode == VFM_EP_NONE && plain && e.c_dt == VFM_BF16)
+    epi_fast<VFM_EP_NONE, VFM_BF16, 0, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+  else if (mode == VFM_EP_NONE && plain && e.c_dt == VFM_F32)
+    epi_fast<VFM_EP_NONE, VFM_F32, 0, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+  else if (mode == VFM_EP_NONE && !e.C2 && e.residual && e.r_dt == VFM_F32 && e.c_dt == VFM_F32)
+    epi_fast<VFM_EP_NONE, VFM_F32, 1, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+  else if (mode == VFM_EP_GELU && e.C2 && e.c2_dt == VFM_BF16 && !e.residual && e.c_dt == VFM_BF16)
+    epi_fast<VFM_EP_GELU, VFM_BF16, 0, true, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+  else if (mode == VFM_EP_MUL_GELU_GRAD && e.aux_dt == VFM_BF16 && plain && e.c_dt == VFM_BF16)
+    epi_fast<VFM_EP_MUL_GELU_GRAD, VFM_BF16, 0, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+  else
+    epi_generic<MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+}
+
+// unaligned outputs (N % 4 != 0, odd leading dims ...): same LDS image, one element per lane and step, rolled loop
+template <int MI, int NI, int GROUP>
+__device__ __forceinline__ void epi_scalar(const EpiParams& e, long zoff, f32x16 (&acc)[MI][NI], float* img, int lane, long m_base,
+                                           long n_base, long M, long N) {
+  constexpr int WN = NI * 32, LD = WN + 4, NG = MI / GROUP;
+  const int fr = lane & 31, fh = lane >> 5;
+  auto group = [&](auto Gc) {
+    constexpr int gi = decltype(Gc)::value;
+#pragma unroll
+    for (int s = 0; s < GROUP; ++s)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          img[(s * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LD + j * 32 + fr] = acc[gi * GROUP + s][j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int idx = lane; idx < GROUP * 32 * WN; idx += 64) {
+      const int irow = idx / WN, col = idx % WN;
+      const long m = m_base + gi * GROUP * 32 + irow, n = n_base + col;
+      if (m < M && n < N) epi_store(e, zoff, m, n, img[irow * LD + col]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+  group(IC<0>{});
+  if constexpr (NG > 1) group(IC<1>{});
+  if constexpr (NG > 2) group(IC<2>{});
+  if constexpr (NG > 3) group(IC<3>{});
+}
