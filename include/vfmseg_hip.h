@@ -80,6 +80,17 @@ int vfm_mask_token_bwd(const float* dout, const uint8_t* keep, float* dx, float*
  * output y2 = y * mask2 (LoRA input dropout, peft lora.Linear) ; stats = (mean, rstd) fp32 [rows,2] */
 int vfm_layernorm_fwd(const float* x, long ld_x, const float* w, const float* b, float eps, void* y, int y_dt, long ld_y,
                       float* stats, long rows, long C, void* stream);
+/* LayerNorm forward fused with the LoRA-branch dropout (peft lora.Linear: lora_dropout(x)): besides y (bf16) it
+ * writes mask[row, c] = 0 or 1/(1-p) (bf16; the values vfm_dropout_mask gives for element offset + row*C + c) and
+ * y_drop = y * mask.  C % 256 == 0, 16-byte aligned rows. */
+int vfm_layernorm_dropout_fwd(const float* x, long ld_x, const float* w, const float* b, float eps, void* y, long ld_y,
+                              float* stats, void* y_drop, long ld_yd, void* mask, long ld_mask, float p, uint64_t seed,
+                              uint64_t offset, long rows, long C, void* stream);
+/* LN backward that also emits t_out = bf16(dx_new * t_scale[c]) - the LayerScale-weighted operand of the next dgrad GEMM
+ * (block.py:99-114: x + ls(f(norm(x)))).  Vectorised path only (C % 256 == 0), no dw/db. */
+int vfm_layernorm_bwd_scaled(const void* dy, int dy_dt, long ld_dy, const float* x, long ld_x, const float* w,
+                             const float* stats, float* dx, long ld_dx, int accumulate_dx, void* t_out, long ld_t,
+                             const float* t_scale, long rows, long C, void* stream);
 /* dx (+)= LN backward; dw/db accumulate into fp32 [C] when non-null (two-stage, ws >= 2*128*C floats) */
 int vfm_layernorm_bwd(const void* dy, int dy_dt, long ld_dy, const float* x, long ld_x, const float* w,
                       const float* stats, float* dx, long ld_dx, int accumulate_dx, float* dw, float* db, float* ws,

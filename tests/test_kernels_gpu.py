@@ -114,6 +114,38 @@ def test_layernorm(C):
     assert relerr(dw, wr.grad) < 2e-5 and relerr(db, br.grad) < 2e-5
 
 
+@pytest.mark.parametrize("C", [1024, 1280])
+def test_layernorm_fused_variants(C):
+    """LN forward + LoRA dropout and LN backward + scaled bf16 copy: bit-identical to the separate kernels they replace."""
+    rows = 133
+    x = (rnd(rows, C, seed=70, scale=2.0) + 0.5).to(DEV)
+    w, b = (rnd(C, seed=71) * 0.1 + 1).to(DEV), (rnd(C, seed=72) * 0.1).to(DEV)
+    y0 = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+    st0 = torch.empty(rows, 2, device=DEV)
+    ops.layernorm_fwd(x, w, b, 1e-6, y0, st0)
+    m0 = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+    ops.dropout_mask(m0, 0.1, 1234, offset=5 * rows * C)
+    d0 = torch.empty_like(y0)
+    ops.mul_mask(y0, m0, d0)
+    big = torch.zeros(rows, C + 64, dtype=torch.bfloat16, device=DEV)   # y lands in a strided view, as in the engine
+    st1 = torch.empty(rows, 2, device=DEV)
+    m1, d1 = torch.empty_like(m0), torch.empty_like(d0)
+    ops.layernorm_dropout_fwd(x, w, b, 1e-6, big[:, :C], st1, d1, m1, 0.1, 1234, offset=5 * rows * C)
+    assert torch.equal(big[:, :C], y0) and torch.allclose(st1, st0, rtol=1e-6, atol=1e-7) and torch.equal(m1, m0)
+    assert torch.equal(d1.view(torch.int16), d0.view(torch.int16))
+    assert 0.05 < (m1 == 0).float().mean().item() < 0.15
+    dy = rnd(rows, C, seed=73).to(DEV).bfloat16()
+    g = (rnd(C, seed=74) * 0.3 + 1).to(DEV)
+    dx0 = torch.ones(rows, C, device=DEV)
+    ops.layernorm_bwd(dy, x, w, st0, dx0, accumulate_dx=True)
+    t0 = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+    ops.cast(dx0, t0, g)
+    dx1 = torch.ones(rows, C, device=DEV)
+    t1 = torch.empty_like(t0)
+    ops.layernorm_bwd_scaled(dy, x, w, st0, dx1, t1, g, accumulate_dx=True)
+    assert torch.allclose(dx1, dx0, rtol=1e-6, atol=1e-7) and relerr(t1.float(), t0.float()) < 1e-2
+
+
 @pytest.mark.parametrize("C,G,act", [(1024, 32, 2), (256, 32, 1), (64, 32, 1), (128, 32, 0)])
 def test_groupnorm(C, G, act):
     B, P = 2, 32 * 32
@@ -355,7 +387,7 @@ def test_resize_and_labels():
     assert torch.equal(u.cpu(), e)
 
 
-@pytest.mark.parametrize("h,H", [(32, 128), (8, 128), (16, 16)])
+@pytest.mark.parametrize("h,H", [(32, 128), (8, 128), (16, 16), (12, 48), (128, 512)])
 def test_upsample_ce(h, H):
     B, C = 2, 19
     lg = rnd(B, h, h, C, seed=54, scale=2.0)

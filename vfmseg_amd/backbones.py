@@ -387,15 +387,22 @@ class DinoEngine:
             kq = Lp["qkv"].k
             a1 = torch.empty(M, kq, dtype=cd, device=dev)  # [LN(x) | T]: the T GEMM writes all R_PAD columns (A is zero-padded)
             st1 = torch.empty(M, 2, dtype=torch.float32, device=dev)
-            ops.layernorm_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1)
+            q = blk.attn.qkv if lora else None
+            fused_drop = lora and training and q.p > 0 and cd == torch.bfloat16 and D % 256 == 0
+            if fused_drop:  # LN + dropout multiplier + dropped copy in one pass
+                mask = torch.empty(M, D, dtype=cd, device=dev)
+                xd = torch.empty(M, D, dtype=cd, device=dev)
+                ops.layernorm_dropout_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1, xd, mask, q.p, seed, offset=li * M * D)
+            else:
+                ops.layernorm_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1)
             if lora:
-                q = blk.attn.qkv
-                xd, mask = a1[:, :D], None
-                if training and q.p > 0:
-                    mask = torch.empty(M, D, dtype=cd, device=dev)
-                    ops.dropout_mask(mask, q.p, seed, offset=li * M * D)
-                    xd = torch.empty(M, D, dtype=cd, device=dev)
-                    ops.mul_mask(a1[:, :D], mask, xd)
+                if not fused_drop:
+                    xd, mask = a1[:, :D], None
+                    if training and q.p > 0:
+                        mask = torch.empty(M, D, dtype=cd, device=dev)
+                        ops.dropout_mask(mask, q.p, seed, offset=li * M * D)
+                        xd = torch.empty(M, D, dtype=cd, device=dev)
+                        ops.mul_mask(a1[:, :D], mask, xd)
                 ops.gemm(xd, Lp["a"], a1[:, D:D + R_PAD], alpha=q.scaling)  # T = s * drop(xn) A^T
                 S.update(xd=xd if mask is not None else None, mask=mask)
             qkv = torch.empty(M, 3 * D, dtype=cd, device=dev)
@@ -433,25 +440,33 @@ class DinoEngine:
         M, Mp, nimg, Np = ctx["M"], ctx["Mp"], ctx["nimg"], ctx["Np"]
         dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
         grads = [None] * (2 * len(v.blocks))
-        for li in range(len(v.blocks) - 1, -1, -1):
-            blk, Lp, S = v.blocks[li], P["layers"][li], ctx["saved"][li]
-            q = blk.attn.qkv
+        fuse_t = cd == torch.bfloat16 and D % 256 == 0  # LN backward emits the next dgrad operand bf16(dx * gamma) itself
+        def add_tap(li):
             if li in v.out_indices:
                 i = v.out_indices.index(li)
                 src = dxcat[:, i * D:(i + 1) * D]
                 ops.strided_copy(src, dx, (Mp, D), (src.stride(0), 1), (D, 1), accumulate=True)
+        t = None
+        for li in range(len(v.blocks) - 1, -1, -1):
+            blk, Lp, S = v.blocks[li], P["layers"][li], ctx["saved"][li]
+            q = blk.attn.qkv
             # ---- MLP branch: x_out = x_mid + g2 * fc2(gelu(fc1(LN2(x_mid))))
-            t = torch.empty(M, D, dtype=cd, device=dev)
-            ops.cast(dx, t, Lp["g2"])
+            if t is None:  # (the previous iteration's LN1 backward already produced t = bf16(dx * g2) otherwise)
+                add_tap(li)
+                t = torch.empty(M, D, dtype=cd, device=dev)
+                ops.cast(dx, t, Lp["g2"])
             hid = Lp["fc1"].n
             dh = torch.empty(M, hid, dtype=cd, device=dev)
             Lp["fc2"].dgrad(t, dh, ep_mode=ops.EP_MUL_GELU_GRAD, aux=S["hpre"])
             dn = torch.empty(M, D, dtype=cd, device=dev)
             Lp["fc1"].dgrad(dh, dn)
-            ops.layernorm_bwd(dn, S["x_mid"], Lp["n2w"], S["st2"], dx, accumulate_dx=True)
+            if fuse_t:
+                ops.layernorm_bwd_scaled(dn, S["x_mid"], Lp["n2w"], S["st2"], dx, t, Lp["g1"], accumulate_dx=True)
+            else:
+                ops.layernorm_bwd(dn, S["x_mid"], Lp["n2w"], S["st2"], dx, accumulate_dx=True)
+                ops.cast(dx, t, Lp["g1"])
             del dh
             # ---- attention branch: x_mid = x_in + g1 * proj(attn(qkv(LN1(x_in))))
-            ops.cast(dx, t, Lp["g1"])
             dao = torch.empty(M, D, dtype=cd, device=dev)
             Lp["proj"].dgrad(t, dao)
             dqkv = torch.empty(M, 3 * D, dtype=cd, device=dev)
@@ -486,7 +501,13 @@ class DinoEngine:
                 # d LN1(x) = da1[:, :D] + mask * (s * dT @ A)
                 ep = dict(ep_mode=ops.EP_MUL, aux=S["mask"]) if S["mask"] is not None else {}
                 ops.gemm(da1[:, D:D + R_PAD], Lp["at"], da1[:, :D], alpha=q.scaling, residual=da1[:, :D], **ep)
-            ops.layernorm_bwd(da1[:, :D], S["x_in"], Lp["n1w"], S["st1"], dx, accumulate_dx=True)
+            if fuse_t and li > 0:  # dx becomes d(x_out) of block li-1: its tap gradient goes in first, then LN1 backward
+                add_tap(li - 1)     # accumulates and emits t = bf16(dx * g2[li-1]) for that block's fc2 dgrad
+                ops.layernorm_bwd_scaled(da1[:, :D], S["x_in"], Lp["n1w"], S["st1"], dx, t, P["layers"][li - 1]["g2"],
+                                         accumulate_dx=True)
+            else:
+                ops.layernorm_bwd(da1[:, :D], S["x_in"], Lp["n1w"], S["st1"], dx, accumulate_dx=True)
+                t = None
             ctx["saved"][li] = None
             if BACKWARD_EVENTS["block_done"] is not None:
                 BACKWARD_EVENTS["block_done"](li)

@@ -47,9 +47,14 @@ __global__ void k_ln_fwd(const float* __restrict__ x, long ld_x, const float* __
 
 
 // ---- vectorised LayerNorm (C % 256 == 0): each lane owns float4 chunks -> 16-byte loads/stores (Guideline 13)
-template <typename TO, int NV>
+// DROP: also writes the dropout multiplier (0 or 1/(1-p), element index offset + row*C + c of the counter-based RNG, the
+// values vfm_dropout_mask produces) and y_drop = y * multiplier - the LoRA branch input - in the same pass.
+struct LnDrop {
+  void* yd; long ld_yd; void* mask; long ld_mask; float p, keep_scale; uint64_t seed, offset;
+};
+template <typename TO, int NV, bool DROP = false>
 __global__ void k_ln_fwd_v4(const float* __restrict__ x, long ld_x, const float* __restrict__ w, const float* __restrict__ b,
-                            float eps, TO* __restrict__ y, long ld_y, float* __restrict__ stats, long rows, int C) {
+                            float eps, TO* __restrict__ y, long ld_y, float* __restrict__ stats, long rows, int C, LnDrop dr = LnDrop()) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -86,6 +91,23 @@ __global__ void k_ln_fwd_v4(const float* __restrict__ x, long ld_x, const float*
     if constexpr (sizeof(TO) == 2) {
       ushort4 p = {f32_to_bf16(o.x), f32_to_bf16(o.y), f32_to_bf16(o.z), f32_to_bf16(o.w)};
       *reinterpret_cast<ushort4*>(y + row * ld_y + c0) = p;
+      if constexpr (DROP) {
+        const uint64_t e0 = dr.offset + (uint64_t)row * C + c0;
+        const bf16_t ks = f32_to_bf16(dr.keep_scale);
+        const float ksf = bf16_to_f32(ks);
+        ushort4 mk, yd;
+        const bool k0 = (hash_u32(dr.seed, e0) >> 8) * (1.0f / 16777216.0f) >= dr.p;
+        const bool k1 = (hash_u32(dr.seed, e0 + 1) >> 8) * (1.0f / 16777216.0f) >= dr.p;
+        const bool k2 = (hash_u32(dr.seed, e0 + 2) >> 8) * (1.0f / 16777216.0f) >= dr.p;
+        const bool k3 = (hash_u32(dr.seed, e0 + 3) >> 8) * (1.0f / 16777216.0f) >= dr.p;
+        mk.x = k0 ? ks : 0, mk.y = k1 ? ks : 0, mk.z = k2 ? ks : 0, mk.w = k3 ? ks : 0;
+        yd.x = k0 ? f32_to_bf16(bf16_to_f32(p.x) * ksf) : f32_to_bf16(bf16_to_f32(p.x) * 0.f);
+        yd.y = k1 ? f32_to_bf16(bf16_to_f32(p.y) * ksf) : f32_to_bf16(bf16_to_f32(p.y) * 0.f);
+        yd.z = k2 ? f32_to_bf16(bf16_to_f32(p.z) * ksf) : f32_to_bf16(bf16_to_f32(p.z) * 0.f);
+        yd.w = k3 ? f32_to_bf16(bf16_to_f32(p.w) * ksf) : f32_to_bf16(bf16_to_f32(p.w) * 0.f);
+        *reinterpret_cast<ushort4*>((bf16_t*)dr.mask + row * dr.ld_mask + c0) = mk;
+        *reinterpret_cast<ushort4*>((bf16_t*)dr.yd + row * dr.ld_yd + c0) = yd;
+      }
     } else {
       *reinterpret_cast<float4*>(y + row * ld_y + c0) = o;
     }
@@ -95,7 +117,8 @@ __global__ void k_ln_fwd_v4(const float* __restrict__ x, long ld_x, const float*
 template <typename TD, int NV>
 __global__ void k_ln_bwd_v4(const TD* __restrict__ dy, long ld_dy, const float* __restrict__ x, long ld_x,
                             const float* __restrict__ w, const float* __restrict__ stats, float* __restrict__ dx, long ld_dx,
-                            int accumulate_dx, long rows, int C) {
+                            int accumulate_dx, long rows, int C, bf16_t* __restrict__ t_out = nullptr, long ld_t = 0,
+                            const float* __restrict__ t_scale = nullptr) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -132,6 +155,11 @@ __global__ void k_ln_bwd_v4(const TD* __restrict__ dy, long ld_dy, const float* 
       o.x += old.x, o.y += old.y, o.z += old.z, o.w += old.w;
     }
     *p = o;
+    if (t_out) {  // bf16(dx * t_scale): the operand of the next (preceding-branch) dgrad GEMM, saves a cast pass
+      const float4 ts = *reinterpret_cast<const float4*>(t_scale + c0);
+      const ushort4 tv = {f32_to_bf16(o.x * ts.x), f32_to_bf16(o.y * ts.y), f32_to_bf16(o.z * ts.z), f32_to_bf16(o.w * ts.w)};
+      *reinterpret_cast<ushort4*>(t_out + row * ld_t + c0) = tv;
+    }
   }
 }
 
@@ -161,6 +189,26 @@ extern "C" int vfm_layernorm_fwd(const float* x, long ld_x, const float* w, cons
   else if (y_dt == VFM_F32) { if (pl <= 4) L(float, 4); else if (pl <= 16) L(float, 16); else if (pl <= 32) L(float, 32); else L(float, 48); }
   else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_fwd: dtype");
 #undef L
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+extern "C" int vfm_layernorm_dropout_fwd(const float* x, long ld_x, const float* w, const float* b, float eps, void* y, long ld_y,
+                                         float* stats, void* y_drop, long ld_yd, void* mask, long ld_mask, float p, uint64_t seed,
+                                         uint64_t offset, long rows, long C, void* stream) {
+  VFM_CHECK(p >= 0.f && p < 1.f, VFM_E_INVAL, "vfm_layernorm_dropout_fwd: p");
+  const long nv = C / 256;
+  VFM_CHECK(C % 256 == 0 && (nv == 1 || nv == 2 || nv == 4 || nv == 5 || nv == 8), VFM_E_SHAPE, "vfm_layernorm_dropout_fwd: C=%ld", C);
+  VFM_CHECK(ld_x % 4 == 0 && ld_y % 4 == 0 && ld_yd % 4 == 0 && ld_mask % 4 == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 8 == 0 &&
+                (uintptr_t)y_drop % 8 == 0 && (uintptr_t)mask % 8 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)b % 16 == 0,
+            VFM_E_ALIGN, "vfm_layernorm_dropout_fwd: alignment");
+  if (rows == 0) return VFM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 blk(256), grid(cdiv(rows, 4));
+  LnDrop dr{y_drop, ld_yd, mask, ld_mask, p, 1.0f / (1.0f - p), seed, offset};
+#define LVD(NV) hipLaunchKernelGGL((k_ln_fwd_v4<bf16_t, NV, true>), grid, blk, 0, s, x, ld_x, w, b, eps, (bf16_t*)y, ld_y, stats, rows, (int)C, dr)
+  if (nv == 1) LVD(1); else if (nv == 2) LVD(2); else if (nv == 4) LVD(4); else if (nv == 5) LVD(5); else LVD(8);
+#undef LVD
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }
@@ -238,9 +286,25 @@ __global__ void k_ln_bwd_fin(const float* __restrict__ ws, int parts, int C, flo
   if (db) db[c] += b;
 }
 
+static int ln_bwd_impl(const void* dy, int dy_dt, long ld_dy, const float* x, long ld_x, const float* w, const float* stats,
+                       float* dx, long ld_dx, int accumulate_dx, float* dw, float* db, float* ws, long rows, long C, void* t_out,
+                       long ld_t, const float* t_scale, void* stream);
 extern "C" int vfm_layernorm_bwd(const void* dy, int dy_dt, long ld_dy, const float* x, long ld_x, const float* w,
                                  const float* stats, float* dx, long ld_dx, int accumulate_dx, float* dw, float* db,
                                  float* ws, long rows, long C, void* stream) {
+  return ln_bwd_impl(dy, dy_dt, ld_dy, x, ld_x, w, stats, dx, ld_dx, accumulate_dx, dw, db, ws, rows, C, nullptr, 0, nullptr, stream);
+}
+extern "C" int vfm_layernorm_bwd_scaled(const void* dy, int dy_dt, long ld_dy, const float* x, long ld_x, const float* w,
+                                        const float* stats, float* dx, long ld_dx, int accumulate_dx, void* t_out, long ld_t,
+                                        const float* t_scale, long rows, long C, void* stream) {
+  VFM_CHECK(t_out && t_scale && ld_t % 4 == 0 && (uintptr_t)t_out % 8 == 0 && (uintptr_t)t_scale % 16 == 0, VFM_E_INVAL,
+            "vfm_layernorm_bwd_scaled: t_out / t_scale");
+  return ln_bwd_impl(dy, dy_dt, ld_dy, x, ld_x, w, stats, dx, ld_dx, accumulate_dx, nullptr, nullptr, nullptr, rows, C, t_out, ld_t,
+                     t_scale, stream);
+}
+static int ln_bwd_impl(const void* dy, int dy_dt, long ld_dy, const float* x, long ld_x, const float* w, const float* stats,
+                       float* dx, long ld_dx, int accumulate_dx, float* dw, float* db, float* ws, long rows, long C, void* t_out,
+                       long ld_t, const float* t_scale, void* stream) {
   VFM_CHECK(C > 0 && (C <= 1024 || (C <= 3072 && !(dw || db))), VFM_E_SHAPE, "vfm_layernorm_bwd: C=%ld unsupported", C);
   VFM_CHECK(!(dw || db) || ws, VFM_E_INVAL, "vfm_layernorm_bwd: ws required for dw/db");
   if (rows == 0) return VFM_OK;
@@ -252,7 +316,7 @@ extern "C" int vfm_layernorm_bwd(const void* dy, int dy_dt, long ld_dy, const fl
                   ((uintptr_t)w % 16 == 0);
   if (v4) {
     dim3 grid(cdiv(rows, 4)), blk(256);
-#define LV(TD, NV) hipLaunchKernelGGL((k_ln_bwd_v4<TD, NV>), grid, blk, 0, s, (const TD*)dy, ld_dy, x, ld_x, w, stats, dx, ld_dx, accumulate_dx, rows, (int)C)
+#define LV(TD, NV) hipLaunchKernelGGL((k_ln_bwd_v4<TD, NV>), grid, blk, 0, s, (const TD*)dy, ld_dy, x, ld_x, w, stats, dx, ld_dx, accumulate_dx, rows, (int)C, (bf16_t*)t_out, ld_t, t_scale)
     if (dy_dt == VFM_BF16) { if (nv == 1) LV(bf16_t, 1); else if (nv == 2) LV(bf16_t, 2); else if (nv == 4) LV(bf16_t, 4); else LV(bf16_t, 5); }
     else if (dy_dt == VFM_F32) { if (nv == 1) LV(float, 1); else if (nv == 2) LV(float, 2); else if (nv == 4) LV(float, 4); else LV(float, 5); }
     else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_bwd: dtype");
@@ -260,6 +324,7 @@ extern "C" int vfm_layernorm_bwd(const void* dy, int dy_dt, long ld_dy, const fl
     VFM_LAUNCH_CHECK();
     return VFM_OK;
   }
+  VFM_CHECK(!t_out, VFM_E_UNSUPPORTED, "vfm_layernorm_bwd_scaled: needs the vectorised path (C %% 256 == 0, aligned operands, no dw/db)");
   const int parts = need_w ? 128 : cdiv(rows, 4);
   const size_t shm = need_w ? (size_t)4 * 2 * C * sizeof(float) : 0;
   float* wsp = need_w ? ws : nullptr;

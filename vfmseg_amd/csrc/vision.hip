@@ -392,6 +392,119 @@ __global__ void __launch_bounds__(256) k_upsample_ce(const float* __restrict__ l
     }
   }
 }
+// Tiled form for integer scale factors S (H = S*h, W = S*w; the x4 LinearHead loss): a block owns T x T low-res pixels.
+//   1. the (T+2)^2 low-res logit vectors it touches go to LDS,
+//   2. every high-res pixel of the (T+1)S x (T+1)S region whose footprint touches an owned pixel gets its interpolated
+//      logits / softmax ONCE per block (all operands from LDS): probabilities, label, loss term are kept in LDS,
+//   3. each (owned pixel, class) pair gathers its gradient from its 2S x 2S members in a fixed order (no float atomics,
+//      bitwise reproducible); class 0's thread also accounts the loss / accuracy of the high-res pixels the pixel owns.
+// The one-wave-per-low-res-pixel kernel above spends its time in uncoalesced 4-byte loads (76 per candidate) and visits
+// every high-res pixel four times; here the redundancy is ((T+1)/T)^2 and global memory sees each operand once.
+template <int S, int T>
+__global__ void __launch_bounds__(256) k_upsample_ce_tile(const float* __restrict__ lg, const int64_t* __restrict__ label, int B, int h,
+                                                           int w, int C, int H, int W, int ignore, float inv_total,
+                                                           float* __restrict__ loss_parts, int32_t* __restrict__ counts,
+                                                           float* __restrict__ dlogits) {
+  constexpr int R = (T + 1) * S, LT = T + 2, PS = CE_CMAX + 1;  // odd LDS stride: conflict-free per-pixel vectors
+  extern __shared__ float ce_smem[];
+  float* Ls = ce_smem;                    // [LT*LT][C]
+  float* Ps = Ls + LT * LT * PS;     // [R*R][C]   probabilities
+  float* Lv = Ps + R * R * PS;       // [R*R]      loss term (lse - v[label]) of valid pixels
+  int* Lb = (int*)(Lv + R * R);           // [R*R]      label, -1 = outside the image / ignored; bit 8 set = arg-max hit
+  const int tid = threadIdx.x;
+  const int tiles_x = w / T, tiles_y = h / T;
+  const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y;
+  const long b = blockIdx.x / (tiles_x * tiles_y);
+  const int y0 = by * T, x0 = bx * T;
+  const float sc = 1.0f / S;
+  const float* lb = lg + b * (long)h * w * C;
+  for (int i = tid; i < LT * LT * C; i += 256) {
+    const int c = i % C, p = i / C;
+    const int yy = min(max(y0 - 1 + p / LT, 0), h - 1), xx = min(max(x0 - 1 + p % LT, 0), w - 1);
+    Ls[p * PS + c] = lb[((long)yy * w + xx) * C + c];
+  }
+  __syncthreads();
+  const int hy_base = S * y0 - S / 2, hx_base = S * x0 - S / 2;
+  for (int i = tid; i < R * R; i += 256) {
+    const int ry = i / R, rx = i % R;
+    const int hy = hy_base + ry, hx = hx_base + rx;
+    int lab = -1;
+    float lossv = 0.f;
+    if (hy >= 0 && hy < H && hx >= 0 && hx < W) {
+      const int64_t l64 = label[(b * H + hy) * (long)W + hx];
+      if (l64 != ignore) {
+        lab = (int)l64;
+        const Lerp ly = lerp_idx(hy, sc, h), lx = lerp_idx(hx, sc, w);
+        const float* p00 = Ls + ((ly.i0 - y0 + 1) * LT + (lx.i0 - x0 + 1)) * PS;
+        const float* p01 = Ls + ((ly.i0 - y0 + 1) * LT + (lx.i1 - x0 + 1)) * PS;
+        const float* p10 = Ls + ((ly.i1 - y0 + 1) * LT + (lx.i0 - x0 + 1)) * PS;
+        const float* p11 = Ls + ((ly.i1 - y0 + 1) * LT + (lx.i1 - x0 + 1)) * PS;
+        float v[CE_CMAX];
+        float m = -INFINITY, vl = 0.f;
+        int am = 0;
+#pragma unroll
+        for (int c = 0; c < CE_CMAX; ++c) {
+          if (c < C) {
+            v[c] = ly.l0 * (lx.l0 * p00[c] + lx.l1 * p01[c]) + ly.l1 * (lx.l0 * p10[c] + lx.l1 * p11[c]);
+            if (v[c] > m) m = v[c], am = c;
+            if (c == lab) vl = v[c];
+          }
+        }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < CE_CMAX; ++c)
+          if (c < C) v[c] = __expf(v[c] - m), se += v[c];
+        const float inv_se = 1.f / se;
+#pragma unroll
+        for (int c = 0; c < CE_CMAX; ++c)
+          if (c < C) Ps[i * PS + c] = v[c] * inv_se;
+        lossv = m + __logf(se) - vl;
+        if (am == lab) lab |= 256;
+      }
+    }
+    Lb[i] = lab;
+    Lv[i] = lossv;
+  }
+  __syncthreads();
+  for (int task = tid; task < T * T * C; task += 256) {
+    const int c = task % C, lp = task / C;
+    const int ty = lp / T, tx = lp % T;
+    const int y = y0 + ty, x = x0 + tx;
+    float g = 0.f, loss = 0.f;
+    int hits = 0, valid = 0;
+    for (int dy = 0; dy < 2 * S; ++dy) {
+      const int ry = ty * S + dy, hy = hy_base + ry;
+      if (hy < 0 || hy >= H) continue;
+      const Lerp ly = lerp_idx(hy, sc, h);
+      const float wy = (ly.i0 == y ? ly.l0 : 0.f) + (ly.i1 == y ? ly.l1 : 0.f);
+      for (int dx = 0; dx < 2 * S; ++dx) {
+        const int rx = tx * S + dx, hx = hx_base + rx;
+        if (hx < 0 || hx >= W) continue;
+        const int i = ry * R + rx;
+        const int lab = Lb[i];
+        if (lab < 0) continue;
+        const Lerp lx = lerp_idx(hx, sc, w);
+        const float wx = (lx.i0 == x ? lx.l0 : 0.f) + (lx.i1 == x ? lx.l1 : 0.f);
+        g += wy * wx * inv_total * (Ps[i * PS + c] - ((lab & 255) == c ? 1.f : 0.f));
+        if (c == 0 && ly.i0 == y && lx.i0 == x) {
+          loss += Lv[i];
+          valid += 1;
+          hits += (lab >> 8) & 1;
+        }
+      }
+    }
+    const long pix = (b * h + y) * (long)w + x;
+    if (dlogits) dlogits[pix * C + c] = g;
+    if (c == 0) {
+      loss_parts[pix] = loss;
+      if (valid) {
+        atomicAdd(&counts[0], hits);
+        atomicAdd(&counts[1], valid);
+      }
+    }
+  }
+}
+
 extern "C" int vfm_upsample_ce(const float* logits_low, const int64_t* label, int B, int h, int w, int C, int H, int W,
                                int ignore_index, float* loss_parts, int32_t* counts, float* dlogits, void* stream) {
   VFM_CHECK(C > 0 && C <= CE_CMAX, VFM_E_SHAPE, "vfm_upsample_ce: C=%d > %d", C, CE_CMAX);
@@ -399,7 +512,12 @@ extern "C" int vfm_upsample_ce(const float* logits_low, const int64_t* label, in
   const long npix = (long)B * h * w;
   if (npix == 0) return VFM_OK;
   const bool big = ((long)H * W) >= 64L * h * w;  // footprint (2*scale)^2 >= 256 candidates per low-res pixel
-  if (big)
+  if (H == 4 * h && W == 4 * w && h % 4 == 0 && w % 4 == 0) {
+    constexpr int S = 4, T = 4, R = (T + 1) * S, LT = T + 2;
+    const size_t smem = (size_t)(LT * LT * (CE_CMAX + 1) + R * R * (CE_CMAX + 1) + 2 * R * R) * 4;
+    hipLaunchKernelGGL((k_upsample_ce_tile<S, T>), dim3((unsigned)(B * (h / T) * (w / T))), dim3(256), smem, (hipStream_t)stream,
+                       logits_low, label, B, h, w, C, H, W, ignore_index, 1.0f / ((float)B * H * W), loss_parts, counts, dlogits);
+  } else if (big)
     hipLaunchKernelGGL(k_upsample_ce<4>, dim3((unsigned)npix), dim3(256), 0, (hipStream_t)stream, logits_low, label, B, h, w, C, H, W,
                        ignore_index, (float)h / (float)H, (float)w / (float)W, 1.0f / ((float)B * H * W), loss_parts, counts,
                        dlogits);

@@ -65,6 +65,8 @@ SIGNATURES = {
     "vfm_mask_token_fwd": [vp, vp, vp, vp, cl, cl, vp],
     "vfm_mask_token_bwd": [vp, vp, vp, vp, cl, cl, vp],
     "vfm_layernorm_fwd": [vp, cl, vp, vp, cf, vp, ci, cl, vp, cl, cl, vp],
+    "vfm_layernorm_dropout_fwd": [vp, cl, vp, vp, cf, vp, cl, vp, vp, cl, vp, cl, cf, u64, u64, cl, cl, vp],
+    "vfm_layernorm_bwd_scaled": [vp, ci, cl, vp, cl, vp, vp, vp, cl, ci, vp, cl, vp, cl, cl, vp],
     "vfm_layernorm_bwd": [vp, ci, cl, vp, cl, vp, vp, vp, cl, ci, vp, vp, vp, cl, cl, vp],
     "vfm_groupnorm_fwd": [vp, vp, vp, cf, ci, ci, vp, ci, vp, vp, cl, cl, cl, vp],
     "vfm_groupnorm_bwd": [vp, ci, vp, vp, vp, vp, ci, ci, vp, vp, vp, vp, cl, cl, cl, vp],

@@ -171,6 +171,28 @@ def layernorm_fwd(x, w, b, eps, y, stats=None):
     return y
 
 
+def layernorm_dropout_fwd(x, w, b, eps, y, stats, y_drop, mask, p, seed, offset=0):
+    """LN forward that also writes the dropout multiplier `mask` and y_drop = y * mask (bf16 outputs, C % 256 == 0)."""
+    lib = L.load()
+    rows, c = x.shape
+    assert y.dtype == torch.bfloat16 and y_drop.dtype == torch.bfloat16 and mask.dtype == torch.bfloat16
+    L.check(lib.vfm_layernorm_dropout_fwd(L.ptr(x), _ld(x), L.ptr(w), L.ptr(b), float(eps), L.ptr(y), _ld(y), L.ptr(stats),
+                                          L.ptr(y_drop), _ld(y_drop), L.ptr(mask), _ld(mask), float(p), int(seed), int(offset),
+                                          rows, c, L.stream()), "vfm_layernorm_dropout_fwd")
+    return y
+
+
+def layernorm_bwd_scaled(dy, x, w, stats, dx, t_out, t_scale, accumulate_dx=False):
+    """LN backward into dx (fp32) that also emits t_out = bf16(dx_new * t_scale[c])."""
+    lib = L.load()
+    rows, c = x.shape
+    assert t_out.dtype == torch.bfloat16 and t_scale.dtype == torch.float32
+    L.check(lib.vfm_layernorm_bwd_scaled(L.ptr(dy), L.dt_of(dy), _ld(dy), L.ptr(x), _ld(x), L.ptr(w), L.ptr(stats), L.ptr(dx),
+                                         _ld(dx), int(accumulate_dx), L.ptr(t_out), _ld(t_out), L.ptr(t_scale), rows, c,
+                                         L.stream()), "vfm_layernorm_bwd_scaled")
+    return dx
+
+
 def layernorm_bwd(dy, x, w, stats, dx, accumulate_dx=False, dw=None, db=None):
     lib = L.load()
     rows, c = x.shape
