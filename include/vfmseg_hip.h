@@ -49,6 +49,11 @@ int vfm_axpby(const float* x, float a, float* y, float b, long n, void* stream);
 int vfm_scale_by_device_scalar(float* y, const float* scalar, long n, void* stream);
 /* out[c] (+)= sum_r x[r,c]  (bias gradients); deterministic two-stage reduction, ws >= 64*cols floats */
 int vfm_colsum(const void* x, int dt, long ld, long rows, long cols, float* out, int accumulate, float* ws, void* stream);
+/* Split-K combine fused with the scatter into the parameter-gradient layout:
+ * dst[p*sp + q*sq] (+)= alpha * sum_k slabs[k][p][q], p < rows_used (slabs fp32 [kch, P, Q]).  LoRA dA/dB (peft lora.Linear
+ * backward) from the transposed-B weight-gradient GEMM of vfm_gemm. */
+int vfm_slab_reduce(const float* slabs, int kch, long P, long Q, long rows_used, float alpha, float* dst, long sp, long sq,
+                    int accumulate, void* stream);
 /* Bernoulli keep-mask multipliers: out[i] = (u_i >= p) ? 1/(1-p) : 0, counter-based hash RNG (seed, offset) */
 int vfm_dropout_mask(void* out, int dt, long n, float p, uint64_t seed, uint64_t offset, void* stream);
 /* dst[r,c] = src[r,c] * mask[(r / rows_per_group) * mask_ld + c]   (Dropout2d: one multiplier per (image, channel));
@@ -73,7 +78,8 @@ int vfm_act_grad_mul(const void* dy, int dy_dt, long ld_dy, const void* pre, int
                      long ld_out, long rows, long cols, int act, void* stream);
 /* query masking (Transformer.py:263-268): out[r,:] = keep[r] ? x[r,:] : token[:] ; bwd splits the gradient */
 int vfm_mask_token_fwd(const float* x, const uint8_t* keep, const float* token, float* out, long rows, long C, void* stream);
-int vfm_mask_token_bwd(const float* dout, const uint8_t* keep, float* dx, float* dtoken, long rows, long C, void* stream);
+int vfm_mask_token_bwd(const float* dout, const uint8_t* keep, float* dx, float* dtoken, float* ws /* >= 64*C floats */,
+                       long rows, long C, void* stream);
 
 /* ---- normalisation --------------------------------------------------------------------------- */
 /* LayerNorm over the last dim (block.py:63,75; Transformer.py:167-169). x fp32 [rows, C]; y in out_dt; optional second

@@ -482,19 +482,25 @@ class DinoEngine:
                 a1 = S["a1"]
                 xd = S["xd"] if S["xd"] is not None else a1[:, :D]
                 # dB^T[r, out] = T^T @ dqkv ;  dA[r, in] = s * dT^T @ drop(xn)   (reductions over the M tokens)
-                gBt = torch.empty(R_PAD, Bm.shape[0], dtype=torch.float32, device=dev)
-                gAp = torch.empty(R_PAD, A.shape[1], dtype=torch.float32, device=dev)
-                _wgrad_small_t(a1[:, D:D + R_PAD], dqkv, gBt)
-                _wgrad_small_t(da1[:, D:D + R_PAD], xd, gAp, alpha=q.scaling)
                 from .functional import direct_grad_target
                 tB, tA = direct_grad_target(Bm), direct_grad_target(A)
-                if tB is not None:
+                gBt = torch.empty(R_PAD, Bm.shape[0], dtype=torch.float32, device=dev)
+                gAp = torch.empty(R_PAD, A.shape[1], dtype=torch.float32, device=dev)
+                # with a flat gradient buffer the split-K combine scatters straight into B.grad [out, r] / A.grad [r, in]
+                doneB = _wgrad_small_t(a1[:, D:D + R_PAD], dqkv, gBt, scatter=None if tB is None else (tB, r, 1, r))
+                doneA = _wgrad_small_t(da1[:, D:D + R_PAD], xd, gAp, alpha=q.scaling,
+                                       scatter=None if tA is None else (tA, r, A.shape[1], 1))
+                if doneB is True:
+                    pass
+                elif tB is not None:
                     ops.strided_copy(gBt, tB, (Bm.shape[0], r), (1, gBt.stride(0)), (r, 1), accumulate=True)
                 else:
                     gB = torch.empty_like(Bm, dtype=torch.float32)
                     ops.strided_copy(gBt, gB, (Bm.shape[0], r), (1, gBt.stride(0)), (r, 1))
                     grads[2 * li + 1] = gB
-                if tA is not None:
+                if doneA is True:
+                    pass
+                elif tA is not None:
                     ops.axpby(gAp[:r].reshape(-1), 1.0, tA.view(-1), 1.0)
                 else:
                     grads[2 * li] = gAp[:r]
@@ -519,10 +525,12 @@ def _pack_at(A, at, r):
     ops.strided_copy(A, at, (A.shape[1], r), (1, A.stride(0)), (at.stride(0), 1))
 
 
-def _wgrad_small_t(xs, y, out, alpha=1.0):
+def _wgrad_small_t(xs, y, out, alpha=1.0, scatter=None):
     """out[P, Q] = alpha * xs^T @ y   with xs [M, P] small (P <= 64) and y [M, Q] large, consumed in place.
     bf16: only the small operand is transposed (zero-padded to a multiple of 64 tokens); the large one is the
-    transposed-B operand of the MFMA GEMM.  f32: strided operands."""
+    transposed-B operand of the MFMA GEMM.  f32: strided operands.
+    scatter = (dst, rows_used, sp, sq): instead of writing `out`, accumulate dst[p*sp + q*sq] += result[p, q] for
+    p < rows_used (the gradient's own layout inside the optimiser's flat buffer); returns True when that was done."""
     M = xs.shape[0]
     if xs.dtype == torch.bfloat16:
         mp = (M + 63) // 64 * 64
@@ -535,6 +543,10 @@ def _wgrad_small_t(xs, y, out, alpha=1.0):
             P, Q = xt.shape[0], y.shape[1]
             slabs = torch.empty(kch, P, Q, dtype=torch.float32, device=xs.device)
             ops.gemm_splitk_bt(xt, y, slabs, kch)
+            if scatter is not None:
+                dst, rows_used, sp, sq = scatter
+                ops.slab_reduce(slabs, rows_used, dst, sp, sq, alpha=alpha, accumulate=True)
+                return True
             ops.colsum(slabs.view(kch, P * Q), out.view(P * Q))
             if alpha != 1.0:
                 ops.axpby(out.view(-1), alpha, out.view(-1), 0.0)

@@ -196,6 +196,34 @@ extern "C" int vfm_colsum(const void* x, int dt, long ld, long rows, long cols, 
   return VFM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ split-K slab reduction
+// dst[p*sp + q*sq] (+)= alpha * sum_k slabs[k][p][q]  for p < rows_used: the combine step of the split-K weight-gradient
+// GEMMs, with the (possibly transposing) scatter into the parameter's gradient layout and the accumulation fused in -
+// one launch instead of colsum (2) + strided copy (1).  Fixed summation order: bitwise reproducible.
+__global__ void k_slab_reduce(const float* __restrict__ slabs, int kch, long P, long Q, long rows_used, float alpha,
+                              float* __restrict__ dst, long sp, long sq, int accumulate) {
+  const long total = rows_used * Q;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i / Q, q = i - p * Q;
+    float a = 0.f;
+    for (int k = 0; k < kch; ++k) a += slabs[((long)k * P + p) * Q + q];
+    a *= alpha;
+    float* d = dst + p * sp + q * sq;
+    *d = accumulate ? *d + a : a;
+  }
+}
+extern "C" int vfm_slab_reduce(const float* slabs, int kch, long P, long Q, long rows_used, float alpha, float* dst, long sp,
+                               long sq, int accumulate, void* stream) {
+  VFM_CHECK(kch >= 1 && rows_used >= 0 && rows_used <= P, VFM_E_SHAPE, "vfm_slab_reduce: bad shape");
+  const long total = rows_used * Q;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_slab_reduce, dim3(grid), dim3(256), 0, (hipStream_t)stream, slabs, kch, P, Q, rows_used, alpha, dst, sp, sq,
+                     accumulate);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ dropout
 template <typename T>
 __global__ void k_dropout_mask(T* __restrict__ out, long n, float p, float keep_scale, uint64_t seed, uint64_t offset) {
@@ -390,15 +418,19 @@ __global__ void k_mask_token_fwd(const float* __restrict__ x, const uint8_t* __r
     out[i] = keep[r] ? x[i] : tok[c];
   }
 }
-// dx = keep ? dout : 0 ; dtoken[c] = sum over masked rows of dout[r,c]   (one block per 64 columns, deterministic)
+// dx = keep ? dout : 0 ; dtoken[c] = sum over masked rows of dout[r,c].  Block (64 columns, one row chunk) -> partial sums
+// ws[chunk][C]; k_colsum2 adds the chunks in a fixed order (deterministic; 4 blocks looping over every row took 136 us).
 __global__ void k_mask_token_bwd(const float* __restrict__ dout, const uint8_t* __restrict__ keep, float* __restrict__ dx,
-                                 float* __restrict__ dtok, long rows, long C) {
+                                 float* __restrict__ ws, long rows, long C, long rows_per_chunk) {
   __shared__ float sh[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const long c = (long)blockIdx.x * 64 + tx;
+  const long r0 = (long)blockIdx.y * rows_per_chunk;
+  long r1 = r0 + rows_per_chunk;
+  if (r1 > rows) r1 = rows;
   float acc = 0.f;
   if (c < C) {
-    for (long r = ty; r < rows; r += 4) {
+    for (long r = r0 + ty; r < r1; r += 4) {
       const float d = dout[r * C + c];
       const bool k = keep[r] != 0;
       dx[r * C + c] = k ? d : 0.f;
@@ -407,7 +439,7 @@ __global__ void k_mask_token_bwd(const float* __restrict__ dout, const uint8_t* 
   }
   sh[ty][tx] = acc;
   __syncthreads();
-  if (ty == 0 && c < C) dtok[c] = sh[0][tx] + sh[1][tx] + sh[2][tx] + sh[3][tx];
+  if (ty == 0 && c < C) ws[(long)blockIdx.y * C + c] = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
 }
 extern "C" int vfm_mask_token_fwd(const float* x, const uint8_t* keep, const float* token, float* out, long rows, long C,
                                   void* stream) {
@@ -418,10 +450,16 @@ extern "C" int vfm_mask_token_fwd(const float* x, const uint8_t* keep, const flo
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }
-extern "C" int vfm_mask_token_bwd(const float* dout, const uint8_t* keep, float* dx, float* dtoken, long rows, long C,
+extern "C" int vfm_mask_token_bwd(const float* dout, const uint8_t* keep, float* dx, float* dtoken, float* ws, long rows, long C,
                                   void* stream) {
+  VFM_CHECK(ws, VFM_E_INVAL, "vfm_mask_token_bwd: ws (>= 64*C floats) required");
   if (rows * C == 0) return VFM_OK;
-  hipLaunchKernelGGL(k_mask_token_bwd, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, dout, keep, dx, dtoken, rows, C);
+  long nchunk = (rows + 31) / 32;
+  if (nchunk > 64) nchunk = 64;
+  const long rpc = (rows + nchunk - 1) / nchunk;
+  hipLaunchKernelGGL(k_mask_token_bwd, dim3(cdiv(C, 64), (unsigned)nchunk), dim3(256), 0, (hipStream_t)stream, dout, keep, dx, ws, rows,
+                     C, rpc);
+  hipLaunchKernelGGL(k_colsum2, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, ws, C, (int)nchunk, dtoken, 0);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }

@@ -274,16 +274,23 @@ __global__ void k_ln_bwd(const TD* __restrict__ dy, long ld_dy, const float* __r
     }
   }
 }
+// block = 64 channels x 4 part-groups (a thread per channel looping over all 128 partials took 32 us)
 __global__ void k_ln_bwd_fin(const float* __restrict__ ws, int parts, int C, float* __restrict__ dw, float* __restrict__ db) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float sh[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
   float a = 0.f, b = 0.f;
-  for (int p = 0; p < parts; ++p) {
-    a += ws[((long)p * 2 + 0) * C + c];
-    b += ws[((long)p * 2 + 1) * C + c];
+  if (c < C)
+    for (int p = ty; p < parts; p += 4) {
+      a += ws[((long)p * 2 + 0) * C + c];
+      b += ws[((long)p * 2 + 1) * C + c];
+    }
+  sh[0][ty][tx] = a, sh[1][ty][tx] = b;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    if (dw) dw[c] += (sh[0][0][tx] + sh[0][1][tx]) + (sh[0][2][tx] + sh[0][3][tx]);
+    if (db) db[c] += (sh[1][0][tx] + sh[1][1][tx]) + (sh[1][2][tx] + sh[1][3][tx]);
   }
-  if (dw) dw[c] += a;
-  if (db) db[c] += b;
 }
 
 static int ln_bwd_impl(const void* dy, int dy_dt, long ld_dy, const float* x, long ld_x, const float* w, const float* stats,
@@ -340,7 +347,7 @@ static int ln_bwd_impl(const void* dy, int dy_dt, long ld_dy, const float* x, lo
     else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_bwd: dtype");
   }
 #undef L
-  if (need_w) hipLaunchKernelGGL(k_ln_bwd_fin, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, parts, (int)C, dw, db);
+  if (need_w) hipLaunchKernelGGL(k_ln_bwd_fin, dim3(cdiv(C, 64)), dim3(256), 0, s, ws, parts, (int)C, dw, db);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }
@@ -410,19 +417,26 @@ static inline int pick_chunks(long P) {
 
 // =============================================================================================== GroupNorm
 // finalize forward: one thread per (b,g): combine channel partials in double
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// one wave per (image, group): the lanes split the nchunk x (C/G) partial sums (a single thread looping over them took 25 us)
 __global__ void k_gn_fin_fwd(const float* __restrict__ ws, int nchunk, int C, int G, long P, float eps,
                              float* __restrict__ stats, int BG) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= BG) return;
   const int b = i / G, g = i - b * G, cg = C / G;
   double s = 0.0, q = 0.0;
-  for (int k = 0; k < nchunk; ++k) {
+  for (int e = lane; e < nchunk * cg; e += 64) {
+    const int k = e / cg, j = e - k * cg;
     const long slot = (long)b * nchunk + k;
-    for (int j = 0; j < cg; ++j) {
-      s += ws[(slot * 2 + 0) * C + g * cg + j];
-      q += ws[(slot * 2 + 1) * C + g * cg + j];
-    }
+    s += ws[(slot * 2 + 0) * C + g * cg + j];
+    q += ws[(slot * 2 + 1) * C + g * cg + j];
   }
+  s = wave_sum_f64(s), q = wave_sum_f64(q);
+  if (lane) return;
   const double n = (double)P * cg;
   const double mean = s / n;
   double var = q / n - mean * mean;
@@ -453,7 +467,7 @@ extern "C" int vfm_groupnorm_fwd(const float* x, const float* w, const float* b,
   float* ws = ws_in + B * G * 2;
   hipLaunchKernelGGL((k_chan_moments<0, float>), dim3(cdiv(C, 64), nchunk, (unsigned)B), dim3(256), 0, s, x, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0.f, 0, ws, P, (int)C, rpc);
-  hipLaunchKernelGGL(k_gn_fin_fwd, dim3(cdiv(B * G, 64)), dim3(64), 0, s, ws, nchunk, (int)C, G, P, eps, stats, (int)(B * G));
+  hipLaunchKernelGGL(k_gn_fin_fwd, dim3(cdiv(B * G, 4)), dim3(256), 0, s, ws, nchunk, (int)C, G, P, eps, stats, (int)(B * G));
   const long total = B * P * C;
   const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   if (y_dt == VFM_BF16) hipLaunchKernelGGL(k_gn_apply<bf16_t>, dim3(grid), dim3(256), 0, s, x, w, b, stats, G, act, (bf16_t*)y, B, P, (int)C);
@@ -466,31 +480,38 @@ extern "C" int vfm_groupnorm_fwd(const float* x, const float* w, const float* b,
 // backward finalize: per (b,g): s1 = sum_c w*sum dz, s2 = sum_c w*sum dz*xhat -> gs[b][g][2]; and dw/db accumulate
 __global__ void k_gn_fin_bwd(const float* __restrict__ ws, int nchunk, int C, int G, const float* __restrict__ w,
                              float* __restrict__ gs, int BG) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= BG) return;
   const int b = i / G, g = i - b * G, cg = C / G;
   double s1 = 0.0, s2 = 0.0;
-  for (int k = 0; k < nchunk; ++k) {
+  for (int e = lane; e < nchunk * cg; e += 64) {
+    const int k = e / cg, j = e - k * cg;
     const long slot = (long)b * nchunk + k;
-    for (int j = 0; j < cg; ++j) {
-      const int c = g * cg + j;
-      s1 += (double)w[c] * ws[(slot * 2 + 0) * C + c];
-      s2 += (double)w[c] * ws[(slot * 2 + 1) * C + c];
-    }
+    const int c = g * cg + j;
+    s1 += (double)w[c] * ws[(slot * 2 + 0) * C + c];
+    s2 += (double)w[c] * ws[(slot * 2 + 1) * C + c];
   }
+  s1 = wave_sum_f64(s1), s2 = wave_sum_f64(s2);
+  if (lane) return;
   gs[i * 2] = (float)s1;
   gs[i * 2 + 1] = (float)s2;
 }
 __global__ void k_chan_fin_wb(const float* __restrict__ ws, int slots, int C, float* __restrict__ dw, float* __restrict__ db) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float sh[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
   float a = 0.f, b = 0.f;
-  for (int k = 0; k < slots; ++k) {
-    b += ws[((long)k * 2 + 0) * C + c];
-    a += ws[((long)k * 2 + 1) * C + c];
+  if (c < C)
+    for (int k = ty; k < slots; k += 4) {
+      b += ws[((long)k * 2 + 0) * C + c];
+      a += ws[((long)k * 2 + 1) * C + c];
+    }
+  sh[0][ty][tx] = a, sh[1][ty][tx] = b;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    if (dw) dw[c] += (sh[0][0][tx] + sh[0][1][tx]) + (sh[0][2][tx] + sh[0][3][tx]);
+    if (db) db[c] += (sh[1][0][tx] + sh[1][1][tx]) + (sh[1][2][tx] + sh[1][3][tx]);
   }
-  if (dw) dw[c] += a;
-  if (db) db[c] += b;
 }
 template <typename TD>
 __global__ void k_gn_bwd_apply(const TD* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ w,
@@ -526,8 +547,8 @@ extern "C" int vfm_groupnorm_bwd(const void* dy, int dy_dt, const float* x, cons
   else if (dy_dt == VFM_F32)
     hipLaunchKernelGGL((k_chan_moments<1, float>), grid, dim3(256), 0, s, x, (const float*)dy, w, b, stats, G, 0.f, act, part, P, (int)C, rpc);
   else VFM_FAIL(VFM_E_INVAL, "vfm_groupnorm_bwd: dtype");
-  hipLaunchKernelGGL(k_gn_fin_bwd, dim3(cdiv(B * G, 64)), dim3(64), 0, s, part, nchunk, (int)C, G, w, gs, (int)(B * G));
-  if (dw || db) hipLaunchKernelGGL(k_chan_fin_wb, dim3(cdiv(C, 256)), dim3(256), 0, s, part, (int)(B * nchunk), (int)C, dw, db);
+  hipLaunchKernelGGL(k_gn_fin_bwd, dim3(cdiv(B * G, 4)), dim3(256), 0, s, part, nchunk, (int)C, G, w, gs, (int)(B * G));
+  if (dw || db) hipLaunchKernelGGL(k_chan_fin_wb, dim3(cdiv(C, 64)), dim3(256), 0, s, part, (int)(B * nchunk), (int)C, dw, db);
   const long total = B * P * C;
   const int g2 = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   if (dy_dt == VFM_BF16) hipLaunchKernelGGL(k_gn_bwd_apply<bf16_t>, dim3(g2), dim3(256), 0, s, (const bf16_t*)dy, x, w, b, stats, gs, G, act, dx, B, P, (int)C);

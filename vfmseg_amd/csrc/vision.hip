@@ -411,7 +411,9 @@ __global__ void __launch_bounds__(256) k_upsample_ce_tile(const float* __restric
   float* Ps = Ls + LT * LT * PS;     // [R*R][C]   probabilities
   float* Lv = Ps + R * R * PS;       // [R*R]      loss term (lse - v[label]) of valid pixels
   int* Lb = (int*)(Lv + R * R);           // [R*R]      label, -1 = outside the image / ignored; bit 8 set = arg-max hit
+  __shared__ int cnt_s[2];
   const int tid = threadIdx.x;
+  if (tid < 2) cnt_s[tid] = 0;
   const int tiles_x = w / T, tiles_y = h / T;
   const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y;
   const long b = blockIdx.x / (tiles_x * tiles_y);
@@ -497,12 +499,14 @@ __global__ void __launch_bounds__(256) k_upsample_ce_tile(const float* __restric
     if (dlogits) dlogits[pix * C + c] = g;
     if (c == 0) {
       loss_parts[pix] = loss;
-      if (valid) {
-        atomicAdd(&counts[0], hits);
-        atomicAdd(&counts[1], valid);
+      if (valid) {  // block-level tally first: same-address global atomics serialise (2 per low-res pixel cost ~250 us)
+        atomicAdd(&cnt_s[0], hits);
+        atomicAdd(&cnt_s[1], valid);
       }
     }
   }
+  __syncthreads();
+  if (tid < 2 && cnt_s[tid]) atomicAdd(&counts[tid], cnt_s[tid]);
 }
 
 extern "C" int vfm_upsample_ce(const float* logits_low, const int64_t* label, int B, int h, int w, int C, int H, int W,

@@ -54,6 +54,7 @@ SIGNATURES = {
     "vfm_axpby": [vp, cf, vp, cf, cl, vp],
     "vfm_scale_by_device_scalar": [vp, vp, cl, vp],
     "vfm_colsum": [vp, ci, cl, cl, cl, vp, ci, vp, vp],
+    "vfm_slab_reduce": [vp, ci, cl, cl, cl, cf, vp, cl, cl, ci, vp],
     "vfm_dropout_mask": [vp, ci, cl, cf, u64, u64, vp],
     "vfm_mul_mask": [vp, ci, cl, vp, ci, cl, cl, vp, ci, cl, cl, cl, vp],
     "vfm_geglu_fwd": [vp, ci, cl, vp, ci, cl, cl, cl, vp],
@@ -63,7 +64,7 @@ SIGNATURES = {
     "vfm_rope": [vp, ci, cl, cl, ci, ci, ci, vp, vp, ci, vp],
     "vfm_act_grad_mul": [vp, ci, cl, vp, ci, cl, vp, ci, cl, cl, cl, ci, vp],
     "vfm_mask_token_fwd": [vp, vp, vp, vp, cl, cl, vp],
-    "vfm_mask_token_bwd": [vp, vp, vp, vp, cl, cl, vp],
+    "vfm_mask_token_bwd": [vp, vp, vp, vp, vp, cl, cl, vp],
     "vfm_layernorm_fwd": [vp, cl, vp, vp, cf, vp, ci, cl, vp, cl, cl, vp],
     "vfm_layernorm_dropout_fwd": [vp, cl, vp, vp, cf, vp, cl, vp, vp, cl, vp, cl, cf, u64, u64, cl, cl, vp],
     "vfm_layernorm_bwd_scaled": [vp, ci, cl, vp, cl, vp, vp, vp, cl, ci, vp, cl, vp, cl, cl, vp],

@@ -159,7 +159,8 @@ def mask_token_fwd(x, keep, token, out):
 
 def mask_token_bwd(dout, keep, dx, dtoken):
     lib = L.load()
-    L.check(lib.vfm_mask_token_bwd(L.ptr(dout), L.ptr(keep), L.ptr(dx), L.ptr(dtoken), dout.shape[0], dout.shape[1],
+    ws = workspace(64 * dout.shape[1], dout.device)
+    L.check(lib.vfm_mask_token_bwd(L.ptr(dout), L.ptr(keep), L.ptr(dx), L.ptr(dtoken), L.ptr(ws), dout.shape[0], dout.shape[1],
                                    L.stream()), "vfm_mask_token_bwd")
 
 
@@ -312,6 +313,16 @@ def gemm(a, b, c, *, alpha=1.0, bias=None, bias_mod=0, colscale=None, residual=N
         d.batch = 1
     L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
     return c
+
+
+def slab_reduce(slabs, rows_used, dst, sp, sq, alpha=1.0, accumulate=False):
+    """dst[p*sp + q*sq] (+)= alpha * sum_k slabs[k, p, q] for p < rows_used (slabs fp32 [kch, P, Q], dst fp32)."""
+    lib = L.load()
+    kch, P, Q = slabs.shape
+    assert slabs.is_contiguous() and slabs.dtype == torch.float32 and dst.dtype == torch.float32
+    L.check(lib.vfm_slab_reduce(L.ptr(slabs), kch, P, Q, int(rows_used), float(alpha), L.ptr(dst), int(sp), int(sq), int(accumulate),
+                                L.stream()), "vfm_slab_reduce")
+    return dst
 
 
 def gemm_splitk_bt(at, y, slabs, kch):
