@@ -7,7 +7,7 @@ from vfmseg_amd import ops
 cfg = int(os.environ.get("CFG", "30"))
 torch.manual_seed(0)
 bad = 0
-for (M, N, K) in [(256, 256, 128), (256, 256, 192), (300, 520, 320), (4096, 4096, 1024), (4100, 3072, 1088), (1000, 1000, 4096),
+for (M, N, K) in [(256, 256, 256), (256, 256, 320), (300, 520, 320), (4096, 4096, 1024), (4100, 3072, 1088), (1000, 1000, 4096),
                   (4096, 1024, 4096), (515, 2048, 64 * 7)]:
     a = torch.randn(M, K, device="cuda").bfloat16()
     b = torch.randn(N, K, device="cuda").bfloat16()

@@ -220,11 +220,11 @@ class Packed:
         n, k = w_f32.shape
         k_pad = k_pad or k
         self.n, self.k = n, k_pad
-        self.w = torch.zeros(n, k_pad, dtype=cd, device=w_f32.device)
+        self.w = ops.empty_ld(n, k_pad, cd, w_f32.device, zero=True)
         ops.cast(w_f32, self.w[:, :k])
         self.wt = None
         if cd == torch.bfloat16:
-            self.wt = torch.zeros(k_pad, n, dtype=cd, device=w_f32.device)
+            self.wt = ops.empty_ld(k_pad, n, cd, w_f32.device, zero=True)
             ops.transpose(w_f32, self.wt[:k], pad_rows=n)
 
     def fwd(self, a, out, **epi):
@@ -417,7 +417,7 @@ class DinoEngine:
             ops.layernorm_fwd(xm, Lp["n2w"], Lp["n2b"], 1e-6, a2, st2)
             hid = Lp["fc1"].n
             hpre = torch.empty(M, hid, dtype=cd, device=dev)
-            g = torch.empty(M, hid, dtype=cd, device=dev)
+            g = ops.empty_ld(M, hid, cd, dev)
             Lp["fc1"].fwd(a2, g, bias=Lp["fc1_b"], ep_mode=ops.EP_GELU, c2=hpre)
             xo = torch.empty(M, D, dtype=torch.float32, device=dev)
             Lp["fc2"].fwd(g, xo, bias=Lp["fc2_b"], colscale=Lp["g2"], residual=xm)
@@ -456,7 +456,7 @@ class DinoEngine:
                 t = torch.empty(M, D, dtype=cd, device=dev)
                 ops.cast(dx, t, Lp["g2"])
             hid = Lp["fc1"].n
-            dh = torch.empty(M, hid, dtype=cd, device=dev)
+            dh = ops.empty_ld(M, hid, cd, dev)
             Lp["fc2"].dgrad(t, dh, ep_mode=ops.EP_MUL_GELU_GRAD, aux=S["hpre"])
             dn = torch.empty(M, D, dtype=cd, device=dev)
             Lp["fc1"].dgrad(dh, dn)

@@ -367,6 +367,7 @@ static bool vec_ok(const vfm_gemm_desc* d) {
 //  15: 256x256 4x2 NS2  16: 256x256 4x4 NS2   17: 128x128 2x4 NS2  18: 64x128 2x2 NS2   19: 128x64 2x2 NS2
 static int gemm_main(const vfm_gemm_desc* d, hipStream_t s);
 void vfm_gemm_launch_pp256(const vfm_gemm_desc* d, hipStream_t s, bool vec);  // gemm_pp.hip
+void vfm_gemm_launch_pp128(const vfm_gemm_desc* d, hipStream_t s, bool vec);  // gemm_pp.hip
 
 int vfm_gemm_bf16_impl(const vfm_gemm_desc* d0, hipStream_t s) {
   // A few rows past a 128-row boundary (M = B*1024 patch tokens + B [cls] tokens) would cost a whole extra row of
@@ -413,6 +414,8 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s) {
     const long t256 = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
     if (d->N <= 32) cfg = 10;                                        // 64x64 tiles: many rows, few columns
     else if (t128 <= 160) cfg = 18;                                  // small problems: 64x128 tiles fill more CUs
+    else if (g_use_pp && t128 > 160 && t128 <= 272 && d->K >= 256 && (d->M + 128) * d->sa_m < (1l << 31) && (d->N + 128) * d->sb_n < (1l << 31))
+      cfg = 31;  // about one 128x128 tile per CU: the ping-pong kernel (one block per CU, 4-slot DMA ring)
     else if (d->N >= 2048 && (t256 % 256 == 0 || t256 >= 768))
       cfg = (g_use_pp && d->K >= 128 && (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31)) ? 30 : 16;  // 256x256 tiles
     else cfg = 17;                                                   // 128x128, 8 waves, 2 blocks per CU
@@ -443,6 +446,10 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s) {
     case 22: launch_cfg<256, 128, 4, 4, 2>(d, s, vec); break;
     case 23: launch_cfg<128, 128, 4, 4, 3>(d, s, vec); break;
     case 24: launch_cfg<128, 128, 4, 4, 2>(d, s, vec); break;
+    case 31:
+      VFM_CHECK(d->K >= 256, VFM_E_UNSUPPORTED, "vfm_gemm(bf16): the 128x128 ping-pong kernel needs K >= 256");
+      vfm_gemm_launch_pp128(d, s, vec);
+      break;
     case 30:
       VFM_CHECK(d->K >= 128, VFM_E_UNSUPPORTED, "vfm_gemm(bf16): the ping-pong kernel needs K >= 128");
       vfm_gemm_launch_pp256(d, s, vec);

@@ -206,6 +206,192 @@ __global__ void __launch_bounds__(512)
   else epi_scalar<4, 2, 2>(e, zoff, acc, img, lane, m0 + g * 128, n0 + wc * 64, M, N);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 128 x 128 tiles (the N = 1024 GEMMs of a ViT-L block at M = 4096: exactly one tile per CU).  Same ping-pong structure:
+// group g = rows g*64..g*64+63, wave w&3 = a 32-column strip, phase = one 64-wide K-tile = 8 MFMAs per wave; the
+// fragments (12 ds_read_b128 per phase) are double-buffered in registers (the accumulator is only 32 VGPRs here), so
+//     group 0:  MFMA(P)  READ(P+1)  DMA          group 1:  DMA  READ(P+1)  MFMA(P)
+// and every wave ends the interval with its counted vmcnt, lgkmcnt(0) and the barrier.
+// LDS: ring of 4 K-tile slots x (A 128 rows x 128 B | B 128 rows x 128 B), the k_gemm_bf16 image (16-B piece c of row r at
+// c ^ ((r>>1)&7)), 4 DMA pieces (8 rows x 128 B) per wave and K-tile.  K-tile j is issued in interval j-4 (its slot's last
+// reads finished before the barrier that ended interval j-5), is waited for at the end of interval j-2 (two K-tiles = 8
+// DMA instructions stay in flight) and read in interval j-1.
+namespace {
+constexpr int P1_SLOT = 32768;
+constexpr int P1_RING = 4 * P1_SLOT;
+constexpr int P1_EPI_BYTES = 8 * 64 * (32 + 4) * 4;
+constexpr int P1_SMEM = P1_RING;
+}  // namespace
+
+template <bool VEC>
+__global__ void __launch_bounds__(512)
+    k_gemm_pp128(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, long M, long N, long K, long stride_a,
+                 long stride_b, long stride_c, int tiles_m, int tiles_n, EpiParams e) {
+  constexpr int BM = 128, BN = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave >> 2, wc = wave & 3;
+
+  const int ntiles = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GM = 8;
+  const int group = bid / (GM * tiles_n);
+  const int first_m = group * GM;
+  const int gsz = min(tiles_m - first_m, GM);
+  const int tm = first_m + (bid % (GM * tiles_n)) % gsz;
+  const int tn = (bid % (GM * tiles_n)) / gsz;
+  const long m0 = (long)tm * BM, n0 = (long)tn * BN;
+  const long z = blockIdx.y;
+  const bf16_t* Ab = A + z * stride_a;
+  const bf16_t* Bb = B + z * stride_b;
+
+  // DMA sources: piece = 8 rows x 128 B; wave w moves pieces 2w, 2w+1 of the A image and of the B image
+  unsigned soff[2][2];  // [0: A, 1: B][piece]
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave * 2 + j) * 8 + (lane >> 3);
+    const int sw = ((lane & 7) ^ ((r >> 1) & 7)) << 3;
+    long gm = m0 + r, gn = n0 + r;
+    if (gm > M - 1) gm = M - 1;
+    if (gn > N - 1) gn = N - 1;
+    soff[0][j] = (unsigned)((gm * lda + sw) * 2);
+    soff[1][j] = (unsigned)((gn * ldb + sw) * 2);
+  }
+  auto issue = [&](int u) {  // K-tile u -> ring slot u & 3
+    char* dst = smem + (u & 3) * P1_SLOT + wave * 2048;
+    const char* pa = (const char*)Ab + (long)u * 128;
+    const char* pb = (const char*)Bb + (long)u * 128;
+    glds16(pa + soff[0][0], dst);
+    glds16(pa + soff[0][1], dst + 1024);
+    glds16(pb + soff[1][0], dst + 16384);
+    glds16(pb + soff[1][1], dst + 16384 + 1024);
+  };
+
+  f32x16 acc[2][1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  int ra[4], rb[4];  // byte offsets inside a slot, per k-step s
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int kx = ((2 * s + fh) ^ ((fr >> 1) & 7)) << 4;
+    ra[s] = (g * 64 + fr) * 128 + kx;
+    rb[s] = 16384 + (wc * 32 + fr) * 128 + kx;
+  }
+  const int nk = (int)(K / 64);  // >= 4 (checked by the dispatcher)
+  bf16x8 af[2][2][4], bfr[2][4];  // [buffer][i][s], [buffer][s]
+
+  auto read = [&](auto Bc, int u) {  // fragments of K-tile u -> register buffer Bc
+    constexpr int BUF = decltype(Bc)::value;
+    const char* sl = smem + (u & 3) * P1_SLOT;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) bfr[BUF][s] = *reinterpret_cast<const bf16x8*>(sl + rb[s]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) af[BUF][i][s] = *reinterpret_cast<const bf16x8*>(sl + ra[s] + i * 4096);
+  };
+  // X: 0 steady; 1..4 = the last four phases (nothing left to issue; the last one has nothing left to read)
+  auto phase = [&](auto Gc, auto Bc, auto Xc, int u) {
+    constexpr int G = decltype(Gc)::value, BUF = decltype(Bc)::value, X = decltype(Xc)::value;
+    auto mfma = [&]() {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[BUF][i][s], bfr[BUF][s], acc[i][0], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (G == 0) {
+      mfma();
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (X != 4) read(IC<BUF ^ 1>{}, u + 1);
+      if constexpr (X == 0) issue(u + 4);
+    } else {
+      if constexpr (X == 0) issue(u + 4);
+      if constexpr (X != 4) read(IC<BUF ^ 1>{}, u + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int live = X == 0 ? 2 : (X == 1 ? 1 : 0);  // K-tiles that may stay in flight
+    wait_vmcnt<4 * live>();
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: K-tiles 0..3 in flight, 0 and 1 landed, fragments of K-tile 0 in buffer 0
+  issue(0);
+  issue(1);
+  issue(2);
+  issue(3);
+  wait_vmcnt<8>();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  read(IC<0>{}, 0);
+  __builtin_amdgcn_sched_barrier(0);
+
+  const int its = (nk - 4) / 2;
+  auto mainloop = [&](auto Gc) {
+    int u = 0;
+    for (int it = 0; it < its; ++it) {
+      phase(Gc, IC<0>{}, IC<0>{}, u);
+      phase(Gc, IC<1>{}, IC<0>{}, u + 1);
+      u += 2;
+    }
+    if ((nk - 4) & 1) {
+      phase(Gc, IC<0>{}, IC<0>{}, u);
+      phase(Gc, IC<1>{}, IC<1>{}, u + 1);
+      phase(Gc, IC<0>{}, IC<2>{}, u + 2);
+      phase(Gc, IC<1>{}, IC<3>{}, u + 3);
+      phase(Gc, IC<0>{}, IC<4>{}, u + 4);
+    } else {
+      phase(Gc, IC<0>{}, IC<1>{}, u);
+      phase(Gc, IC<1>{}, IC<2>{}, u + 1);
+      phase(Gc, IC<0>{}, IC<3>{}, u + 2);
+      phase(Gc, IC<1>{}, IC<4>{}, u + 3);
+    }
+  };
+  if (g == 0) mainloop(IC<0>{});
+  else mainloop(IC<1>{});
+  __builtin_amdgcn_sched_barrier(0);
+
+  const long zoff = z * stride_c;
+  __syncthreads();
+  float* img = reinterpret_cast<float*>(smem) + wave * 64 * (32 + 4);
+  if constexpr (VEC) epi_wave_tile<2, 1, 2>(e, zoff, acc, img, lane, m0 + g * 64, n0 + wc * 32, M, N);
+  else epi_scalar<2, 1, 2>(e, zoff, acc, img, lane, m0 + g * 64, n0 + wc * 32, M, N);
+}
+
+template <bool VEC>
+static void launch_pp128_t(const vfm_gemm_desc* d, hipStream_t s) {
+  const int tiles_m = cdiv(d->M, 128), tiles_n = cdiv(d->N, 128);
+  const long batch = d->batch > 0 ? d->batch : 1;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_gemm_pp128<VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, P1_SMEM);
+    attr = true;
+  }
+  hipLaunchKernelGGL((k_gemm_pp128<VEC>), dim3(tiles_m * tiles_n, (unsigned)batch), dim3(512), P1_SMEM, s, (const bf16_t*)d->A,
+                     d->sa_m, (const bf16_t*)d->B, d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c, tiles_m, tiles_n,
+                     make_epi(d));
+}
+void vfm_gemm_launch_pp128(const vfm_gemm_desc* d, hipStream_t s, bool vec) {
+  if (vec) launch_pp128_t<true>(d, s);
+  else launch_pp128_t<false>(d, s);
+}
+
 int g_pp_dbg = 0;
 template <bool VEC>
 static void launch_pp256_t(const vfm_gemm_desc* d, hipStream_t s) {
