@@ -266,6 +266,41 @@ def test_gemm_bf16(M, N, K):
     assert relerr(cw[:, :N], a.double() @ b.double().t()) < 2e-5 and cw[:, N:].abs().sum() == 0
 
 
+@pytest.mark.parametrize("cfg", [17, 16, 30, 31])
+@pytest.mark.parametrize("M,N,K", [(4100, 1024, 1024), (300, 520, 320), (1024, 2048, 448), (256, 256, 4096)])
+def test_gemm_bf16_configs_fast_epilogues(cfg, M, N, K):
+    """Every tile configuration incl. the ping-pong kernels (30: 256x256, 31: 128x128) x the specialised epilogue instances
+    the backbones use; repeated launches double as a race screen for the LDS-DMA ring."""
+    a, b = rnd(M, K, seed=80).bfloat16().to(DEV), rnd(N, K, seed=81).bfloat16().to(DEV)
+    bias, cs, res = rnd(N, seed=82).to(DEV), (rnd(N, seed=83) * 0.2 + 1).to(DEV), rnd(M, N, seed=84).to(DEV)
+    aux = rnd(M, N, seed=85).bfloat16().to(DEV)
+    acc = a.double() @ b.double().t()
+    bd, cd, rd, ad = bias.double(), cs.double(), res.double(), aux.double()
+    gelu = lambda t: 0.5 * t * (1 + torch.erf(t / 2 ** 0.5))
+    gelu_grad = lambda t: 0.5 * (1 + torch.erf(t / 2 ** 0.5)) + t * torch.exp(-0.5 * t * t) / (2 * 3.141592653589793) ** 0.5
+    ops.tune("gemm_cfg", cfg)
+    try:
+        for rep in range(3):
+            c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ops.gemm(a, b, c, bias=bias)
+            assert relerr(c.float(), acc + bd) < 1e-2
+            c = torch.full((M, N), float("nan"), device=DEV)
+            ops.gemm(a, b, c, alpha=0.5)
+            assert relerr(c, 0.5 * acc) < 2e-5
+            c = torch.full((M, N), float("nan"), device=DEV)
+            ops.gemm(a, b, c, bias=bias, colscale=cs, residual=res)
+            assert relerr(c, (acc + bd) * cd + rd) < 2e-5
+            c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            c2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ops.gemm(a, b, c, bias=bias, ep_mode=ops.EP_GELU, c2=c2)
+            assert relerr(c.float(), gelu(acc + bd)) < 1e-2 and relerr(c2.float(), acc + bd) < 1e-2
+            c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ops.gemm(a, b, c, ep_mode=ops.EP_MUL_GELU_GRAD, aux=aux)
+            assert relerr(c.float(), acc * gelu_grad(ad)) < 1e-2
+    finally:
+        ops.tune("gemm_cfg", -1)
+
+
 @pytest.mark.parametrize("P,M,Q", [(64, 4100, 3072), (64, 4100, 1024), (1024, 2048, 4096), (19, 1000, 256), (200, 333, 128)])
 def test_gemm_bf16_transposed_b(P, M, Q):
     """Weight-gradient form: out[P,Q] = xs^T[P,M] @ y[M,Q], y consumed in place ([K,N] operand), tokens zero-padded."""
