@@ -327,7 +327,7 @@ def test_gemm_bf16_transposed_b(P, M, Q):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("nq_extra,nk_extra,nq,nk", [(1, 1, 200, 200), (0, 0, 256, 256), (0, 0, 130, 70), (1, 1, 1024, 1024)])
+@pytest.mark.parametrize("nq_extra,nk_extra,nq,nk", [(1, 1, 200, 200), (0, 0, 256, 256), (0, 0, 130, 70), (1, 1, 1024, 1024), (1, 1, 128, 384)])
 def test_attention(dt, nq_extra, nk_extra, nq, nk):
     B, H, d = 2, 3, 64
     hd = H * d
