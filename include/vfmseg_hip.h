@@ -24,9 +24,10 @@ extern "C" {
 enum { VFM_F32 = 0, VFM_BF16 = 1, VFM_U8 = 2, VFM_I64 = 3 };
 enum { VFM_OK = 0, VFM_E_INVAL = -1, VFM_E_SHAPE = -2, VFM_E_ALIGN = -3, VFM_E_HIP = -4, VFM_E_UNSUPPORTED = -5 };
 /* GEMM epilogue modes */
-enum { VFM_EP_NONE = 0, VFM_EP_GELU = 1, VFM_EP_RELU = 2, VFM_EP_MUL_GELU_GRAD = 3, VFM_EP_MUL = 4 };
+enum { VFM_EP_NONE = 0, VFM_EP_GELU = 1, VFM_EP_RELU = 2, VFM_EP_MUL_GELU_GRAD = 3, VFM_EP_MUL = 4,
+       VFM_EP_QGELU = 5 /* CLIP QuickGELU x*sigmoid(1.702x), clip.py:18-20 */, VFM_EP_MUL_QGELU_GRAD = 6 };
 /* activation fused into norm kernels */
-enum { VFM_ACT_NONE = 0, VFM_ACT_GELU = 1, VFM_ACT_RELU = 2 };
+enum { VFM_ACT_NONE = 0, VFM_ACT_GELU = 1, VFM_ACT_RELU = 2, VFM_ACT_QGELU = 3 };
 
 const char* vfm_last_error(void);
 int vfm_abi_version(void);

@@ -317,6 +317,56 @@ def gen_eva02(_model=None):
     print("eva02", {k: v[:2] for k, v in out.items() if k.endswith("stats")}, out["lora_live_grad_norm"], out["lora_inert_count"])
 
 
+def gen_clip(_model=None):
+    """CLIP ViT-L/16 + LoRA (out_proj / mlp.c_fc / mlp.c_proj targets; out_proj is consumed by weight inside
+    nn.MultiheadAttention and stays inert): taps and LoRA gradients."""
+    M = ref_shim.load_clip()
+    bcfg = presets.clip_backbone()
+    bb = M.build(bcfg)
+    base_sd = synth_like(bb.state_dict())
+    del bb
+    with tempfile.NamedTemporaryFile(suffix=".pth", delete=False) as f:
+        torch.save(base_sd, f.name)
+        ck = f.name
+    model = M.build(dict(type="LoRABackbone", backbone=bcfg, checkpoint=ck, Lora_config=presets.clip_lora_cfg(dropout=0.0)))
+    os.unlink(ck)
+    sd = model.state_dict()
+    new = synth_like(sd)
+    for k in sd:
+        if "lora_" not in k:
+            new[k] = sd[k]
+    model.load_state_dict(new)
+    model.train()
+    x = synth_image(1, 512, seed=51)
+    taps = model(x)
+    out = {}
+    gen = torch.Generator().manual_seed(7)
+    loss = 0
+    for i, t in enumerate(taps):
+        out[f"tap{i}_stats"] = stats(t)
+        out[f"tap{i}_slice"] = sl(t)
+        loss = loss + (t * torch.randn(t.shape, generator=gen)).sum()
+    loss.backward()
+    named = dict(model.named_parameters())
+    pre = "model.base_model.model.transformer.resblocks."
+    live, inert = 0.0, 0
+    for k, p in named.items():
+        if "lora_" in k:
+            if p.grad is None or float(p.grad.abs().max()) == 0.0:
+                inert += 1
+            else:
+                live += p.grad.double().pow(2).sum().item()
+    out["lora_live_grad_norm"] = np.array([live ** 0.5])
+    out["lora_inert_count"] = np.array([inert])
+    for blk in (0, 23):
+        for nm in ("mlp.c_fc", "mlp.c_proj"):
+            for ab in ("lora_A", "lora_B"):
+                k = f"{pre}{blk}.{nm}.{ab}.default.weight"
+                out["grad_slice::" + k] = sl(named[k].grad)
+    np.savez_compressed(os.path.join(GOLD, "clip.npz"), **out)
+    print("clip", {k: v[:2] for k, v in out.items() if k.endswith("stats")}, out["lora_live_grad_norm"], out["lora_inert_count"])
+
+
 def gen_sam(_model=None):
     """SAM-ViT-H + LoRA(qkv): taps of one 512^2 crop (28 windowed + 4 global blocks, decomposed rel-pos with non-zero tables)."""
     M = ref_shim.load_sam()
@@ -363,6 +413,8 @@ def main():
         gen_eva02()
     if a.only in (None, "sam"):
         gen_sam()
+    if a.only in (None, "clip"):
+        gen_clip()
 
 
 if __name__ == "__main__":

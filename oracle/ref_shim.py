@@ -431,6 +431,12 @@ def load_sam():
     return MODELS
 
 
+def load_clip():
+    load_all()
+    ref_import("models.backbones.clip")
+    return MODELS
+
+
 def load_eva02():
     load_all()
     ref_import("models.backbones.eva_02")

@@ -160,6 +160,50 @@ def eva02_forward(sd, x, depth=24, heads=16, out_indices=(7, 11, 15, 23), patch=
     return outs
 
 
+# =============================================================================== CLIP backbone
+def clip_block(sd, x, i, heads, lora=True, p=BB):
+    """ResidualAttentionBlock.forward (clip.py:65-68): x + MHA(ln_1(x)); x + c_proj(QuickGELU(c_fc(ln_2(x)))).
+    nn.MultiheadAttention consumes in_proj_weight/bias and out_proj.weight/bias as tensors, so the LoRA adapter peft puts on
+    `out_proj` never enters the graph; the adapters on mlp.c_fc / mlp.c_proj are live.  x: [B, N, C]."""
+    q_ = f"{p}transformer.resblocks.{i}."
+    b, n, c = x.shape
+    d = c // heads
+    h = F.layer_norm(x, (c,), sd[q_ + "ln_1.weight"], sd[q_ + "ln_1.bias"], 1e-5)
+    qkv = F.linear(h, sd[q_ + "attn.in_proj_weight"], sd[q_ + "attn.in_proj_bias"]).reshape(b, n, 3, heads, d).permute(2, 0, 3, 1, 4)
+    o = attention(qkv[0], qkv[1], qkv[2], d ** -0.5).transpose(1, 2).reshape(b, n, c)
+    ow = q_ + "attn.out_proj." + ("base_layer." if (q_ + "attn.out_proj.base_layer.weight") in sd else "")
+    x = x + F.linear(o, sd[ow + "weight"], sd[ow + "bias"])
+    h = F.layer_norm(x, (c,), sd[q_ + "ln_2.weight"], sd[q_ + "ln_2.bias"], 1e-5)
+    h = lora_linear(sd, q_ + "mlp.c_fc.", h, lora)
+    h = h * torch.sigmoid(1.702 * h)
+    return x + lora_linear(sd, q_ + "mlp.c_proj.", h, lora)
+
+
+def clip_forward(sd, x, depth=24, heads=16, out_indices=(7, 11, 15, 23), patch=16, lora=True, p=BB):
+    """CLIPVisionTransformer.forward (clip.py:315-348, get_embeddings=False): bias-less conv1, the class embedding is added
+    twice (once in the token, once in cls_pos, :318-337), positional embedding bilinearly re-interpolated to the token grid
+    each forward, ln_pre, taps without the cls token; the fpn layers built in __init__ are never called."""
+    b = x.shape[0]
+    t = F.conv2d(x, sd[p + "conv1.weight"], None, stride=patch)
+    _, c, hh, ww = t.shape
+    t = t.reshape(b, c, -1).permute(0, 2, 1)
+    ce = sd[p + "class_embedding"]
+    t = torch.cat([ce + torch.zeros(b, 1, c), t], dim=1)
+    pos = sd[p + "positional_embedding"]
+    ss = int(round((pos.shape[0] - 1) ** 0.5))
+    cls_pos = pos[0] + ce
+    sp = F.interpolate(pos[1:].reshape(1, ss, ss, c).permute(0, 3, 1, 2), size=(hh, ww), mode="bilinear")
+    sp = sp.reshape(1, c, hh * ww).permute(0, 2, 1)
+    t = t + torch.cat([cls_pos.reshape(1, 1, c), sp], dim=1)
+    t = F.layer_norm(t, (c,), sd[p + "ln_pre.weight"], sd[p + "ln_pre.bias"], 1e-5)
+    outs = []
+    for i in range(depth):
+        t = clip_block(sd, t, i, heads, lora, p)
+        if i in out_indices:
+            outs.append(t[:, 1:].permute(0, 2, 1).reshape(b, -1, hh, ww).contiguous())
+    return outs
+
+
 # =============================================================================== SAM backbone
 def sam_rel_pos(q_size, k_size, rel_pos):
     """sam_vit.py:359-389 get_rel_pos: (optionally linearly re-interpolated) table gathered at q - k + (k_size-1)."""

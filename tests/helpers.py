@@ -180,6 +180,45 @@ def eva02_state_dict(depth=24, dim=1024):
     return sd
 
 
+def clip_shapes(depth=24, dim=1024, r=32, n_pos=1025):
+    """state_dict key -> shape of LoRABackbone(CLIPVisionTransformer) under 'backbone.' (the fpn layers the reference
+    constructs but never calls are left out)."""
+    s = {}
+    bb = "backbone.model.base_model.model."
+    s[bb + "conv1.weight"] = (dim, 3, 16, 16)
+    s[bb + "class_embedding"] = (dim,)
+    s[bb + "positional_embedding"] = (n_pos, dim)
+    s[bb + "ln_pre.weight"] = (dim,)
+    s[bb + "ln_pre.bias"] = (dim,)
+    for i in range(depth):
+        q = f"{bb}transformer.resblocks.{i}."
+        for n in ("ln_1", "ln_2"):
+            s[q + n + ".weight"] = (dim,)
+            s[q + n + ".bias"] = (dim,)
+        s[q + "attn.in_proj_weight"] = (3 * dim, dim)
+        s[q + "attn.in_proj_bias"] = (3 * dim,)
+        for nm, (o, i_) in (("attn.out_proj", (dim, dim)), ("mlp.c_fc", (4 * dim, dim)), ("mlp.c_proj", (dim, 4 * dim))):
+            s[q + nm + ".base_layer.weight"] = (o, i_)
+            s[q + nm + ".base_layer.bias"] = (o,)
+            s[q + nm + ".lora_A.default.weight"] = (r, i_)
+            s[q + nm + ".lora_B.default.weight"] = (o, r)
+    return s
+
+
+def clip_state_dict(depth=24, dim=1024):
+    """Base weights = synth of the bare-backbone key, LoRA factors = synth of the wrapped key (see eva02_state_dict)."""
+    shapes = clip_shapes(depth, dim)
+    bb = "backbone.model.base_model.model."
+    wrapped = {k[len("backbone."):]: v for k, v in shapes.items()}
+    sd = {"backbone." + k: v for k, v in synth_state_dict(wrapped).items()}
+    bare = {k[len(bb):].replace(".base_layer", ""): v for k, v in shapes.items() if "lora_" not in k}
+    bare_sd = synth_state_dict(bare)
+    for k in list(sd):
+        if "lora_" not in k:
+            sd[k] = bare_sd[k[len(bb):].replace(".base_layer", "")]
+    return sd
+
+
 def sam_shapes(depth=32, dim=1280, heads=16, r=32, grid=32, window=14, global_idx=(7, 15, 23, 31)):
     s = {}
     bb = "backbone.model.base_model.model."

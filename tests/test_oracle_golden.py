@@ -141,6 +141,31 @@ def test_eva02_taps_and_lora_grads(golden_dir):
             assert rel_err(sl(grads[k]), G[name]) < 2e-3, k
 
 
+def test_clip_taps_and_lora_grads(golden_dir):
+    from tests.helpers import clip_state_dict
+    G = _g(golden_dir, "clip.npz")
+    sd = dict(clip_state_dict())
+    tk = [k for k in sd if "lora_" in k]
+    for k in tk:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    taps = R.clip_forward(sd, synth_image(1, 512, seed=51))
+    gen = torch.Generator().manual_seed(7)
+    loss = 0
+    for i, t in enumerate(taps):
+        assert rel_err(sl(t), G[f"tap{i}_slice"]) < TOL
+        np.testing.assert_allclose(stats(t), G[f"tap{i}_stats"], rtol=1e-3, atol=1e-5)
+        loss = loss + (t * torch.randn(t.shape, generator=gen)).sum()
+    grads = dict(zip(tk, torch.autograd.grad(loss, [sd[k] for k in tk], allow_unused=True)))
+    inert = sum(1 for g in grads.values() if g is None or float(g.abs().max()) == 0.0)
+    assert inert == int(G["lora_inert_count"][0])          # the out_proj adapter never enters the graph
+    live = sum(g.double().pow(2).sum().item() for g in grads.values() if g is not None) ** 0.5
+    np.testing.assert_allclose(live, G["lora_live_grad_norm"][0], rtol=1e-3)
+    for name in G.files:
+        if name.startswith("grad_slice::"):
+            k = "backbone." + name.split("::", 1)[1]
+            assert rel_err(sl(grads[k]), G[name]) < 2e-3, k
+
+
 @pytest.mark.slow
 def test_sam_taps(golden_dir):
     from tests.helpers import sam_state_dict

@@ -67,6 +67,13 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
+// CLIP QuickGELU (clip.py:18-20): x * sigmoid(1.702 x) and its derivative
+__device__ __forceinline__ float qgelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float qgelu_grad_f(float x) {
+  const float sg = 1.0f / (1.0f + __expf(-1.702f * x));
+  return sg * (1.0f + 1.702f * x * (1.0f - sg));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -394,7 +394,7 @@ __global__ void k_act_grad_mul(const void* __restrict__ dy, int dy_dt, long ld_d
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long r = i / cols, c = i - r * cols;
     const float p = ld_any(pre, r * ld_pre + c, pre_dt);
-    const float g = act == VFM_ACT_GELU ? gelu_grad_f(p) : (act == VFM_ACT_RELU ? (p > 0.f ? 1.f : 0.f) : 1.f);
+    const float g = act == VFM_ACT_GELU ? gelu_grad_f(p) : (act == VFM_ACT_RELU ? (p > 0.f ? 1.f : 0.f) : (act == VFM_ACT_QGELU ? qgelu_grad_f(p) : 1.f));
     st_any(out, r * ld_out + c, out_dt, ld_any(dy, r * ld_dy + c, dy_dt) * g);
   }
 }

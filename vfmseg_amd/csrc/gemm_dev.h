@@ -54,7 +54,10 @@ __device__ __forceinline__ void epi_store4(const EpiParams& e, long zoff, long m
   } else if (e.ep_mode == VFM_EP_RELU) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) x[i] = fmaxf(x[i], 0.f);
-  } else if (e.ep_mode == VFM_EP_MUL_GELU_GRAD || e.ep_mode == VFM_EP_MUL) {
+  } else if (e.ep_mode == VFM_EP_QGELU) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = qgelu_f(x[i]);
+  } else if (e.ep_mode == VFM_EP_MUL_GELU_GRAD || e.ep_mode == VFM_EP_MUL || e.ep_mode == VFM_EP_MUL_QGELU_GRAD) {
     float a[4];
     const long o = m * e.ld_aux + n;
     if (e.aux_dt == VFM_BF16) {
@@ -65,7 +68,8 @@ __device__ __forceinline__ void epi_store4(const EpiParams& e, long zoff, long m
       a[0] = p.x, a[1] = p.y, a[2] = p.z, a[3] = p.w;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] *= (e.ep_mode == VFM_EP_MUL ? a[i] : gelu_grad_f(a[i]));
+    for (int i = 0; i < 4; ++i)
+      x[i] *= (e.ep_mode == VFM_EP_MUL ? a[i] : (e.ep_mode == VFM_EP_MUL_QGELU_GRAD ? qgelu_grad_f(a[i]) : gelu_grad_f(a[i])));
   }
   if (e.colscale) {
     const float4 s = *reinterpret_cast<const float4*>(e.colscale + n);
@@ -129,7 +133,7 @@ __device__ __forceinline__ void epi_fast(const EpiParams& e, long zoff, f32x16 (
                                          long n_base, long M, long N) {
   constexpr int WN = NI * 32, LD = WN + 4, LPR = WN / 4, RPP = 64 / LPR, PPS = 32 / RPP, NP = MI * PPS, NG = MI / GROUP;
   static_assert(MI % GROUP == 0 && NG <= 4, "slab grouping");
-  constexpr bool AUX = (MODE == VFM_EP_MUL_GELU_GRAD || MODE == VFM_EP_MUL);
+  constexpr bool AUX = (MODE == VFM_EP_MUL_GELU_GRAD || MODE == VFM_EP_MUL || MODE == VFM_EP_MUL_QGELU_GRAD);
   const int fr = lane & 31, fh = lane >> 5;
   const int rr = lane / LPR, cc = (lane % LPR) * 4;
   const long n = n_base + cc;
@@ -196,6 +200,12 @@ __device__ __forceinline__ void epi_fast(const EpiParams& e, long zoff, f32x16 (
       } else if constexpr (MODE == VFM_EP_MUL_GELU_GRAD) {
         x[0] *= gelu_grad_fast(bf16_to_f32(aux[p].x)), x[1] *= gelu_grad_fast(bf16_to_f32(aux[p].y));
         x[2] *= gelu_grad_fast(bf16_to_f32(aux[p].z)), x[3] *= gelu_grad_fast(bf16_to_f32(aux[p].w));
+      } else if constexpr (MODE == VFM_EP_QGELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = qgelu_f(x[i]);
+      } else if constexpr (MODE == VFM_EP_MUL_QGELU_GRAD) {
+        x[0] *= qgelu_grad_f(bf16_to_f32(aux[p].x)), x[1] *= qgelu_grad_f(bf16_to_f32(aux[p].y));
+        x[2] *= qgelu_grad_f(bf16_to_f32(aux[p].z)), x[3] *= qgelu_grad_f(bf16_to_f32(aux[p].w));
       } else if constexpr (MODE == VFM_EP_MUL) {
         x[0] *= bf16_to_f32(aux[p].x), x[1] *= bf16_to_f32(aux[p].y), x[2] *= bf16_to_f32(aux[p].z), x[3] *= bf16_to_f32(aux[p].w);
       }
@@ -271,6 +281,10 @@ __device__ __forceinline__ void epi_wave_tile(const EpiParams& e, long zoff, f32
     epi_fast<VFM_EP_GELU, VFM_BF16, 0, true, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
   else if (mode == VFM_EP_MUL_GELU_GRAD && e.aux_dt == VFM_BF16 && plain && e.c_dt == VFM_BF16)
     epi_fast<VFM_EP_MUL_GELU_GRAD, VFM_BF16, 0, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+  else if (mode == VFM_EP_QGELU && e.C2 && e.c2_dt == VFM_BF16 && !e.residual && e.c_dt == VFM_BF16)
+    epi_fast<VFM_EP_QGELU, VFM_BF16, 0, true, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+  else if (mode == VFM_EP_MUL_QGELU_GRAD && e.aux_dt == VFM_BF16 && plain && e.c_dt == VFM_BF16)
+    epi_fast<VFM_EP_MUL_QGELU_GRAD, VFM_BF16, 0, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
   else
     epi_generic<MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
 }

@@ -34,6 +34,8 @@ __device__ __forceinline__ void epi_store(const EpiParams& e, long zoff, long m,
     case VFM_EP_RELU: v = fmaxf(v, 0.f); break;
     case VFM_EP_MUL_GELU_GRAD: v *= gelu_grad_f(ld_any(e.aux, m * e.ld_aux + n, e.aux_dt)); break;
     case VFM_EP_MUL: v *= ld_any(e.aux, m * e.ld_aux + n, e.aux_dt); break;
+    case VFM_EP_QGELU: v = qgelu_f(v); break;
+    case VFM_EP_MUL_QGELU_GRAD: v *= qgelu_grad_f(ld_any(e.aux, m * e.ld_aux + n, e.aux_dt)); break;
     default: break;
   }
   if (e.colscale) v *= e.colscale[n];

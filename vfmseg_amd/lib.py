@@ -9,8 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvfmseg_hip.so")
 
 F32, BF16, U8, I64 = 0, 1, 2, 3
-EP_NONE, EP_GELU, EP_RELU, EP_MUL_GELU_GRAD, EP_MUL = 0, 1, 2, 3, 4
-ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+EP_NONE, EP_GELU, EP_RELU, EP_MUL_GELU_GRAD, EP_MUL, EP_QGELU, EP_MUL_QGELU_GRAD = 0, 1, 2, 3, 4, 5, 6
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_QGELU = 0, 1, 2, 3
 
 vp, ci, cl, cf, u64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64
 

@@ -7,7 +7,8 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, EP_GELU, EP_MUL, EP_MUL_GELU_GRAD, EP_NONE, EP_RELU, F32  # noqa: F401
+from .lib import (ACT_GELU, ACT_NONE, ACT_QGELU, ACT_RELU, BF16, EP_GELU, EP_MUL, EP_MUL_GELU_GRAD, EP_MUL_QGELU_GRAD,  # noqa: F401
+                  EP_NONE, EP_QGELU, EP_RELU, F32)
 
 _ws_cache = {}
 

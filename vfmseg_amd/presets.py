@@ -169,3 +169,21 @@ def sam_linear(depth=32, checkpoint=None):
         train_cfg=dict(),
         test_cfg=dict(mode="slide", stride=[320, 320], crop_size=[512, 512]),
     )
+
+
+def clip_backbone(layers=24, width=1024, heads=16, input_resolution=512, out_indices=(7, 11, 15, 23)):
+    """configs/_base_/models/lora_clip_ms_masked.py:16-29"""
+    return dict(type="CLIPVisionTransformer", patch_size=16, width=width, output_dim=512, get_embeddings=False, drop_path_rate=0.1,
+                layers=layers, input_resolution=input_resolution, style="pytorch", out_indices=list(out_indices), heads=heads)
+
+
+def clip_lora_cfg(dropout=0.1):
+    """configs/_base_/models/lora_clip_ms_masked.py:31-37"""
+    return dict(r=32, lora_alpha=32, target_modules=["out_proj", "mlp.c_fc", "mlp.c_proj"], lora_dropout=dropout)
+
+
+def clip_ms_masked(layers=24, checkpoint=None, work_dir="work_dirs/tmp"):
+    """configs/_base_/models/lora_clip_ms_masked.py: CLIP ViT-L/16 + LoRA, LinearHead + VFMHead."""
+    cfg = dinov2_ms_masked(work_dir=work_dir)
+    cfg["backbone"] = dict(type="LoRABackbone", backbone=clip_backbone(layers), checkpoint=checkpoint, Lora_config=clip_lora_cfg())
+    return cfg
