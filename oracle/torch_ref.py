@@ -398,6 +398,9 @@ def forward_train(sd, img, label, hr_box, mask_keep, depth=24, heads=16, out_ind
     if backbone == "eva02":
         lr_feats = eva02_forward(sd, lr_img, depth, heads, out_indices)
         hr_feats = eva02_forward(sd, hr_img, depth, heads, out_indices)
+    elif backbone == "clip":
+        lr_feats = clip_forward(sd, lr_img, depth, heads, out_indices)
+        hr_feats = clip_forward(sd, hr_img, depth, heads, out_indices)
     else:
         lr_feats = dinov2_forward(sd, lr_img, depth, heads, out_indices, drop_masks=lora_drop_masks[0])
         hr_feats = dinov2_forward(sd, hr_img, depth, heads, out_indices, drop_masks=lora_drop_masks[1])

@@ -119,6 +119,74 @@ def test_eva02_taps_and_lora_grads(mode, tol, gtol):
         set_compute_dtype("bf16")
 
 
+@pytest.mark.parametrize("mode,tol,gtol", [("f32", 3e-4, 3e-3), ("bf16", 3e-2, 1e-1)])
+def test_clip_taps_and_lora_grads(mode, tol, gtol):
+    """CLIP ViT-L/16 (double class embedding, ln_pre, packed in_proj, QuickGELU, LoRA on mlp.c_fc / mlp.c_proj; the
+    out_proj adapter is inert) vs the CPU oracle, depth 4."""
+    from tests.helpers import clip_state_dict
+    set_compute_dtype(mode)
+    try:
+        sd = clip_state_dict(depth=DEPTH)
+        cfg = dict(type="LoRABackbone", backbone=presets.clip_backbone(layers=DEPTH, out_indices=OUT),
+                   Lora_config=presets.clip_lora_cfg(dropout=0.0))
+        m = MODELS.build(cfg)
+        bsd = {k[len("backbone."):]: v for k, v in sd.items()}
+        missing, unexpected = m.load_state_dict(bsd, strict=False)
+        assert not unexpected and all(".fpn" in k for k in missing), (missing, unexpected)
+        m = m.cuda()
+        img = synth_image(1, 512, seed=53)
+        sdo = dict(sd)
+        tk = [k for k in sd if "mlp.c_" in k and "lora_" in k]
+        for k in tk:
+            sdo[k] = sd[k].clone().requires_grad_(True)
+        taps = R.clip_forward(sdo, img, depth=DEPTH, out_indices=OUT)
+        gen = torch.Generator().manual_seed(8)
+        dts = [torch.randn(t.shape, generator=gen) for t in taps]
+        loss = sum((t * d).sum() for t, d in zip(taps, dts))
+        og = dict(zip(tk, torch.autograd.grad(loss, [sdo[k] for k in tk])))
+        xcat, (hp, wp) = m.forward_tokens([(img.cuda(), None)])
+        v = xcat.float().view(1, 32, 32, 4, 1024)
+        for i, t in enumerate(taps):
+            e = rel_err(v[:, :, :, i].permute(0, 3, 1, 2).cpu(), t.detach())
+            assert e < tol, (i, e)
+        dx = torch.stack([d.permute(0, 2, 3, 1) for d in dts], dim=3).reshape(1024, 4 * 1024).to(xcat.dtype).cuda()
+        xcat.backward(dx)
+        n_live = 0
+        for n, p in m.named_parameters():
+            if "mlp.c_" in n and "lora_" in n:
+                e = rel_err(p.grad.cpu(), og["backbone." + n])
+                assert e < gtol, (n, e)
+                n_live += 1
+            elif "lora_" in n:
+                assert not p.requires_grad and p.grad is None   # the out_proj adapter (SURVEY Q2)
+        assert n_live == 4 * DEPTH
+    finally:
+        set_compute_dtype("bf16")
+
+
+def test_clip_lora_dropout_training_smoke():
+    """bf16 training mode with lora_dropout 0.1: both adapter sites draw masks (fused LN+dropout for c_fc, mask kernel for
+    c_proj); gradients are finite, non-zero, and reproducible for a fixed seed."""
+    from tests.helpers import clip_state_dict
+    set_compute_dtype("bf16")
+    sd = clip_state_dict(depth=2)
+    cfg = dict(type="LoRABackbone", backbone=presets.clip_backbone(layers=2, out_indices=(0, 1)), Lora_config=presets.clip_lora_cfg(0.1))
+    m = MODELS.build(cfg)
+    m.load_state_dict({k[len("backbone."):]: v for k, v in sd.items()}, strict=False)
+    m = m.cuda().train()
+    img = synth_image(2, 512, seed=54).cuda()
+    outs = []
+    for rep in range(2):
+        for p in m.parameters():
+            p.grad = None
+        xcat, _ = m.forward_tokens([(img, None)], seed=77)
+        xcat.backward(torch.ones_like(xcat))
+        g = torch.cat([p.grad.flatten() for n, p in m.named_parameters() if p.requires_grad])
+        assert torch.isfinite(g).all() and g.abs().sum() > 0
+        outs.append((xcat.detach().clone(), g.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7)
+
+
 @pytest.mark.parametrize("mode,tol", [("f32", 3e-4), ("bf16", 4e-2)])
 def test_sam_taps(mode, tol):
     """SAM-ViT-H widths, depth 8 (windowed blocks + 2 global blocks, non-zero rel-pos tables, LoRA on qkv) vs the oracle."""

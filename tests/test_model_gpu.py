@@ -191,6 +191,46 @@ def test_eva02_train_step_matches_oracle():
         set_compute_dtype("bf16")
 
 
+def test_clip_train_step_matches_oracle():
+    """lora_clip_ms_masked.py (CLIP ViT-L/16 + LoRA on mlp.c_fc / mlp.c_proj + LinearHead + VFMHead), depth 4, full
+    forward_train + backward vs the oracle: losses and one gradient per adapter site."""
+    from tests.helpers import clip_state_dict, full_state_dict
+    set_compute_dtype("f32")
+    try:
+        depth, out_idx = 4, [0, 1, 2, 3]
+        cfg = presets.clip_ms_masked(layers=depth)
+        cfg["backbone"]["backbone"]["out_indices"] = out_idx
+        cfg["backbone"]["Lora_config"]["lora_dropout"] = 0.0
+        sd = {k: v for k, v in full_state_dict(depth=1).items() if not k.startswith("backbone.")}
+        sd.update(clip_state_dict(depth=depth))
+        model = MODELS.build(cfg)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not unexpected and all(".fpn" in k for k in missing), (missing, unexpected)
+        model = model.cuda().train()
+        _zero_dropout(model)
+        box = (128, 640, 256, 768)
+        keep = torch.rand(2, 1, 32, 32, generator=torch.Generator().manual_seed(4)) > 0.2
+        model.fixed_crop_box, model.aux_decoder.transformer_decoder.fixed_keep = box, keep
+        img, lab = synth_image(2, 1024, seed=17), synth_label(2, 1024, seed=17)
+        losses = model.loss(img.cuda(), [SegDataSample(gt_sem_seg=lab[i]) for i in range(2)])
+        total, _ = model.parse_losses(losses)
+        total.backward()
+        pre = "backbone.model.base_model.model.transformer.resblocks."
+        keys = [pre + "1.mlp.c_fc.lora_B.default.weight", pre + "2.mlp.c_proj.lora_A.default.weight"]
+        sdo = {k: v.clone() for k, v in sd.items()}
+        for k in keys:
+            sdo[k].requires_grad_(True)
+        lo = R.forward_train(sdo, img, lab, box, keep, depth=depth, out_indices=tuple(out_idx), backbone="clip")
+        ref_g = torch.autograd.grad(R.total_loss(lo), [sdo[k] for k in keys])
+        for k in ("decode_lr.loss_ce", "decode_hr.loss_ce"):
+            assert abs(float(losses[k]) - float(lo[k])) <= 3e-4 * max(1.0, abs(float(lo[k]))), (k, float(losses[k]), float(lo[k]))
+        named = dict(model.named_parameters())
+        for k, g in zip(keys, ref_g):
+            assert rel_err(named[k].grad.cpu(), g) < 5e-3, k
+    finally:
+        set_compute_dtype("bf16")
+
+
 def test_sam_slide_inference_matches_oracle():
     """BASELINE config 5 semantics (lora_sam_linear.py: EncoderDecoder, LoRA SAM + LinearHead, mode='slide', stride 320,
     crop 512 -> 3x3 windows on a 1024^2 image), SAM-H widths at depth 8, fp32 parity mode: logits and argmax mask."""

@@ -5,6 +5,6 @@ Importing the package registers the model classes under the reference's registry
 """
 from .precision import compute_dtype, set_compute_dtype  # noqa: F401
 from .registry import BACKBONES, MODELS, OPTIM_WRAPPER_CONSTRUCTORS  # noqa: F401
-from . import backbones, eva, sam, heads, segmentors, optim, metrics  # noqa: F401,E402
+from . import backbones, eva, sam, clip, heads, segmentors, optim, metrics  # noqa: F401,E402
 
 __version__ = "0.1.0"
