@@ -184,9 +184,23 @@ int vfm_attn_bwd(const vfm_attn_desc* d, void* stream);
  * vfm_sam_attn_merge   : window_unpartition + head merge back to token-major */
 int vfm_sam_relpos_table(const float* rel_pos, int L, int d, int S, float* out, void* stream);
 int vfm_sam_attn_prep(const void* qkv, int dt, long ld, const float* bias, const float* rh, const float* rw, void* q_aug,
-                      void* k_aug, void* v_win, int nimg, int G, int S, int H, int d, int Dq, int NP, float scale, void* stream);
+                      void* k_aug, void* v_win, int nimg, int G, int S, int H, int d, int Dq, int NP,
+                      int rows_per_batch /* of q_aug / k_aug, >= S*S */, float scale, void* stream);
 int vfm_softmax_rows(const float* scores, long ld_s, void* out, int out_dt, long ld_o, long rows, int n, int npad, void* stream);
 int vfm_sam_attn_merge(const void* o_win, int dt, void* out, long ld, int nimg, int G, int S, int H, int d, int NP, void* stream);
+/* Backward of the SAM attention form (sam_vit.py:273-298, :392-430 under autograd).  bwd_prep: window-partitioned, head-dim
+ * zero-padded (dp) operands dO [nb,NP,dp] and its transpose, V [nb,NP,dp], (scale q)^T [nb,dp,NP]; softmax_rows_batched /
+ * softmax_rows_bwd: row softmax and its backward over batches of rows_per_batch rows of which valid_rows are real (the rest
+ * are zero-filled); bwd_merge: dQaug [nb,NP,Dq], dK^T, dV^T [nb,dp,NP] -> token-major dqkv (rel-pos chain rule folded in). */
+int vfm_sam_attn_bwd_prep(const void* dao, long ld_dao, const void* qkv, long ld_qkv, const float* bias, int dt, void* dow,
+                          void* dowT, void* vp, void* qsT, int nimg, int G, int S, int H, int d, int dp, int NP, float scale,
+                          void* stream);
+int vfm_softmax_rows_batched(const float* scores, long ld_s, void* out, int out_dt, long ld_o, long rows, int n, int npad,
+                             int rows_per_batch, int valid_rows, void* stream);
+int vfm_softmax_rows_bwd(const void* p, const float* dp, long ld_dp, void* ds, int dt, long ld_p, long rows, int n, int npad,
+                         int rows_per_batch, int valid_rows, void* stream);
+int vfm_sam_attn_bwd_merge(const void* dqa, const void* dkT, const void* dvT, int dt, const float* rh, const float* rw, void* dqkv,
+                           long ld, int nimg, int G, int S, int H, int d, int dp, int NP, int Dq, float scale, void* stream);
 
 /* ---- ViT input / output ------------------------------------------------------------------------ */
 /* im2col of non-overlapping PxP patches (patch_embed.py:65-77): img fp32 NCHW [B,3,H,W] (crop window y0,x0,

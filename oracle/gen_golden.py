@@ -385,15 +385,29 @@ def gen_sam(_model=None):
         if "lora_" not in k:
             new[k] = sd[k]
     model.load_state_dict(new)
-    model.eval()
+    model.train()                  # LoRABackbone.train(): base stays in eval, lora_dropout = 0 here
     x = synth_image(1, 512, seed=41)
-    with torch.no_grad():
-        taps = model(x)
+    taps = model(x)
     out = {}
+    gen = torch.Generator().manual_seed(9)
+    loss = 0
     for i, t in enumerate(taps):
-        out[f"tap{i}_stats"] = stats(t)
-        out[f"tap{i}_slice"] = sl(t)
-        out[f"tap{i}_tail"] = t[0, -4:, -3:, -5:].numpy().copy()
+        out[f"tap{i}_stats"] = stats(t.detach())
+        out[f"tap{i}_slice"] = sl(t.detach())
+        out[f"tap{i}_tail"] = t.detach()[0, -4:, -3:, -5:].numpy().copy()
+        loss = loss + (t * torch.randn(t.shape, generator=gen)).sum()
+    loss.backward()
+    named = dict(model.named_parameters())
+    pre = "model.base_model.model.blocks."
+    tot = 0.0
+    for k, p_ in named.items():
+        if "lora_" in k:
+            tot += p_.grad.double().pow(2).sum().item()
+    out["lora_grad_norm"] = np.array([tot ** 0.5])
+    for blk in (0, 7, 30, 31):      # windowed (0, 30) and global (7, 31) blocks
+        for ab in ("lora_A", "lora_B"):
+            k = f"{pre}{blk}.attn.qkv.{ab}.default.weight"
+            out["grad_slice::" + k] = sl(named[k].grad)
     np.savez_compressed(os.path.join(GOLD, "sam.npz"), **out)
     print("sam", {k: v[:2] for k, v in out.items() if k.endswith("stats")})
 

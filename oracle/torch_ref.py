@@ -389,7 +389,7 @@ def get_crop_bbox(img_h, img_w, crop_size, divisible=1, rng=np.random):
 
 def forward_train(sd, img, label, hr_box, mask_keep, depth=24, heads=16, out_indices=(7, 11, 15, 23),
                   lora_drop_masks=(None, None), drop2d=(None, None), detail_loss=1.0, bn_out=None, dec_depth=3,
-                  backbone="dinov2"):
+                  backbone="dinov2", backbone_kw=None):
     """MsVFMEncoderDecoder.forward_train (Ms_VFM_encoder_decoder.py:125-200) with the RNG consumers made explicit
     (SURVEY App. B): hr_box = (y1,y2,x1,x2), mask_keep = bool [B,1,32,32], optional dropout multipliers."""
     y1, y2, x1, x2 = hr_box
@@ -401,6 +401,10 @@ def forward_train(sd, img, label, hr_box, mask_keep, depth=24, heads=16, out_ind
     elif backbone == "clip":
         lr_feats = clip_forward(sd, lr_img, depth, heads, out_indices)
         hr_feats = clip_forward(sd, hr_img, depth, heads, out_indices)
+    elif backbone == "sam":
+        kw = dict(depth=depth, heads=heads, out_indices=out_indices, **(backbone_kw or {}))
+        lr_feats = sam_forward(sd, lr_img, **kw)
+        hr_feats = sam_forward(sd, hr_img, **kw)
     else:
         lr_feats = dinov2_forward(sd, lr_img, depth, heads, out_indices, drop_masks=lora_drop_masks[0])
         hr_feats = dinov2_forward(sd, hr_img, depth, heads, out_indices, drop_masks=lora_drop_masks[1])
@@ -458,7 +462,7 @@ def grid_boxes(h_img, w_img, crop=(512, 512), stride=(320, 320)):
 
 def whole_inference(sd, img, out_size, backbone="dinov2", **kw):
     """mmseg whole_inference -> encode_decode -> LinearHead.forward -> predict_by_feat (bilinear to img_shape)."""
-    fwd = {"dinov2": dinov2_forward, "eva02": eva02_forward, "sam": sam_forward}[backbone]
+    fwd = {"dinov2": dinov2_forward, "eva02": eva02_forward, "sam": sam_forward, "clip": clip_forward}[backbone]
     feats = fwd(sd, img, **kw)
     lg = linear_head_forward(sd, feats, training=False)
     return F.interpolate(lg, size=out_size, mode="bilinear", align_corners=False)

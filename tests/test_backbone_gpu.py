@@ -211,3 +211,46 @@ def test_sam_taps(mode, tol):
             assert e < tol, (i, e)
     finally:
         set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("mode,tol,gtol", [("f32", 3e-4, 3e-3), ("bf16", 4e-2, 1.5e-1)])
+def test_sam_training_lora_grads(mode, tol, gtol):
+    """SAM training (lora_sam_ms_masked.py): backward through the windowed / global attention with decomposed rel-pos bias
+    (batched GEMM form) vs autograd of the oracle, SAM-H widths, depth 4 with one global block."""
+    from tests.helpers import sam_state_dict
+    set_compute_dtype(mode)
+    try:
+        depth, gidx, oidx = 4, (2,), (0, 1, 2, 3)
+        sd = sam_state_dict(depth=depth, global_idx=gidx)
+        cfg = dict(type="LoRABackbone", backbone=presets.sam_backbone(depth=depth, global_idx=gidx, out_indices=oidx),
+                   Lora_config=presets.lora_cfg(dropout=0.0))
+        m = MODELS.build(cfg)
+        m.load_state_dict({k[len("backbone."):]: v for k, v in sd.items()}, strict=False)
+        m = m.cuda().train()
+        img = synth_image(1, 512, seed=44)
+        sdo = dict(sd)
+        tk = [k for k in sd if "lora_" in k]
+        for k in tk:
+            sdo[k] = sd[k].clone().requires_grad_(True)
+        taps = R.sam_forward(sdo, img, depth=depth, global_idx=gidx, out_indices=oidx)
+        gen = torch.Generator().manual_seed(10)
+        dts = [torch.randn(t.shape, generator=gen) for t in taps]
+        loss = sum((t * d_).sum() for t, d_ in zip(taps, dts))
+        og = dict(zip(tk, torch.autograd.grad(loss, [sdo[k] for k in tk])))
+        xcat, (hp, wp) = m.forward_tokens([(img.cuda(), None)])
+        D = 1280
+        v = xcat.float().view(1, 32, 32, 4, D)
+        for i, t in enumerate(taps):
+            e = rel_err(v[:, :, :, i].permute(0, 3, 1, 2).cpu(), t.detach())
+            assert e < tol, (i, e)
+        dx = torch.stack([d_.permute(0, 2, 3, 1) for d_ in dts], dim=3).reshape(1024, 4 * D).to(xcat.dtype).cuda()
+        xcat.backward(dx)
+        n = 0
+        for name, p in m.named_parameters():
+            if "lora_" in name:
+                e = rel_err(p.grad.cpu(), og["backbone." + name])
+                assert e < gtol, (name, e)
+                n += 1
+        assert n == 2 * depth
+    finally:
+        set_compute_dtype("bf16")

@@ -231,6 +231,49 @@ def test_clip_train_step_matches_oracle():
         set_compute_dtype("bf16")
 
 
+def test_sam_train_step_matches_oracle():
+    """lora_sam_ms_masked.py (SAM-ViT-H widths + LoRA(qkv) + LinearHead(320) + VFMHead), depth 4 with one global block:
+    full forward_train + backward vs the oracle."""
+    from tests.helpers import sam_state_dict
+    from vfmseg_amd.synth import synth_state_dict
+    set_compute_dtype("f32")
+    try:
+        depth, gidx, oidx = 4, (2,), (0, 1, 2, 3)
+        cfg = presets.sam_ms_masked(depth=depth, global_idx=gidx, out_indices=oidx)
+        cfg["backbone"]["Lora_config"]["lora_dropout"] = 0.0
+        model = MODELS.build(cfg)
+        sd = sam_state_dict(depth=depth, global_idx=gidx)
+        heads = {k: (tuple(v.shape) if v.dtype != torch.int64 else ((), torch.int64)) for k, v in model.state_dict().items()
+                 if k.startswith(("decode_head.", "aux_decoder."))}
+        sd.update(synth_state_dict(heads))
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        model = model.cuda().train()
+        _zero_dropout(model)
+        box = (128, 640, 256, 768)
+        keep = torch.rand(1, 1, 32, 32, generator=torch.Generator().manual_seed(4)) > 0.2
+        model.fixed_crop_box, model.aux_decoder.transformer_decoder.fixed_keep = box, keep
+        img, lab = synth_image(1, 1024, seed=19), synth_label(1, 1024, seed=19)
+        losses = model.loss(img.cuda(), [SegDataSample(gt_sem_seg=lab[0])])
+        total, _ = model.parse_losses(losses)
+        total.backward()
+        pre = "backbone.model.base_model.model.blocks."
+        keys = [pre + "1.attn.qkv.lora_B.default.weight", pre + "2.attn.qkv.lora_A.default.weight"]
+        sdo = {k: v.clone() for k, v in sd.items()}
+        for k in keys:
+            sdo[k].requires_grad_(True)
+        lo = R.forward_train(sdo, img, lab, box, keep, depth=depth, out_indices=oidx, backbone="sam",
+                             backbone_kw=dict(global_idx=gidx))
+        ref_g = torch.autograd.grad(R.total_loss(lo), [sdo[k] for k in keys])
+        for k in ("decode_lr.loss_ce", "decode_hr.loss_ce"):
+            assert abs(float(losses[k]) - float(lo[k])) <= 3e-4 * max(1.0, abs(float(lo[k]))), (k, float(losses[k]), float(lo[k]))
+        named = dict(model.named_parameters())
+        for k, g in zip(keys, ref_g):
+            assert rel_err(named[k].grad.cpu(), g) < 5e-3, k
+    finally:
+        set_compute_dtype("bf16")
+
+
 def test_sam_slide_inference_matches_oracle():
     """BASELINE config 5 semantics (lora_sam_linear.py: EncoderDecoder, LoRA SAM + LinearHead, mode='slide', stride 320,
     crop 512 -> 3x3 windows on a 1024^2 image), SAM-H widths at depth 8, fp32 parity mode: logits and argmax mask."""

@@ -167,16 +167,28 @@ def test_clip_taps_and_lora_grads(golden_dir):
 
 
 @pytest.mark.slow
-def test_sam_taps(golden_dir):
+def test_sam_taps_and_lora_grads(golden_dir):
     from tests.helpers import sam_state_dict
     G = _g(golden_dir, "sam.npz")
-    sd = sam_state_dict()
-    with torch.no_grad():
-        taps = R.sam_forward(sd, synth_image(1, 512, seed=41))
+    sd = dict(sam_state_dict())
+    tk = [k for k in sd if "lora_" in k]
+    for k in tk:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    taps = R.sam_forward(sd, synth_image(1, 512, seed=41))
+    gen = torch.Generator().manual_seed(9)
+    loss = 0
     for i, t in enumerate(taps):
-        assert rel_err(sl(t), G[f"tap{i}_slice"]) < TOL
-        assert rel_err(t[0, -4:, -3:, -5:], G[f"tap{i}_tail"]) < TOL
-        np.testing.assert_allclose(stats(t), G[f"tap{i}_stats"], rtol=1e-3, atol=1e-5)
+        assert rel_err(sl(t.detach()), G[f"tap{i}_slice"]) < TOL
+        assert rel_err(t.detach()[0, -4:, -3:, -5:], G[f"tap{i}_tail"]) < TOL
+        np.testing.assert_allclose(stats(t.detach()), G[f"tap{i}_stats"], rtol=1e-3, atol=1e-5)
+        loss = loss + (t * torch.randn(t.shape, generator=gen)).sum()
+    grads = dict(zip(tk, torch.autograd.grad(loss, [sd[k] for k in tk])))
+    tot = sum(g.double().pow(2).sum().item() for g in grads.values()) ** 0.5
+    np.testing.assert_allclose(tot, G["lora_grad_norm"][0], rtol=1e-3)
+    for name in G.files:
+        if name.startswith("grad_slice::"):
+            k = "backbone." + name.split("::", 1)[1]
+            assert rel_err(sl(grads[k]), G[name]) < 2e-3, k
 
 
 def test_optimizer_rules():

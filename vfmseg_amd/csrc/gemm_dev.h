@@ -279,6 +279,8 @@ __device__ __forceinline__ void epi_wave_tile(const EpiParams& e, long zoff, f32
     epi_fast<VFM_EP_NONE, VFM_F32, 1, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
   else if (mode == VFM_EP_GELU && e.C2 && e.c2_dt == VFM_BF16 && !e.residual && e.c_dt == VFM_BF16)
     epi_fast<VFM_EP_GELU, VFM_BF16, 0, true, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+  else if (mode == VFM_EP_GELU && plain && e.c_dt == VFM_BF16)  // inference: no pre-activation copy
+    epi_fast<VFM_EP_GELU, VFM_BF16, 0, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
   else if (mode == VFM_EP_MUL_GELU_GRAD && e.aux_dt == VFM_BF16 && plain && e.c_dt == VFM_BF16)
     epi_fast<VFM_EP_MUL_GELU_GRAD, VFM_BF16, 0, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
   else if (mode == VFM_EP_QGELU && e.C2 && e.c2_dt == VFM_BF16 && !e.residual && e.c_dt == VFM_BF16)

@@ -46,6 +46,7 @@ struct SamPrepP {
   const float* rh; const float* rw;  // [S,S,d]
   void* qa; void* ka; void* vw;
   int nimg, G, S, nwin_side, H, d, C, Dq, NP;
+  int rpb;  // rows per batch of q_aug / k_aug (>= S*S; rows S*S..rpb-1 are left untouched: the caller zero-fills them)
   float scale;
 };
 __global__ void k_sam_prep(SamPrepP p) {
@@ -93,17 +94,18 @@ __global__ void k_sam_prep(SamPrepP p) {
       qo = 0.f;
       ko = 0.f;
     }
-    st_any(p.qa, idx, p.dt, qo);
-    st_any(p.ka, idx, p.dt, ko);
+    const long oidx = (bz * p.rpb + tok) * p.Dq + j;
+    st_any(p.qa, oidx, p.dt, qo);
+    st_any(p.ka, oidx, p.dt, ko);
   }
 }
 extern "C" int vfm_sam_attn_prep(const void* qkv, int dt, long ld, const float* bias, const float* rh, const float* rw, void* q_aug,
-                                 void* k_aug, void* v_win, int nimg, int G, int S, int H, int d, int Dq, int NP, float scale,
-                                 void* stream) {
-  VFM_CHECK(S > 0 && G > 0 && Dq >= d + 2 * S && NP >= S * S, VFM_E_SHAPE, "vfm_sam_attn_prep: shape");
+                                 void* k_aug, void* v_win, int nimg, int G, int S, int H, int d, int Dq, int NP, int rows_per_batch,
+                                 float scale, void* stream) {
+  VFM_CHECK(S > 0 && G > 0 && Dq >= d + 2 * S && NP >= S * S && rows_per_batch >= S * S, VFM_E_SHAPE, "vfm_sam_attn_prep: shape");
   SamPrepP p;
   p.qkv = qkv; p.dt = dt; p.ld = ld; p.bias = bias; p.rh = rh; p.rw = rw; p.qa = q_aug; p.ka = k_aug; p.vw = v_win;
-  p.nimg = nimg; p.G = G; p.S = S; p.nwin_side = (G + S - 1) / S; p.H = H; p.d = d; p.C = H * d; p.Dq = Dq; p.NP = NP; p.scale = scale;
+  p.nimg = nimg; p.G = G; p.S = S; p.nwin_side = (G + S - 1) / S; p.H = H; p.d = d; p.C = H * d; p.Dq = Dq; p.NP = NP; p.rpb = rows_per_batch; p.scale = scale;
   const long total = (long)nimg * p.nwin_side * p.nwin_side * H * S * S * Dq;
   if (total == 0) return VFM_OK;
   const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
@@ -162,6 +164,172 @@ extern "C" int vfm_sam_attn_merge(const void* o_win, int dt, void* out, long ld,
   if (total == 0) return VFM_OK;
   const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipLaunchKernelGGL(k_sam_merge, dim3(grid), dim3(256), 0, (hipStream_t)stream, o_win, dt, out, ld, nimg, G, S, (G + S - 1) / S, H, d, NP);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------ backward
+// Backward of the same attention form (training with a SAM backbone: lora_sam_ms_masked.py).  With P = softmax(S),
+//   dP = dO V^T,  dS = P o (dP - rowsum(P o dP)),  dV^T = dO^T P,  dK^T = (scale q)^T dS,  dQaug = dS Kaug,
+//   dq = scale dQaug[:d] + sum_kh dQaug[d+kh] Rh[qh,kh,:] + sum_kw dQaug[d+S+kw] Rw[qw,kw,:]
+// every product is a batched MFMA GEMM whose [K,N] operand (P, dS, Kaug) is consumed in place; only the small per-window
+// operands are laid out transposed here.  The head dimension (80) is zero-padded to dp (128) where it is a GEMM K.
+struct SamBwdPrepP {
+  const void* dao; long ld_dao;   // token-major gradient of the attention output [nimg*G*G, >= C]
+  const void* qkv; long ld_qkv;   // token-major qkv [nimg*G*G, 3C]
+  const float* bias;
+  int dt;
+  void* dow; void* dowT; void* vp; void* qsT;   // [nb,NP,dp], [nb,dp,NP], [nb,NP,dp], [nb,dp,NP]
+  int nimg, G, S, nws, H, d, C, dp, NP;
+  float scale;
+};
+__global__ void k_sam_bwd_prep(SamBwdPrepP p) {
+  const int S2 = p.S * p.S, nwin = p.nws * p.nws;
+  const long nb = (long)p.nimg * nwin * p.H;
+  const long total = nb * p.NP * p.dp;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % p.dp);
+    long t = idx / p.dp;
+    const int tok = (int)(t % p.NP);
+    const long bz = t / p.NP;
+    const int h = (int)(bz % p.H);
+    const long iw = bz / p.H;
+    const int win = (int)(iw % nwin), img = (int)(iw / nwin);
+    const int iy = tok / p.S, ix = tok % p.S;
+    const int gy = (win / p.nws) * p.S + iy, gx = (win % p.nws) * p.S + ix;
+    const bool tokv = tok < S2, inside = tokv && gy < p.G && gx < p.G, cv = c < p.d;
+    const long row = ((long)img * p.G + gy) * p.G + gx;
+    float g = 0.f, vv = 0.f, qs = 0.f;
+    if (cv && tokv) {
+      if (inside) {
+        g = ld_any(p.dao, row * p.ld_dao + h * p.d + c, p.dt);
+        vv = ld_any(p.qkv, row * p.ld_qkv + 2 * p.C + h * p.d + c, p.dt);
+        qs = ld_any(p.qkv, row * p.ld_qkv + h * p.d + c, p.dt) * p.scale;
+      } else {  // zero-padded window token: q, k, v = projection bias, no gradient flows back
+        vv = p.bias ? p.bias[2 * p.C + h * p.d + c] : 0.f;
+        qs = (p.bias ? p.bias[h * p.d + c] : 0.f) * p.scale;
+      }
+    }
+    st_any(p.dow, idx, p.dt, g);
+    st_any(p.vp, idx, p.dt, vv);
+    const long tidx = (bz * p.dp + c) * p.NP + tok;
+    st_any(p.dowT, tidx, p.dt, g);
+    st_any(p.qsT, tidx, p.dt, qs);
+  }
+}
+extern "C" int vfm_sam_attn_bwd_prep(const void* dao, long ld_dao, const void* qkv, long ld_qkv, const float* bias, int dt, void* dow,
+                                     void* dowT, void* vp, void* qsT, int nimg, int G, int S, int H, int d, int dp, int NP,
+                                     float scale, void* stream) {
+  VFM_CHECK(S > 0 && G > 0 && dp >= d && NP >= S * S, VFM_E_SHAPE, "vfm_sam_attn_bwd_prep: shape");
+  SamBwdPrepP p;
+  p.dao = dao; p.ld_dao = ld_dao; p.qkv = qkv; p.ld_qkv = ld_qkv; p.bias = bias; p.dt = dt;
+  p.dow = dow; p.dowT = dowT; p.vp = vp; p.qsT = qsT;
+  p.nimg = nimg; p.G = G; p.S = S; p.nws = (G + S - 1) / S; p.H = H; p.d = d; p.C = H * d; p.dp = dp; p.NP = NP; p.scale = scale;
+  const long total = (long)nimg * p.nws * p.nws * H * NP * dp;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_sam_bwd_prep, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// batched row softmax for training: rows are grouped in batches of `rpb` rows of which the first `valid` are real; the
+// others are written as zeros (they are K rows of later transposed-operand GEMMs).  ds != null: softmax BACKWARD instead,
+// ds[r,c] = p[r,c] * (dp[r,c] - sum_j p[r,j] dp[r,j]).
+__global__ void k_softmax_rows_b(const float* __restrict__ s, long ld_s, void* __restrict__ out, int out_dt, long ld_o, long rows,
+                                 int n, int npad, int rpb, int valid, const void* __restrict__ pin, void* __restrict__ ds) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bool live = (int)(row % rpb) < valid;
+  const float* sr = s + row * ld_s;
+  if (!ds) {
+    float m = -INFINITY, z = 1.f;
+    if (live) {
+      for (int c = lane; c < n; c += 64) m = fmaxf(m, sr[c]);
+      m = wave_max(m);
+      z = 0.f;
+      for (int c = lane; c < n; c += 64) z += __expf(sr[c] - m);
+      z = wave_sum(z);
+    }
+    const float inv = 1.f / z;
+    for (int c = lane; c < npad; c += 64) st_any(out, row * ld_o + c, out_dt, (live && c < n) ? __expf(sr[c] - m) * inv : 0.f);
+  } else {
+    float dot = 0.f;
+    if (live) {
+      for (int c = lane; c < n; c += 64) dot += ld_any(pin, row * ld_o + c, out_dt) * sr[c];
+      dot = wave_sum(dot);
+    }
+    for (int c = lane; c < npad; c += 64)
+      st_any(ds, row * ld_o + c, out_dt, (live && c < n) ? ld_any(pin, row * ld_o + c, out_dt) * (sr[c] - dot) : 0.f);
+  }
+}
+extern "C" int vfm_softmax_rows_batched(const float* scores, long ld_s, void* out, int out_dt, long ld_o, long rows, int n, int npad,
+                                        int rows_per_batch, int valid_rows, void* stream) {
+  VFM_CHECK(npad >= n && ld_o >= npad && ld_s >= n && rows_per_batch >= valid_rows && valid_rows > 0, VFM_E_SHAPE, "vfm_softmax_rows_batched: shape");
+  if (rows == 0) return VFM_OK;
+  hipLaunchKernelGGL(k_softmax_rows_b, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, scores, ld_s, out, out_dt, ld_o, rows, n,
+                     npad, rows_per_batch, valid_rows, (const void*)nullptr, (void*)nullptr);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+extern "C" int vfm_softmax_rows_bwd(const void* p, const float* dp, long ld_dp, void* ds, int dt, long ld_p, long rows, int n, int npad,
+                                    int rows_per_batch, int valid_rows, void* stream) {
+  VFM_CHECK(npad >= n && ld_p >= npad && ld_dp >= n && rows_per_batch >= valid_rows && valid_rows > 0, VFM_E_SHAPE, "vfm_softmax_rows_bwd: shape");
+  if (rows == 0) return VFM_OK;
+  hipLaunchKernelGGL(k_softmax_rows_b, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, dp, ld_dp, (void*)nullptr, dt, ld_p, rows, n,
+                     npad, rows_per_batch, valid_rows, p, ds);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// dQaug [nb, NP, Dq] (fp32 or bf16), dkT / dvT [nb, dp, NP] -> token-major dqkv [nimg*G*G, 3C] (padded tokens dropped)
+struct SamBwdMergeP {
+  const void* dqa; const void* dkT; const void* dvT; int dt;
+  const float* rh; const float* rw;
+  void* dqkv; long ld;
+  int nimg, G, S, nws, H, d, C, dp, NP, Dq;
+  float scale;
+};
+__global__ void k_sam_bwd_merge(SamBwdMergeP p) {
+  const long total = (long)p.nimg * p.G * p.G * p.H * p.d;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % p.d);
+    long t = idx / p.d;
+    const int h = (int)(t % p.H);
+    t /= p.H;
+    const int gx = (int)(t % p.G);
+    t /= p.G;
+    const int gy = (int)(t % p.G);
+    const int img = (int)(t / p.G);
+    const int iy = gy % p.S, ix = gx % p.S;
+    const int win = (gy / p.S) * p.nws + gx / p.S, tok = iy * p.S + ix;
+    const long bz = ((long)img * p.nws * p.nws + win) * p.H + h;
+    const long qrow = (bz * p.NP + tok) * p.Dq;
+    float dq = ld_any(p.dqa, qrow + c, p.dt) * p.scale;
+    const float* rh = p.rh + (long)iy * p.S * p.d + c;
+    const float* rw = p.rw + (long)ix * p.S * p.d + c;
+    for (int k = 0; k < p.S; ++k) {
+      dq += ld_any(p.dqa, qrow + p.d + k, p.dt) * rh[(long)k * p.d];
+      dq += ld_any(p.dqa, qrow + p.d + p.S + k, p.dt) * rw[(long)k * p.d];
+    }
+    const long tidx = (bz * p.dp + c) * p.NP + tok;
+    const long row = ((long)img * p.G + gy) * p.G + gx;
+    st_any(p.dqkv, row * p.ld + h * p.d + c, p.dt, dq);
+    st_any(p.dqkv, row * p.ld + p.C + h * p.d + c, p.dt, ld_any(p.dkT, tidx, p.dt));
+    st_any(p.dqkv, row * p.ld + 2 * p.C + h * p.d + c, p.dt, ld_any(p.dvT, tidx, p.dt));
+  }
+}
+extern "C" int vfm_sam_attn_bwd_merge(const void* dqa, const void* dkT, const void* dvT, int dt, const float* rh, const float* rw,
+                                      void* dqkv, long ld, int nimg, int G, int S, int H, int d, int dp, int NP, int Dq, float scale,
+                                      void* stream) {
+  SamBwdMergeP p;
+  p.dqa = dqa; p.dkT = dkT; p.dvT = dvT; p.dt = dt; p.rh = rh; p.rw = rw; p.dqkv = dqkv; p.ld = ld;
+  p.nimg = nimg; p.G = G; p.S = S; p.nws = (G + S - 1) / S; p.H = H; p.d = d; p.C = H * d; p.dp = dp; p.NP = NP; p.Dq = Dq; p.scale = scale;
+  const long total = (long)nimg * G * G * H * d;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_sam_bwd_merge, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }

@@ -81,9 +81,13 @@ SIGNATURES = {
     "vfm_attn_fwd": [C.POINTER(AttnDesc), vp],
     "vfm_attn_bwd": [C.POINTER(AttnDesc), vp],
     "vfm_sam_relpos_table": [vp, ci, ci, ci, vp, vp],
-    "vfm_sam_attn_prep": [vp, ci, cl, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, vp],
+    "vfm_sam_attn_prep": [vp, ci, cl, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp],
     "vfm_softmax_rows": [vp, cl, vp, ci, cl, cl, ci, ci, vp],
     "vfm_sam_attn_merge": [vp, ci, vp, cl, ci, ci, ci, ci, ci, ci, vp],
+    "vfm_sam_attn_bwd_prep": [vp, cl, vp, cl, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, cf, vp],
+    "vfm_softmax_rows_batched": [vp, cl, vp, ci, cl, cl, ci, ci, ci, ci, vp],
+    "vfm_softmax_rows_bwd": [vp, vp, cl, vp, ci, cl, cl, ci, ci, ci, ci, vp],
+    "vfm_sam_attn_bwd_merge": [vp, vp, vp, ci, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp],
     "vfm_patchify": [vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, ci, cl, ci, vp],
     "vfm_assemble_tokens": [vp, vp, vp, vp, ci, ci, ci, vp],
     "vfm_resize_bilinear": [vp, ci, ci, ci, ci, ci, ci, cl, vp, ci, ci, cl, ci, ci, ci, ci, ci, ci, vp],

@@ -412,8 +412,38 @@ def sam_relpos_table(rel_pos, S, out):
 def sam_attn_prep(qkv, bias, rh, rw, q_aug, k_aug, v_win, nimg, G, S, H, d, scale):
     lib = L.load()
     L.check(lib.vfm_sam_attn_prep(L.ptr(qkv), L.dt_of(qkv), _ld(qkv), L.ptr(bias), L.ptr(rh), L.ptr(rw), L.ptr(q_aug),
-                                  L.ptr(k_aug), L.ptr(v_win), nimg, G, S, H, d, q_aug.shape[-1], v_win.shape[1], float(scale),
-                                  L.stream()), "vfm_sam_attn_prep")
+                                  L.ptr(k_aug), L.ptr(v_win), nimg, G, S, H, d, q_aug.shape[-1], v_win.shape[1], q_aug.shape[1],
+                                  float(scale), L.stream()), "vfm_sam_attn_prep")
+
+
+def sam_attn_bwd_prep(dao, qkv, bias, dow, dowT, vp, qsT, nimg, G, S, H, d, scale):
+    """dO / V window-partitioned with the head dim zero-padded, dO^T and (scale q)^T: the small operands of the backward GEMMs."""
+    lib = L.load()
+    L.check(lib.vfm_sam_attn_bwd_prep(L.ptr(dao), _ld(dao), L.ptr(qkv), _ld(qkv), L.ptr(bias), L.dt_of(qkv), L.ptr(dow), L.ptr(dowT),
+                                      L.ptr(vp), L.ptr(qsT), nimg, G, S, H, d, dow.shape[-1], dow.shape[1], float(scale), L.stream()),
+            "vfm_sam_attn_bwd_prep")
+
+
+def softmax_rows_batched(scores, out, n, rows_per_batch, valid_rows):
+    lib = L.load()
+    L.check(lib.vfm_softmax_rows_batched(L.ptr(scores), _ld(scores), L.ptr(out), L.dt_of(out), _ld(out), scores.shape[0], n, out.shape[1],
+                                         rows_per_batch, valid_rows, L.stream()), "vfm_softmax_rows_batched")
+    return out
+
+
+def softmax_rows_bwd(p, dp, ds, n, rows_per_batch, valid_rows):
+    lib = L.load()
+    L.check(lib.vfm_softmax_rows_bwd(L.ptr(p), L.ptr(dp), _ld(dp), L.ptr(ds), L.dt_of(p), _ld(p), p.shape[0], n, p.shape[1], rows_per_batch,
+                                     valid_rows, L.stream()), "vfm_softmax_rows_bwd")
+    return ds
+
+
+def sam_attn_bwd_merge(dqa, dkT, dvT, rh, rw, dqkv, nimg, G, S, H, d, scale):
+    lib = L.load()
+    L.check(lib.vfm_sam_attn_bwd_merge(L.ptr(dqa), L.ptr(dkT), L.ptr(dvT), L.dt_of(dqa), L.ptr(rh), L.ptr(rw), L.ptr(dqkv), _ld(dqkv), nimg,
+                                       G, S, H, d, dkT.shape[1], dkT.shape[2], dqa.shape[-1], float(scale), L.stream()),
+            "vfm_sam_attn_bwd_merge")
+    return dqkv
 
 
 def softmax_rows(scores2d, out2d, n):

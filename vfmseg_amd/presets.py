@@ -187,3 +187,14 @@ def clip_ms_masked(layers=24, checkpoint=None, work_dir="work_dirs/tmp"):
     cfg = dinov2_ms_masked(work_dir=work_dir)
     cfg["backbone"] = dict(type="LoRABackbone", backbone=clip_backbone(layers), checkpoint=checkpoint, Lora_config=clip_lora_cfg())
     return cfg
+
+
+def sam_ms_masked(depth=32, checkpoint=None, work_dir="work_dirs/tmp", global_idx=(7, 15, 23, 31), out_indices=(7, 15, 23, 31)):
+    """configs/_base_/models/lora_sam_ms_masked.py: SAM-ViT-H + LoRA(qkv), LinearHead(320) + VFMHead on 1280-wide taps."""
+    cfg = dinov2_ms_masked(work_dir=work_dir)
+    cfg["backbone"] = dict(type="LoRABackbone", backbone=sam_backbone(depth, global_idx=global_idx, out_indices=out_indices),
+                           checkpoint=checkpoint, Lora_config=lora_cfg())
+    cfg["decode_head"] = dict(linear_head(1280, 320), in_channels=[1280] * 4)
+    cfg["aux_head"] = dict(vfm_head(1280), in_channels=[1280] * 4)
+    cfg["test_cfg"] = dict(mode="hr_slide_inference", stride=[320, 320], crop_size=[512, 512])   # fixed 512^2 grid (SURVEY Q3)
+    return cfg

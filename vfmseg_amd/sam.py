@@ -6,13 +6,15 @@ NHWC tokens without a cls token: the residual stream is the matrix [n*G*G, 1280]
 k/v equal the projection bias, as in the reference), 4 blocks attend globally; every block adds the decomposed
 relative-position bias.  The bias is folded into augmented Q/K operands (see csrc/sam.hip), which turns the biased
 attention into batched MFMA GEMMs + a row softmax; LoRA is merged into the QKV GEMM by K-concatenation as for DINOv2.
-Training (backward through this attention form) is a later-round item: forward_tokens(training=True) raises.
+Training (lora_sam_ms_masked.py) differentiates the same form: dP = dO V^T, the row-softmax backward, dV^T = dO^T P,
+dK^T = (scale q)^T dS and dQaug = dS Kaug are batched GEMMs whose large operand (P, dS, Kaug) is consumed in place as the
+[K, N] operand; the rel-pos chain rule is folded into the final scatter back to token-major dqkv (csrc/sam.hip).
 """
 import torch
 import torch.nn as nn
 
 from . import ops
-from .backbones import R_PAD, LoraLinear, Packed, _BackboneFn, _Lin, _PatchEmbed, _pack_at
+from .backbones import BACKWARD_EVENTS, R_PAD, LoraLinear, Packed, _BackboneFn, _Lin, _PatchEmbed, _pack_at, _wgrad_small_t
 from .precision import compute_dtype
 from .registry import MODELS
 
@@ -137,6 +139,7 @@ class SamEngine:
                 )
                 if isinstance(qkv, LoraLinear):
                     Lp["a"] = torch.zeros(R_PAD, D, dtype=cd, device=dev)
+                    Lp["at"] = torch.zeros(D, R_PAD, dtype=cd, device=dev)
                 P["layers"].append(Lp)
         self._packed = P
         return P
@@ -147,11 +150,16 @@ class SamEngine:
             for blk, Lp in zip(self.vit.blocks, P["layers"]):
                 q = blk.attn.qkv
                 if isinstance(q, LoraLinear):
-                    ops.cast(q.lora_A["default"].weight.detach(), Lp["a"][:q.r])
-                    ops.cast(q.lora_B["default"].weight.detach(), Lp["qkv"].w[:, D:D + q.r])
+                    A, Bm = q.lora_A["default"].weight.detach(), q.lora_B["default"].weight.detach()
+                    ops.cast(A, Lp["a"][:q.r])
+                    _pack_at(A, Lp["at"], q.r)
+                    ops.cast(Bm, Lp["qkv"].w[:, D:D + q.r])
+                    if Lp["qkv"].wt is not None:
+                        ops.transpose(Bm, Lp["qkv"].wt[D:D + q.r], pad_rows=Bm.shape[0])
 
-    def attention(self, qkv, Lp, nimg, G, H, d, cd, dev):
-        """-> token-major attention output [nimg*G*G, H*d]"""
+    def attention(self, qkv, Lp, nimg, G, H, d, cd, dev, keep=False):
+        """-> token-major attention output [nimg*G*G, H*d] (+ the probabilities [nb, NP, NP] when keep=True: rows / columns
+        beyond the S*S window tokens are zero, so P can later serve in place as a [K, N] GEMM operand)"""
         S = Lp["S"]
         nws = (G + S - 1) // S
         nb, Nw = nimg * nws * nws * H, S * S
@@ -160,25 +168,63 @@ class SamEngine:
         ka = torch.empty(nb, Nw, Dq, dtype=cd, device=dev)
         vw = torch.zeros(nb, NP, d, dtype=cd, device=dev)
         ops.sam_attn_prep(qkv, Lp["qkv_b"], Lp["rh"], Lp["rw"], qa, ka, vw, nimg, G, S, H, d, d ** -0.5)
-        sc = torch.empty(nb, Nw, Nw, dtype=torch.float32, device=dev)
-        ops.gemm(qa, ka, sc)                                        # batched: scores incl. the decomposed rel-pos bias
-        pr = torch.empty(nb, Nw, NP, dtype=cd, device=dev)
-        ops.softmax_rows(sc.view(nb * Nw, Nw), pr.view(nb * Nw, NP), Nw)
+        if not keep:
+            sc = torch.empty(nb, Nw, Nw, dtype=torch.float32, device=dev)
+            ops.gemm(qa, ka, sc)                                    # batched: scores incl. the decomposed rel-pos bias
+            pr = torch.empty(nb, Nw, NP, dtype=cd, device=dev)
+            ops.softmax_rows(sc.view(nb * Nw, Nw), pr.view(nb * Nw, NP), Nw)
+            pa = pr
+        else:
+            sc = torch.empty(nb, NP, NP, dtype=torch.float32, device=dev)
+            ops.gemm(qa, ka, sc[:, :Nw, :Nw])
+            pr = torch.empty(nb, NP, NP, dtype=cd, device=dev)
+            ops.softmax_rows_batched(sc.view(nb * NP, NP), pr.view(nb * NP, NP), Nw, NP, Nw)
+            pa = pr[:, :Nw]
         ow = torch.empty(nb, NP, d, dtype=cd, device=dev)
-        ops.gemm(pr, vw, ow[:, :Nw], trans_b=True)                  # P @ V, V consumed in place as the [K, N] operand
+        ops.gemm(pa, vw, ow[:, :Nw], trans_b=True)                  # P @ V, V consumed in place as the [K, N] operand
         ao = torch.empty(nimg * G * G, H * d, dtype=cd, device=dev)
         ops.sam_attn_merge(ow, ao, nimg, G, S, H, d)
-        return ao
+        return (ao, pr) if keep else ao
+
+    def attention_bwd(self, dao, qkv, pr, Lp, nimg, G, H, d, cd, dev):
+        """d(attention output) [M, H*d] -> dqkv [M, 3*H*d]; pr = the probabilities kept by attention(keep=True)."""
+        S = Lp["S"]
+        nws = (G + S - 1) // S
+        nb, Nw = nimg * nws * nws * H, S * S
+        Dq, NP, dp = _pad64(d + 2 * S), _pad64(Nw), _pad64(d)
+        scale = d ** -0.5
+        dow = torch.empty(nb, NP, dp, dtype=cd, device=dev)
+        vp = torch.empty(nb, NP, dp, dtype=cd, device=dev)
+        dowT = torch.empty(nb, dp, NP, dtype=cd, device=dev)
+        qsT = torch.empty(nb, dp, NP, dtype=cd, device=dev)
+        ops.sam_attn_bwd_prep(dao, qkv, Lp["qkv_b"], dow, dowT, vp, qsT, nimg, G, S, H, d, scale)
+        dP = torch.empty(nb, NP, NP, dtype=torch.float32, device=dev)
+        ops.gemm(dow[:, :Nw], vp, dP[:, :Nw])                       # dP = dO V^T (rows of padded tokens are never read)
+        dS = torch.empty(nb, NP, NP, dtype=cd, device=dev)
+        ops.softmax_rows_bwd(pr.view(nb * NP, NP), dP.view(nb * NP, NP), dS.view(nb * NP, NP), Nw, NP, Nw)
+        del dP
+        dvT = torch.empty(nb, dp, NP, dtype=cd, device=dev)
+        dkT = torch.empty(nb, dp, NP, dtype=cd, device=dev)
+        ops.gemm(dowT, pr, dvT, trans_b=True)                       # dV^T = dO^T P
+        ops.gemm(qsT, dS, dkT, trans_b=True)                        # dK^T = (scale q)^T dS
+        qa = torch.empty(nb, NP, Dq, dtype=cd, device=dev)          # recomputed augmented operands, NP rows per batch
+        ka = torch.zeros(nb, NP, Dq, dtype=cd, device=dev)
+        vw = torch.empty(nb, NP, d, dtype=cd, device=dev)
+        ops.sam_attn_prep(qkv, Lp["qkv_b"], Lp["rh"], Lp["rw"], qa, ka, vw, nimg, G, S, H, d, scale)
+        dqa = torch.empty(nb, NP, Dq, dtype=cd, device=dev)
+        ops.gemm(dS, ka, dqa, trans_b=True)                         # dQaug = dS Kaug
+        dqkv = torch.empty(nimg * G * G, 3 * H * d, dtype=cd, device=dev)
+        ops.sam_attn_bwd_merge(dqa, dkT, dvT, Lp["rh"], Lp["rw"], dqkv, nimg, G, S, H, d, scale)
+        return dqkv
 
     def forward(self, jobs, training, seed):
-        if training:
-            raise NotImplementedError("SAM backward is not on the HIP path yet (round 1 ships SAM inference, config 5)")
         v, P = self.vit, self.packed()
         cd, dev = P["cd"], P["dev"]
         D, H, ps = v.embed_dim, v.num_heads, v.patch_size
         d = D // H
         G = v.img_size // ps
-        if self.lora_on():
+        lora = self.lora_on()
+        if lora:
             self.refresh_lora(P)
         for img, box in jobs:
             y0, y1, x0, x1 = box if box is not None else (0, img.shape[2], 0, img.shape[3])
@@ -197,28 +243,114 @@ class SamEngine:
         P["pe"].fwd(A0, x, bias=P["pe_b"], residual=posb)
         nt = len(v.out_indices)
         xcat = torch.empty(M, nt * D, dtype=cd, device=dev)
+        keep = bool(training) and lora            # activations for the hand-written backward
+        saved = []
         for li, (blk, Lp) in enumerate(zip(v.blocks, P["layers"])):
             kq = Lp["qkv"].k
+            S_ = {"x_in": x}
             a1 = torch.empty(M, kq, dtype=cd, device=dev)
-            ops.layernorm_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], None)
+            st1 = torch.empty(M, 2, dtype=torch.float32, device=dev) if keep else None
+            xd = mask = None
+            q = blk.attn.qkv if lora else None
+            if keep and q.p > 0 and cd == torch.bfloat16 and D % 256 == 0:
+                mask = torch.empty(M, D, dtype=cd, device=dev)
+                xd = torch.empty(M, D, dtype=cd, device=dev)
+                ops.layernorm_dropout_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1, xd, mask, q.p, seed, offset=li * M * D)
+            else:
+                ops.layernorm_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1)
+                if keep and q.p > 0:
+                    mask = torch.empty(M, D, dtype=cd, device=dev)
+                    ops.dropout_mask(mask, q.p, seed, offset=li * M * D)
+                    xd = torch.empty(M, D, dtype=cd, device=dev)
+                    ops.mul_mask(a1[:, :D], mask, xd)
             if kq > D:
-                ops.gemm(a1[:, :D], Lp["a"], a1[:, D:D + R_PAD], alpha=blk.attn.qkv.scaling)
+                ops.gemm(xd if xd is not None else a1[:, :D], Lp["a"], a1[:, D:D + R_PAD], alpha=blk.attn.qkv.scaling)
             qkv = torch.empty(M, 3 * D, dtype=cd, device=dev)
             Lp["qkv"].fwd(a1, qkv, bias=Lp["qkv_b"])
-            ao = self.attention(qkv, Lp, nimg, G, H, d, cd, dev)
+            if keep:
+                ao, pr = self.attention(qkv, Lp, nimg, G, H, d, cd, dev, keep=True)
+            else:
+                ao, pr = self.attention(qkv, Lp, nimg, G, H, d, cd, dev), None
             xm = torch.empty(M, D, dtype=torch.float32, device=dev)
             Lp["proj"].fwd(ao, xm, bias=Lp["proj_b"], residual=x)
             a2 = torch.empty(M, D, dtype=cd, device=dev)
-            ops.layernorm_fwd(xm, Lp["n2w"], Lp["n2b"], 1e-6, a2, None)
-            g = torch.empty(M, Lp["fc1"].n, dtype=cd, device=dev)
-            Lp["fc1"].fwd(a2, g, bias=Lp["fc1_b"], ep_mode=ops.EP_GELU)
+            st2 = torch.empty(M, 2, dtype=torch.float32, device=dev) if keep else None
+            ops.layernorm_fwd(xm, Lp["n2w"], Lp["n2b"], 1e-6, a2, st2)
+            hid = Lp["fc1"].n
+            g = ops.empty_ld(M, hid, cd, dev)
+            hpre = torch.empty(M, hid, dtype=cd, device=dev) if keep else None
+            Lp["fc1"].fwd(a2, g, bias=Lp["fc1_b"], ep_mode=ops.EP_GELU, c2=hpre)
             xo = torch.empty(M, D, dtype=torch.float32, device=dev)
             Lp["fc2"].fwd(g, xo, bias=Lp["fc2_b"], residual=xm)
+            if keep:
+                S_.update(a1=a1, st1=st1, qkv=qkv, pr=pr, x_mid=xm, st2=st2, hpre=hpre, xd=xd, mask=mask)
+                saved.append(S_)
             x = xo
             if li in v.out_indices:
                 i = v.out_indices.index(li)
                 ops.cast(x, xcat[:, i * D:(i + 1) * D])
-        return xcat, (G, G), dict(saved=None)
+        return xcat, (G, G), dict(saved=saved if keep else None, nimg=nimg, M=M, P=P, G=G)
 
+    # ---- backward: d(xcat) -> LoRA grads [dA0, dB0, dA1, dB1, ...]
     def backward(self, ctx, dxcat):
-        raise NotImplementedError("SAM backward is not on the HIP path yet")
+        from .functional import direct_grad_target
+        v, P = self.vit, ctx["P"]
+        cd, dev = P["cd"], P["dev"]
+        D, H = v.embed_dim, v.num_heads
+        d = D // H
+        M, nimg, G = ctx["M"], ctx["nimg"], ctx["G"]
+        dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
+        grads = [None] * (2 * len(v.blocks))
+        t = torch.empty(M, D, dtype=cd, device=dev)
+        for li in range(len(v.blocks) - 1, -1, -1):
+            blk, Lp, S_ = v.blocks[li], P["layers"][li], ctx["saved"][li]
+            q = blk.attn.qkv
+            if li in v.out_indices:
+                i = v.out_indices.index(li)
+                src = dxcat[:, i * D:(i + 1) * D]
+                ops.strided_copy(src, dx, (M, D), (src.stride(0), 1), (D, 1), accumulate=True)
+            # ---- MLP branch: x_out = x_mid + lin2(gelu(lin1(LN2(x_mid))))
+            ops.cast(dx, t)
+            hid = Lp["fc1"].n
+            dh = ops.empty_ld(M, hid, cd, dev)
+            Lp["fc2"].dgrad(t, dh, ep_mode=ops.EP_MUL_GELU_GRAD, aux=S_["hpre"])
+            dn = torch.empty(M, D, dtype=cd, device=dev)
+            Lp["fc1"].dgrad(dh, dn)
+            ops.layernorm_bwd(dn, S_["x_mid"], Lp["n2w"], S_["st2"], dx, accumulate_dx=True)
+            del dh, dn
+            # ---- attention branch: x_mid = x_in + proj(attn(qkv(LN1(x_in))))
+            ops.cast(dx, t)
+            dao = torch.empty(M, D, dtype=cd, device=dev)
+            Lp["proj"].dgrad(t, dao)
+            dqkv = self.attention_bwd(dao, S_["qkv"], S_["pr"], Lp, nimg, G, H, d, cd, dev)
+            kq = Lp["qkv"].k
+            da1 = torch.empty(M, kq, dtype=cd, device=dev)
+            Lp["qkv"].dgrad(dqkv, da1)
+            r = q.r
+            A, Bm = q.lora_A["default"].weight, q.lora_B["default"].weight
+            a1 = S_["a1"]
+            xd = S_["xd"] if S_["xd"] is not None else a1[:, :D]
+            tB, tA = direct_grad_target(Bm), direct_grad_target(A)
+            gBt = torch.empty(R_PAD, Bm.shape[0], dtype=torch.float32, device=dev)
+            gAp = torch.empty(R_PAD, A.shape[1], dtype=torch.float32, device=dev)
+            doneB = _wgrad_small_t(a1[:, D:D + R_PAD], dqkv, gBt, scatter=None if tB is None else (tB, r, 1, r))
+            doneA = _wgrad_small_t(da1[:, D:D + R_PAD], xd, gAp, alpha=q.scaling, scatter=None if tA is None else (tA, r, A.shape[1], 1))
+            if doneB is not True:
+                if tB is not None:
+                    ops.strided_copy(gBt, tB, (Bm.shape[0], r), (1, gBt.stride(0)), (r, 1), accumulate=True)
+                else:
+                    gB = torch.empty_like(Bm, dtype=torch.float32)
+                    ops.strided_copy(gBt, gB, (Bm.shape[0], r), (1, gBt.stride(0)), (r, 1))
+                    grads[2 * li + 1] = gB
+            if doneA is not True:
+                if tA is not None:
+                    ops.axpby(gAp[:r].reshape(-1), 1.0, tA.view(-1), 1.0)
+                else:
+                    grads[2 * li] = gAp[:r]
+            ep = dict(ep_mode=ops.EP_MUL, aux=S_["mask"]) if S_["mask"] is not None else {}
+            ops.gemm(da1[:, D:D + R_PAD], Lp["at"], da1[:, :D], alpha=q.scaling, residual=da1[:, :D], **ep)
+            ops.layernorm_bwd(da1[:, :D], S_["x_in"], Lp["n1w"], S_["st1"], dx, accumulate_dx=True)
+            ctx["saved"][li] = None
+            if BACKWARD_EVENTS["block_done"] is not None:
+                BACKWARD_EVENTS["block_done"](li)
+        return grads
