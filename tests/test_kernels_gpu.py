@@ -478,3 +478,31 @@ def test_adamw():
         opt.step()
         ops.adamw(pd, (g * step).to(DEV), m, v, seg, lrm, wd, 1e-3, (0.9, 0.999), 1e-8, step)
     assert relerr(pd, q.detach()) < 1e-5
+
+
+def test_checkpoint_converters():
+    """vfmseg_amd.convert (HIP resize kernels) vs the F.interpolate calls of the reference's tools/convert_models/*."""
+    from vfmseg_amd import convert
+    g = torch.Generator().manual_seed(90)
+    D = 64
+    sd = {"patch_embed.proj.weight": torch.randn(D, 3, 14, 14, generator=g), "pos_embed": torch.randn(1, 1 + 37 * 37, D, generator=g),
+          "blocks.0.attn.rope.freqs_cos": torch.zeros(4)}
+    ref_k = F.interpolate(sd["patch_embed.proj.weight"], size=(16, 16), mode="bicubic", align_corners=False)
+    ref_p = F.interpolate(sd["pos_embed"][:, 1:].reshape(1, 37, 37, D).permute(0, 3, 1, 2), size=(32, 32), mode="bicubic",
+                          align_corners=False).permute(0, 2, 3, 1).reshape(1, 1024, D)
+    out = convert.convert_dinov2(sd)
+    assert relerr(out["patch_embed.proj.weight"], ref_k) < 1e-5
+    assert relerr(out["pos_embed"][:, 1:], ref_p) < 1e-5 and torch.equal(out["pos_embed"][:, :1], sd["pos_embed"][:, :1])
+    out = convert.convert_eva02(dict(model=sd))
+    assert "blocks.0.attn.rope.freqs_cos" not in out and relerr(out["pos_embed"][:, 1:], ref_p) < 1e-5
+    sam = {"image_encoder.patch_embed.proj.weight": sd["patch_embed.proj.weight"], "image_encoder.pos_embed": torch.randn(1, 64, 64, D, generator=g),
+           "mask_decoder.x": torch.zeros(1)}
+    out = convert.convert_sam(sam)
+    ref_s = F.interpolate(sam["image_encoder.pos_embed"].permute(0, 3, 1, 2), size=(32, 32), mode="bicubic", align_corners=False).permute(0, 2, 3, 1)
+    assert set(out) == {"patch_embed.proj.weight", "pos_embed"} and relerr(out["pos_embed"], ref_s) < 1e-5
+    clip = {"visual.conv1.weight": sd["patch_embed.proj.weight"], "visual.positional_embedding": torch.randn(1 + 16 * 16, D, generator=g),
+            "transformer.x": torch.zeros(1)}
+    out = convert.convert_clip(clip, 512, 16, D)
+    ref_c = F.interpolate(clip["visual.positional_embedding"][1:].reshape(1, 16, 16, D).permute(0, 3, 1, 2), size=(32, 32),
+                          mode="bilinear").reshape(D, 1024).permute(1, 0)
+    assert relerr(out["positional_embedding"][1:], ref_c) < 1e-5 and relerr(out["conv1.weight"], ref_k) < 1e-5
