@@ -243,6 +243,10 @@ int vfm_upsample_ce(const float* logits_low, const int64_t* label, int B, int h,
 int vfm_reduce_sum(const float* x, long n, float scale, float* out, void* stream);
 
 /* ---- inference helpers --------------------------------------------------------------------------- */
+/* mmseg SegDataPreProcessor (lora_dinov2_ms_masked.py:4-12) for one decoded uint8 CHW image (device memory): BGR->RGB,
+ * (x - mean[c]) / std[c] (mean3 / std3: host arrays of 3, given in the OUTPUT channel order), right/bottom padding with pad_val. */
+int vfm_preprocess_u8(const uint8_t* img, int H, int W, float* out, int Hp, int Wp, const float* mean3, const float* std3,
+                      int bgr_to_rgb, float pad_val, void* stream);
 /* confidence gate (Ms_VFM_encoder_decoder.py:446-448): frac[0] = mean_pixels( max softmax(logits) > thr ) over the
  * window of an NCHW map [B,C,H,W]; counts int32 [1] zeroed by the caller */
 int vfm_conf_gate(const float* logits, int B, int C, int H, int W, int y0, int x0, int hc, int wc, float thr,

@@ -506,3 +506,24 @@ def test_checkpoint_converters():
     ref_c = F.interpolate(clip["visual.positional_embedding"][1:].reshape(1, 16, 16, D).permute(0, 3, 1, 2), size=(32, 32),
                           mode="bilinear").reshape(D, 1024).permute(1, 0)
     assert relerr(out["positional_embedding"][1:], ref_c) < 1e-5 and relerr(out["conv1.weight"], ref_k) < 1e-5
+
+
+def test_seg_data_preprocessor_uint8():
+    """uint8 BGR CHW samples of different sizes -> RGB, normalised, padded to `size` (mmseg SegDataPreProcessor + stack_batch)."""
+    from vfmseg_amd.segmentors import SegDataPreProcessor, SegDataSample
+    mean, std = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
+    pp = SegDataPreProcessor(mean=mean, std=std, size=(64, 96), bgr_to_rgb=True, pad_val=0, seg_pad_val=255)
+    g = torch.Generator().manual_seed(91)
+    imgs = [torch.randint(0, 256, (3, 64, 96), generator=g, dtype=torch.uint8), torch.randint(0, 256, (3, 50, 70), generator=g, dtype=torch.uint8)]
+    labs = [torch.randint(0, 19, (1, 64, 96), generator=g), torch.randint(0, 19, (1, 50, 70), generator=g)]
+    out = pp(dict(inputs=imgs, data_samples=[SegDataSample(gt_sem_seg=l) for l in labs]), training=True)
+    x = out["inputs"].cpu()
+    assert x.shape == (2, 3, 64, 96)
+    for i, im in enumerate(imgs):
+        ref = (im[[2, 1, 0]].float() - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
+        h, w = im.shape[-2:]
+        assert torch.allclose(x[i, :, :h, :w], ref, rtol=1e-6, atol=1e-6)
+        assert (x[i, :, h:, :] == 0).all() and (x[i, :, :, w:] == 0).all()
+        lab = out["data_samples"][i].gt_sem_seg.data
+        assert lab.shape == (1, 64, 96) and torch.equal(lab[:, :h, :w], labs[i]) and (lab[:, h:, :] == 255).all() and (lab[:, :, w:] == 255).all()
+        assert out["data_samples"][i].metainfo["padding_size"] == (0, 96 - w, 0, 64 - h)

@@ -533,6 +533,37 @@ extern "C" int vfm_upsample_ce(const float* logits_low, const int64_t* label, in
   return VFM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------- input preprocessing
+// mmseg SegDataPreProcessor on a decoded uint8 CHW image: optional BGR->RGB, (x - mean[c]) / std[c], right/bottom padding to
+// [Hp, Wp] with pad_val (applied AFTER normalisation, as stack_batch does).  One sample of the batch per call.
+__global__ void k_preprocess_u8(const uint8_t* __restrict__ in, int H, int W, float* __restrict__ out, int Hp, int Wp, float m0,
+                                float m1, float m2, float s0, float s1, float s2, int swap_rb, float pad_val) {
+  const long total = 3L * Hp * Wp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wp);
+    const long t = i / Wp;
+    const int y = (int)(t % Hp), c = (int)(t / Hp);
+    float v = pad_val;
+    if (y < H && x < W) {
+      const int cs = swap_rb ? 2 - c : c;
+      const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+      v = ((float)in[((long)cs * H + y) * W + x] - mean) / sd;
+    }
+    out[i] = v;
+  }
+}
+extern "C" int vfm_preprocess_u8(const uint8_t* img, int H, int W, float* out, int Hp, int Wp, const float* mean3, const float* std3,
+                                 int bgr_to_rgb, float pad_val, void* stream) {
+  VFM_CHECK(img && out && mean3 && std3 && Hp >= H && Wp >= W, VFM_E_SHAPE, "vfm_preprocess_u8: shape (mean3/std3 are HOST arrays)");
+  const long total = 3L * Hp * Wp;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_preprocess_u8, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, H, W, out, Hp, Wp, mean3[0], mean3[1], mean3[2],
+                     std3[0], std3[1], std3[2], bgr_to_rgb, pad_val);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------- inference helpers
 __global__ void k_conf_gate(const float* __restrict__ lg, int B, int C, int H, int W, int y0, int x0, int hc, int wc, float thr,
                             int32_t* __restrict__ count) {

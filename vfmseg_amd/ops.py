@@ -530,6 +530,18 @@ def upsample_ce(logits_low, label, ignore_index=255, need_grad=True):
     return loss, counts, dl
 
 
+def preprocess_u8(img_u8, out, mean, std, bgr_to_rgb, pad_val=0.0):
+    """img_u8 uint8 [3,H,W] (cuda) -> out fp32 [3,Hp,Wp]: channel swap, normalise, pad (mmseg SegDataPreProcessor)."""
+    lib = L.load()
+    assert img_u8.dtype == torch.uint8 and img_u8.is_contiguous() and out.is_contiguous() and out.dtype == torch.float32
+    _, H, W = img_u8.shape
+    _, Hp, Wp = out.shape
+    m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+    L.check(lib.vfm_preprocess_u8(L.ptr(img_u8), H, W, L.ptr(out), Hp, Wp, m3, s3, int(bool(bgr_to_rgb)), float(pad_val), L.stream()),
+            "vfm_preprocess_u8")
+    return out
+
+
 def conf_gate_count(logits_nchw, window, thr, count):
     lib = L.load()
     B, Cc, H, W = logits_nchw.shape

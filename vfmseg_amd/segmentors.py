@@ -48,24 +48,60 @@ class CfgDict(dict):
 
 @MODELS.register_module()
 class SegDataPreProcessor(nn.Module):
-    """mmseg SegDataPreProcessor for already-decoded tensors: float inputs are taken as normalised images and stacked;
-    labels are stacked into data_samples (padding to `size` with pad_val / seg_pad_val when shapes differ is a
-    next-row item: synthetic batches are already at `size`)."""
+    """mmseg SegDataPreProcessor (1.2.2 semantics, restated): decoded uint8 CHW images are channel-swapped (bgr_to_rgb),
+    normalised and padded right/bottom to `size` with pad_val by one HIP kernel per sample (vfm_preprocess_u8), labels are
+    padded with seg_pad_val, and img_shape / pad_shape / padding_size land in the sample's metainfo (stack_batch).
+    Float inputs are taken as already-normalised images (the synthetic benchmark path) and only stacked."""
 
     def __init__(self, mean=None, std=None, size=None, size_divisor=None, pad_val=0, seg_pad_val=255, bgr_to_rgb=False,
                  rgb_to_bgr=False, batch_augments=None, test_cfg=None):
         super().__init__()
-        self.size, self.pad_val, self.seg_pad_val, self.bgr_to_rgb = size, pad_val, seg_pad_val, bgr_to_rgb
-        self.register_buffer("mean", torch.tensor(mean if mean is not None else [0.0, 0.0, 0.0]).view(-1, 1, 1), False)
-        self.register_buffer("std", torch.tensor(std if std is not None else [1.0, 1.0, 1.0]).view(-1, 1, 1), False)
+        assert not (bgr_to_rgb and rgb_to_bgr)
+        self.size, self.size_divisor, self.pad_val, self.seg_pad_val = size, size_divisor, pad_val, seg_pad_val
+        self.channel_swap = bool(bgr_to_rgb or rgb_to_bgr)
+        self.test_cfg = test_cfg
+        self.mean_l = list(mean) if mean is not None else [0.0, 0.0, 0.0]
+        self.std_l = list(std) if std is not None else [1.0, 1.0, 1.0]
+        self.register_buffer("mean", torch.tensor(self.mean_l).view(-1, 1, 1), False)
+        self.register_buffer("std", torch.tensor(self.std_l).view(-1, 1, 1), False)
+
+    def _target(self, shapes, training):
+        h, w = max(s[0] for s in shapes), max(s[1] for s in shapes)
+        if training and self.size is not None:
+            h, w = max(h, self.size[-2]), max(w, self.size[-1])
+        div = self.size_divisor if training else (self.test_cfg or {}).get("size_divisor") if self.test_cfg else None
+        if div:
+            h, w = (h + div - 1) // div * div, (w + div - 1) // div * div
+        return h, w
 
     def forward(self, data, training=False):
         inputs, samples = data["inputs"], data.get("data_samples")
-        if isinstance(inputs, (list, tuple)):
-            inputs = torch.stack(list(inputs), 0)
-        if inputs.dtype != torch.float32:
-            raise NotImplementedError("uint8 decode/normalise path is a next-row item; pass normalised float images")
-        return dict(inputs=inputs.cuda(non_blocking=True).contiguous(), data_samples=samples)
+        if torch.is_tensor(inputs) and inputs.dtype == torch.float32:
+            return dict(inputs=inputs.cuda(non_blocking=True).contiguous(), data_samples=samples)
+        imgs = list(inputs)
+        if imgs[0].dtype == torch.float32:
+            return dict(inputs=torch.stack(imgs, 0).cuda(non_blocking=True).contiguous(), data_samples=samples)
+        if imgs[0].dtype != torch.uint8:
+            raise TypeError(f"SegDataPreProcessor: expected uint8 or float32 images, got {imgs[0].dtype}")
+        hp, wp = self._target([tuple(i.shape[-2:]) for i in imgs], training)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        out = torch.empty(len(imgs), 3, hp, wp, dtype=torch.float32, device=dev)
+        for i, im in enumerate(imgs):
+            ops.preprocess_u8(im.to(dev, non_blocking=True).contiguous(), out[i], self.mean_l, self.std_l, self.channel_swap, self.pad_val)
+            if samples is not None:
+                s_ = samples[i]
+                h, w = im.shape[-2:]
+                gt = getattr(s_, "gt_sem_seg", None)
+                g = None if gt is None else (gt if torch.is_tensor(gt) else gt.data)
+                if g is not None and tuple(g.shape[-2:]) != (hp, wp):
+                    pad = torch.full(tuple(g.shape[:-2]) + (hp, wp), self.seg_pad_val, dtype=g.dtype, device=g.device)
+                    pad[..., :g.shape[-2], :g.shape[-1]] = g
+                    s_.gt_sem_seg = PixelData(pad)
+                meta = dict(getattr(s_, "metainfo", {}) or {})
+                meta.update(img_shape=(hp, wp), pad_shape=(hp, wp), padding_size=(0, wp - w, 0, hp - h))
+                meta.setdefault("ori_shape", (h, w))
+                s_.metainfo = meta
+        return dict(inputs=out, data_samples=samples)
 
 
 def get_crop_bbox(img_h, img_w, crop_size, divisible=1):
