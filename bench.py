@@ -60,7 +60,7 @@ class GemmTimer:
         self.recs = []
         self.on = False
         self.calls = 0
-        self.every = 3
+        self.every = 7   # prime: cycles through every GEMM site of a layer over the steps
 
     def install(self):
         from vfmseg_amd import ops

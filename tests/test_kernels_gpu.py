@@ -335,6 +335,11 @@ def test_attention(dt, nq_extra, nk_extra, nq, nk):
     # token-major buffers: main tokens first, then the per-image extra (cls) rows
     q = rnd(B * nq + B * nq_extra, hd, seed=42).to(dt)
     k = rnd(B * nk + B * nk_extra, hd, seed=43).to(dt)
+    if nk >= 256:  # keys of the later tiles score much higher: forces the lazy-rescale branch of the online softmax mid-stream
+        k = k.float()
+        k[B * nk // 2: B * nk // 2 + 7] *= 4.0
+        k[B * nk - 5: B * nk] *= 6.0
+        k = k.to(dt)
     v = rnd(B * nk + B * nk_extra, hd, seed=44).to(dt)
     do = rnd(B * nq + B * nq_extra, hd, seed=45).to(dt)
 

@@ -319,8 +319,12 @@ __global__ void __launch_bounds__(256, 2) k_attn_bf16_q(AttnP p) {
           mx = fmaxf(mx, sacc[kb][r]);
         }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+      // lazy rescale: the reference maximum m only moves when the tile maximum exceeds it by more than 2^8 in the exp2
+      // domain (p <= 256 stays exact enough in bf16 / fp32 sums); after the first tiles the 32 accumulator rescales and
+      // the alpha exp are skipped for the whole wave.  m = -inf on the first tile, so it always takes the update there.
+      const bool need = (mx - m) * c > 8.0f;
+      const float mn = need ? mx : m;
+      const float alpha = need ? __builtin_amdgcn_exp2f((m - mn) * c) : 1.0f;
       const float mnc = mn * c;
       float rs = 0.f;
 #pragma unroll
@@ -333,10 +337,12 @@ __global__ void __launch_bounds__(256, 2) k_attn_bf16_q(AttnP p) {
         }
       l = l * alpha + rs;
       m = mn;
+      if (__ballot(alpha != 1.0f) != 0ull) {  // the running maximum settles after the first tiles: skip the 32 rescales
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[j][r] *= alpha;
+          for (int r = 0; r < 16; ++r) oacc[j][r] *= alpha;
+      }
     } else {
       // ---- dS^T = P^T * (dP^T - delta), P^T = exp(scale*S^T - lse)
       f32x16 dpacc[2] = {zero16(), zero16()};

@@ -326,7 +326,7 @@ static void launch_skinny(const vfm_gemm_desc* d, hipStream_t s) {
 
 static int g_force_cfg = -1;
 static int g_split_tail = 1;
-static int g_use_pp = 1;  // 256x256 tiles: the ping-pong kernel (gemm_pp.hip) instead of config 16
+static int g_use_pp = 3;  // bit 0: 256x256 ping-pong kernel instead of config 16; bit 1: 128x128 ping-pong kernel (gemm_pp.hip)
 extern "C" int vfm_tune(const char* key, int value) {
   if (key && strcmp(key, "gemm_cfg") == 0) {
     g_force_cfg = value;
@@ -414,10 +414,10 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s) {
     const long t256 = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
     if (d->N <= 32) cfg = 10;                                        // 64x64 tiles: many rows, few columns
     else if (t128 <= 160) cfg = 18;                                  // small problems: 64x128 tiles fill more CUs
-    else if (g_use_pp && t128 > 160 && t128 <= 272 && d->K >= 256 && (d->M + 128) * d->sa_m < (1l << 31) && (d->N + 128) * d->sb_n < (1l << 31))
+    else if ((g_use_pp & 2) && t128 > 160 && t128 <= 272 && d->K >= 256 && (d->M + 128) * d->sa_m < (1l << 31) && (d->N + 128) * d->sb_n < (1l << 31))
       cfg = 31;  // about one 128x128 tile per CU: the ping-pong kernel (one block per CU, 4-slot DMA ring)
-    else if (d->N >= 2048 && (t256 % 256 == 0 || t256 >= 768))
-      cfg = (g_use_pp && d->K >= 128 && (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31)) ? 30 : 16;  // 256x256 tiles
+    else if (d->N >= 2048 && (t256 % 256 == 0 || t256 >= 768) && !(g_use_pp & 8))
+      cfg = ((g_use_pp & 1) && d->K >= 128 && (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31)) ? 30 : 16;  // 256x256 tiles
     else cfg = 17;                                                   // 128x128, 8 waves, 2 blocks per CU
   }
   switch (cfg) {
