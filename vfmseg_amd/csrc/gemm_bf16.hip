@@ -34,9 +34,15 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <int BM, int BN, int WM_W, int WN_W, int NS, bool VEC, bool BT>
 __global__ void __launch_bounds__(WM_W* WN_W * 64)
     k_gemm_bf16(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, long M, long N, long K,
-                long stride_a, long stride_b, long stride_c, int tiles_m, int tiles_n, long kb_rows, EpiParams e) {
+                long stride_a, long stride_b, long stride_c, int tiles_m, int tiles_n, long kb_rows, EpiParams e, SkinnyTail sk) {
   using C = Cfg<BM, BN, WM_W, WN_W, NS>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (!BT && C::THREADS == 512 && C::SMEM >= 65536) {
+    if (sk.nblk > 0 && (int)blockIdx.x >= tiles_m * tiles_n) {  // tail rows of M ([cls] tokens): extra blocks at the end of the grid
+      skinny_tile(sk.A, sk.lda, B, ldb, sk.M, N, K, (long)((int)blockIdx.x - tiles_m * tiles_n) * 32, sk.e, 0, smem);
+      return;
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN_W, wn = wave % WN_W;
@@ -204,8 +210,10 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   else epi_scalar<C::MI, C::NI, 1>(e, zoff, acc, img, lane, m0 + wm * C::WM, n0 + wn * C::WN, M, N);
 }
 
+// tail != null: the <= 32 rows past the last full 128-row block run as extra blocks of the same launch when the
+// configuration can host them (512 threads, >= 64 KiB LDS); returns false when the caller has to launch them separately
 template <int BM, int BN, int WM_W, int WN_W, int NS, bool VEC, bool BT>
-static void launch_one(const vfm_gemm_desc* d, hipStream_t s) {
+static bool launch_one(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail = nullptr) {
   using C = Cfg<BM, BN, WM_W, WN_W, NS>;
   const int tiles_m = cdiv(d->M, BM), tiles_n = cdiv(d->N, BN);
   const long batch = d->batch > 0 ? d->batch : 1;
@@ -214,18 +222,25 @@ static void launch_one(const vfm_gemm_desc* d, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)k_gemm_bf16<BM, BN, WM_W, WN_W, NS, VEC, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
     attr = true;
   }
-  dim3 grid(tiles_m * tiles_n, (unsigned)batch), blk(C::THREADS);
+  SkinnyTail sk;
+  sk.nblk = 0;
+  const bool fold = tail && !BT && C::THREADS == 512 && C::SMEM >= 65536 && batch == 1;
+  if (fold) {
+    sk.A = (const bf16_t*)tail->A, sk.lda = tail->sa_m, sk.M = tail->M, sk.nblk = cdiv(tail->N, 32), sk.e = make_epi(tail);
+  }
+  dim3 grid(tiles_m * tiles_n + sk.nblk, (unsigned)batch), blk(C::THREADS);
   const long ldb = BT ? d->sb_k : d->sb_n;
   const long kb_rows = d->kb_rows > 0 ? d->kb_rows : 0;
   hipLaunchKernelGGL((k_gemm_bf16<BM, BN, WM_W, WN_W, NS, VEC, BT>), grid, blk, C::SMEM, s, (const bf16_t*)d->A, d->sa_m,
                      (const bf16_t*)d->B, ldb, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c, tiles_m, tiles_n, kb_rows,
-                     make_epi(d));
+                     make_epi(d), sk);
+  return fold || !tail;
 }
 
 template <int BM, int BN, int WM_W, int WN_W, int NS>
-static void launch_cfg(const vfm_gemm_desc* d, hipStream_t s, bool vec) {
-  if (vec) launch_one<BM, BN, WM_W, WN_W, NS, true, false>(d, s);
-  else launch_one<BM, BN, WM_W, WN_W, NS, false, false>(d, s);
+static bool launch_cfg(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail = nullptr) {
+  if (vec) return launch_one<BM, BN, WM_W, WN_W, NS, true, false>(d, s, tail);
+  return launch_one<BM, BN, WM_W, WN_W, NS, false, false>(d, s, tail);
 }
 
 template <int BM, int WM_W, int WN_W>
@@ -235,87 +250,12 @@ static void launch_bt(const vfm_gemm_desc* d, hipStream_t s, bool vec) {
 }
 
 // ------------------------------------------------------------------------------------------------ skinny tail
-// M <= 32 rows (the [cls] rows that follow the 128-aligned patch-token rows): one block = 32 rows x 32 columns, the 8
-// waves split K eight ways, operands go straight from global memory into MFMA fragments (no LDS staging, no barriers
-// in the loop: B is streamed exactly once), partial sums meet in LDS for the shared epilogue.
 __global__ void __launch_bounds__(512) k_gemm_bf16_skinny(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb,
                                                           long M, long N, long K, long stride_a, long stride_b, long stride_c,
                                                           EpiParams e) {
-  // per-wave staging image of a [32 columns(n) x 128 k] slice of B: 256-B rows, chunk c of row r at c ^ (r & 15)
-  __shared__ __attribute__((aligned(16))) char stg[8][32 * 256];
-  __shared__ float part[8][32][33];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fr = lane & 31, fh = lane >> 5;
-  const long n0 = (long)blockIdx.x * 32;
+  __shared__ __attribute__((aligned(16))) char stg[65536];
   const long z = blockIdx.y;
-  long am = fr;
-  if (am > M - 1) am = M - 1;
-  const bf16_t* ap = A + z * stride_a + am * lda + fh * 8;
-  const bf16_t* Bz = B + z * stride_b;
-  // coalesced loader map: one wave-instruction = 4 rows x 256 B
-  const int lrow = lane >> 4, lch = lane & 15;
-  const bf16_t* bsrc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    long bn = n0 + 4 * i + lrow;
-    if (bn > N - 1) bn = N - 1;
-    bsrc[i] = Bz + bn * ldb + lch * 8;
-  }
-  const long nchunk = K / 128;                       // K % 128 may be 64: handled by the remainder chunk below
-  const long per = (nchunk + 7) / 8;
-  const long c_beg = wave * per, c_end = (c_beg + per < nchunk) ? c_beg + per : nchunk;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  char* W = stg[wave];
-  for (long cidx = c_beg; cidx < c_end; ++cidx) {
-    const long k0 = cidx * 128;
-    uint4 v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const uint4*>(bsrc[i] + k0);
-    bf16x8 af[8];
-#pragma unroll
-    for (int s2 = 0; s2 < 8; ++s2) af[s2] = *reinterpret_cast<const bf16x8*>(ap + k0 + 16 * s2);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = 4 * i + lrow;
-      *reinterpret_cast<uint4*>(W + row * 256 + ((lch ^ (row & 15)) << 4)) = v[i];
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int s2 = 0; s2 < 8; ++s2) {
-      const bf16x8 bf = *reinterpret_cast<const bf16x8*>(W + fr * 256 + (((2 * s2 + fh) ^ (fr & 15)) << 4));
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s2], bf, acc, 0, 0, 0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-  }
-  if ((K % 128) != 0 && wave == 7) {  // trailing 64-wide half chunk (K % 64 == 0 is guaranteed by the caller)
-    const long k0 = nchunk * 128;
-    long bn = n0 + fr;
-    if (bn > N - 1) bn = N - 1;
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + k0 + 16 * s2);
-      const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bz + bn * ldb + fh * 8 + k0 + 16 * s2);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 16; ++r) part[wave][(r & 3) + 8 * (r >> 2) + 4 * fh][fr] = acc[r];
-  __syncthreads();
-  const long zoff = z * stride_c;
-  for (int i = tid; i < 32 * 32; i += 512) {
-    const int row = i >> 5, col = i & 31;
-    const long m = row, n = n0 + col;
-    if (m < M && n < N) {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) v += part[w][row][col];
-      epi_store(e, zoff, m, n, v);
-    }
-  }
+  skinny_tile(A + z * stride_a, lda, B + z * stride_b, ldb, M, N, K, (long)blockIdx.x * 32, e, z * stride_c, stg);
 }
 
 static void launch_skinny(const vfm_gemm_desc* d, hipStream_t s) {
@@ -326,6 +266,7 @@ static void launch_skinny(const vfm_gemm_desc* d, hipStream_t s) {
 
 static int g_force_cfg = -1;
 static int g_split_tail = 1;
+static int g_fold_tail = 1;  // run the tail rows as extra blocks of the tile kernel's launch
 static int g_use_pp = 3;  // bit 0: 256x256 ping-pong kernel instead of config 16; bit 1: 128x128 ping-pong kernel (gemm_pp.hip)
 extern "C" int vfm_tune(const char* key, int value) {
   if (key && strcmp(key, "gemm_cfg") == 0) {
@@ -339,6 +280,10 @@ extern "C" int vfm_tune(const char* key, int value) {
   }
   if (key && strcmp(key, "gemm_use_pp") == 0) {
     g_use_pp = value;
+    return VFM_OK;
+  }
+  if (key && strcmp(key, "gemm_fold_tail") == 0) {
+    g_fold_tail = value;
     return VFM_OK;
   }
   if (key && strcmp(key, "gemm_split_tail") == 0) {
@@ -365,9 +310,9 @@ static bool vec_ok(const vfm_gemm_desc* d) {
 //  5: 256x128 2x2 NS2   6: 256x128 2x2 NS3   7: 256x128 4x2 NS3   8: 256x256 2x4 NS2  9: 128x256 2x2 NS3
 //  10: 64x64 2x2 NS4    11: 256x64 4x2 NS3    12: 128x128 4x2 NS2  13: 128x128 4x2 NS3  14: 256x128 4x2 NS2
 //  15: 256x256 4x2 NS2  16: 256x256 4x4 NS2   17: 128x128 2x4 NS2  18: 64x128 2x2 NS2   19: 128x64 2x2 NS2
-static int gemm_main(const vfm_gemm_desc* d, hipStream_t s);
-void vfm_gemm_launch_pp256(const vfm_gemm_desc* d, hipStream_t s, bool vec);  // gemm_pp.hip
-void vfm_gemm_launch_pp128(const vfm_gemm_desc* d, hipStream_t s, bool vec);  // gemm_pp.hip
+static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail = nullptr, bool* folded = nullptr);
+bool vfm_gemm_launch_pp256(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail);  // gemm_pp.hip
+bool vfm_gemm_launch_pp128(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail);  // gemm_pp.hip
 
 int vfm_gemm_bf16_impl(const vfm_gemm_desc* d0, hipStream_t s) {
   // A few rows past a 128-row boundary (M = B*1024 patch tokens + B [cls] tokens) would cost a whole extra row of
@@ -388,9 +333,10 @@ int vfm_gemm_bf16_impl(const vfm_gemm_desc* d0, hipStream_t s) {
     dt.residual = adv(d0->residual, d0->r_dt, d0->ldr);
     dt.aux = adv(d0->aux, d0->aux_dt, d0->ld_aux);
     dt.C2 = (void*)adv(d0->C2, d0->c2_dt, d0->ldc2);
-    int rc = gemm_main(&dm, s);
+    bool folded = false;
+    int rc = gemm_main(&dm, s, g_fold_tail ? &dt : nullptr, &folded);
     if (rc) return rc;
-    launch_skinny(&dt, s);
+    if (!folded) launch_skinny(&dt, s);
     return VFM_OK;
   }
   if (d0->M <= 32 && d0->N >= 32) {
@@ -400,8 +346,9 @@ int vfm_gemm_bf16_impl(const vfm_gemm_desc* d0, hipStream_t s) {
   return gemm_main(d0, s);
 }
 
-static int gemm_main(const vfm_gemm_desc* d, hipStream_t s) {
+static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail, bool* folded) {
   const bool vec = vec_ok(d);
+  bool fd = false;
   if (d->sb_n == 1 && d->sb_k != 1) {  // B given as [K, N]: transposed-B kernels (BN = 128)
     if (d->M <= 64) launch_bt<64, 1, 4>(d, s, vec);
     else launch_bt<128, 2, 4>(d, s, vec);
@@ -421,40 +368,41 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s) {
     else cfg = 17;                                                   // 128x128, 8 waves, 2 blocks per CU
   }
   switch (cfg) {
-    case 0: launch_cfg<128, 128, 2, 2, 2>(d, s, vec); break;
-    case 1: launch_cfg<128, 128, 2, 2, 3>(d, s, vec); break;
-    case 2: launch_cfg<128, 128, 2, 2, 4>(d, s, vec); break;
-    case 3: launch_cfg<128, 64, 2, 2, 3>(d, s, vec); break;
-    case 4: launch_cfg<128, 64, 2, 2, 4>(d, s, vec); break;
-    case 5: launch_cfg<256, 128, 2, 2, 2>(d, s, vec); break;
-    case 6: launch_cfg<256, 128, 2, 2, 3>(d, s, vec); break;
-    case 7: launch_cfg<256, 128, 4, 2, 3>(d, s, vec); break;
-    case 8: launch_cfg<256, 256, 2, 4, 2>(d, s, vec); break;
-    case 9: launch_cfg<128, 256, 2, 2, 3>(d, s, vec); break;
-    case 10: launch_cfg<64, 64, 2, 2, 4>(d, s, vec); break;
-    case 11: launch_cfg<256, 64, 4, 2, 3>(d, s, vec); break;
-    case 12: launch_cfg<128, 128, 4, 2, 2>(d, s, vec); break;
-    case 13: launch_cfg<128, 128, 4, 2, 3>(d, s, vec); break;
-    case 14: launch_cfg<256, 128, 4, 2, 2>(d, s, vec); break;
-    case 15: launch_cfg<256, 256, 4, 2, 2>(d, s, vec); break;
-    case 16: launch_cfg<256, 256, 4, 4, 2>(d, s, vec); break;
-    case 17: launch_cfg<128, 128, 2, 4, 2>(d, s, vec); break;
-    case 18: launch_cfg<64, 128, 2, 2, 2>(d, s, vec); break;
-    case 19: launch_cfg<128, 64, 2, 2, 2>(d, s, vec); break;
-    case 20: launch_cfg<256, 128, 4, 4, 3>(d, s, vec); break;
-    case 21: launch_cfg<128, 256, 4, 4, 3>(d, s, vec); break;
-    case 22: launch_cfg<256, 128, 4, 4, 2>(d, s, vec); break;
-    case 23: launch_cfg<128, 128, 4, 4, 3>(d, s, vec); break;
-    case 24: launch_cfg<128, 128, 4, 4, 2>(d, s, vec); break;
+    case 0: fd = launch_cfg<128, 128, 2, 2, 2>(d, s, vec, tail); break;
+    case 1: fd = launch_cfg<128, 128, 2, 2, 3>(d, s, vec, tail); break;
+    case 2: fd = launch_cfg<128, 128, 2, 2, 4>(d, s, vec, tail); break;
+    case 3: fd = launch_cfg<128, 64, 2, 2, 3>(d, s, vec, tail); break;
+    case 4: fd = launch_cfg<128, 64, 2, 2, 4>(d, s, vec, tail); break;
+    case 5: fd = launch_cfg<256, 128, 2, 2, 2>(d, s, vec, tail); break;
+    case 6: fd = launch_cfg<256, 128, 2, 2, 3>(d, s, vec, tail); break;
+    case 7: fd = launch_cfg<256, 128, 4, 2, 3>(d, s, vec, tail); break;
+    case 8: fd = launch_cfg<256, 256, 2, 4, 2>(d, s, vec, tail); break;
+    case 9: fd = launch_cfg<128, 256, 2, 2, 3>(d, s, vec, tail); break;
+    case 10: fd = launch_cfg<64, 64, 2, 2, 4>(d, s, vec, tail); break;
+    case 11: fd = launch_cfg<256, 64, 4, 2, 3>(d, s, vec, tail); break;
+    case 12: fd = launch_cfg<128, 128, 4, 2, 2>(d, s, vec, tail); break;
+    case 13: fd = launch_cfg<128, 128, 4, 2, 3>(d, s, vec, tail); break;
+    case 14: fd = launch_cfg<256, 128, 4, 2, 2>(d, s, vec, tail); break;
+    case 15: fd = launch_cfg<256, 256, 4, 2, 2>(d, s, vec, tail); break;
+    case 16: fd = launch_cfg<256, 256, 4, 4, 2>(d, s, vec, tail); break;
+    case 17: fd = launch_cfg<128, 128, 2, 4, 2>(d, s, vec, tail); break;
+    case 18: fd = launch_cfg<64, 128, 2, 2, 2>(d, s, vec, tail); break;
+    case 19: fd = launch_cfg<128, 64, 2, 2, 2>(d, s, vec, tail); break;
+    case 20: fd = launch_cfg<256, 128, 4, 4, 3>(d, s, vec, tail); break;
+    case 21: fd = launch_cfg<128, 256, 4, 4, 3>(d, s, vec, tail); break;
+    case 22: fd = launch_cfg<256, 128, 4, 4, 2>(d, s, vec, tail); break;
+    case 23: fd = launch_cfg<128, 128, 4, 4, 3>(d, s, vec, tail); break;
+    case 24: fd = launch_cfg<128, 128, 4, 4, 2>(d, s, vec, tail); break;
     case 31:
       VFM_CHECK(d->K >= 256, VFM_E_UNSUPPORTED, "vfm_gemm(bf16): the 128x128 ping-pong kernel needs K >= 256");
-      vfm_gemm_launch_pp128(d, s, vec);
+      fd = vfm_gemm_launch_pp128(d, s, vec, tail);
       break;
     case 30:
       VFM_CHECK(d->K >= 128, VFM_E_UNSUPPORTED, "vfm_gemm(bf16): the ping-pong kernel needs K >= 128");
-      vfm_gemm_launch_pp256(d, s, vec);
+      fd = vfm_gemm_launch_pp256(d, s, vec, tail);
       break;
     default: VFM_FAIL(VFM_E_INVAL, "vfm_gemm(bf16): unknown config %d", cfg);
   }
+  if (folded) *folded = fd && tail;
   return VFM_OK;
 }

@@ -322,3 +322,86 @@ __device__ __forceinline__ void epi_scalar(const EpiParams& e, long zoff, f32x16
   if constexpr (NG > 2) group(IC<2>{});
   if constexpr (NG > 3) group(IC<3>{});
 }
+
+// ------------------------------------------------------------------------------------------------ skinny tail
+// M <= 32 rows (the [cls] rows that follow the 128-aligned patch-token rows): one 512-thread block = 32 rows x 32 columns,
+// the 8 waves split K eight ways, B goes global -> registers -> a wave-private LDS image -> MFMA fragments (no block
+// barriers in the loop: B is streamed exactly once), partial sums meet in LDS for the shared epilogue.  64 KiB of LDS.
+// It is a device function so that the tile kernels can run it in extra blocks at the END of their grid (the tail rows of
+// M = 4100 then cost no launch of their own; last linear ids: they fill in as CUs free up and displace nothing).
+struct SkinnyTail {
+  const bf16_t* A; long lda; long M; int nblk; EpiParams e;
+};
+__device__ __forceinline__ void skinny_tile(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ Bz, long ldb, long M, long N,
+                                            long K, long n0, const EpiParams& e, long zoff, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  long am = fr;
+  if (am > M - 1) am = M - 1;
+  const bf16_t* ap = A + am * lda + fh * 8;
+  // coalesced loader map: one wave-instruction = 4 rows x 256 B
+  const int lrow = lane >> 4, lch = lane & 15;
+  const bf16_t* bsrc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    long bn = n0 + 4 * i + lrow;
+    if (bn > N - 1) bn = N - 1;
+    bsrc[i] = Bz + bn * ldb + lch * 8;
+  }
+  const long nchunk = K / 128;                       // K % 128 may be 64: handled by the remainder chunk below
+  const long per = (nchunk + 7) / 8;
+  const long c_beg = wave * per, c_end = (c_beg + per < nchunk) ? c_beg + per : nchunk;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  char* W = smem + wave * 8192;  // [32 columns(n) x 128 k] slice of B: 256-B rows, chunk c of row r at c ^ (r & 15)
+  for (long cidx = c_beg; cidx < c_end; ++cidx) {
+    const long k0 = cidx * 128;
+    uint4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const uint4*>(bsrc[i] + k0);
+    bf16x8 af[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) af[s2] = *reinterpret_cast<const bf16x8*>(ap + k0 + 16 * s2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 4 * i + lrow;
+      *reinterpret_cast<uint4*>(W + row * 256 + ((lch ^ (row & 15)) << 4)) = v[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) {
+      const bf16x8 bf = *reinterpret_cast<const bf16x8*>(W + fr * 256 + (((2 * s2 + fh) ^ (fr & 15)) << 4));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s2], bf, acc, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if ((K % 128) != 0 && wave == 7) {  // trailing 64-wide half chunk (K % 64 == 0 is guaranteed by the caller)
+    const long k0 = nchunk * 128;
+    long bn = n0 + fr;
+    if (bn > N - 1) bn = N - 1;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + k0 + 16 * s2);
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bz + bn * ldb + fh * 8 + k0 + 16 * s2);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+  }
+  __syncthreads();  // every wave is done with its staging slice: the partial sums reuse that memory
+  float* part = reinterpret_cast<float*>(smem);  // [8][32][33]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 33 + fr] = acc[r];
+  __syncthreads();
+  for (int i = tid; i < 32 * 32; i += 512) {
+    const int row = i >> 5, col = i & 31;
+    const long m = row, n = n0 + col;
+    if (m < M && n < N) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += part[(w * 32 + row) * 33 + col];
+      epi_store(e, zoff, m, n, v);
+    }
+  }
+}

@@ -34,9 +34,13 @@ constexpr int PP_SMEM = PP_EPI_BYTES > PP_RING ? PP_EPI_BYTES : PP_RING;
 template <bool VEC>
 __global__ void __launch_bounds__(512)
     k_gemm_pp256(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, long M, long N, long K, long stride_a,
-                 long stride_b, long stride_c, int tiles_m, int tiles_n, EpiParams e, int dbg) {
+                 long stride_b, long stride_c, int tiles_m, int tiles_n, EpiParams e, int dbg, SkinnyTail sk) {
   constexpr int BM = 256, BN = 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (sk.nblk > 0 && (int)blockIdx.x >= tiles_m * tiles_n) {  // tail rows of M: extra blocks at the end of the grid
+    skinny_tile(sk.A, sk.lda, B, ldb, sk.M, N, K, (long)((int)blockIdx.x - tiles_m * tiles_n) * 32, sk.e, 0, smem);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = wave >> 2, wc = wave & 3;
@@ -226,9 +230,13 @@ constexpr int P1_SMEM = P1_RING;
 template <bool VEC>
 __global__ void __launch_bounds__(512)
     k_gemm_pp128(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, long M, long N, long K, long stride_a,
-                 long stride_b, long stride_c, int tiles_m, int tiles_n, EpiParams e) {
+                 long stride_b, long stride_c, int tiles_m, int tiles_n, EpiParams e, SkinnyTail sk) {
   constexpr int BM = 128, BN = 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (sk.nblk > 0 && (int)blockIdx.x >= tiles_m * tiles_n) {  // tail rows of M: extra blocks at the end of the grid
+    skinny_tile(sk.A, sk.lda, B, ldb, sk.M, N, K, (long)((int)blockIdx.x - tiles_m * tiles_n) * 32, sk.e, 0, smem);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = wave >> 2, wc = wave & 3;
@@ -375,7 +383,7 @@ __global__ void __launch_bounds__(512)
 }
 
 template <bool VEC>
-static void launch_pp128_t(const vfm_gemm_desc* d, hipStream_t s) {
+static bool launch_pp128_t(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail) {
   const int tiles_m = cdiv(d->M, 128), tiles_n = cdiv(d->N, 128);
   const long batch = d->batch > 0 ? d->batch : 1;
   static bool attr = false;
@@ -383,18 +391,23 @@ static void launch_pp128_t(const vfm_gemm_desc* d, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)k_gemm_pp128<VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, P1_SMEM);
     attr = true;
   }
-  hipLaunchKernelGGL((k_gemm_pp128<VEC>), dim3(tiles_m * tiles_n, (unsigned)batch), dim3(512), P1_SMEM, s, (const bf16_t*)d->A,
+  SkinnyTail sk;
+  sk.nblk = 0;
+  const bool fold = tail && batch == 1;
+  if (fold) sk.A = (const bf16_t*)tail->A, sk.lda = tail->sa_m, sk.M = tail->M, sk.nblk = cdiv(tail->N, 32), sk.e = make_epi(tail);
+  hipLaunchKernelGGL((k_gemm_pp128<VEC>), dim3(tiles_m * tiles_n + sk.nblk, (unsigned)batch), dim3(512), P1_SMEM, s, (const bf16_t*)d->A,
                      d->sa_m, (const bf16_t*)d->B, d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c, tiles_m, tiles_n,
-                     make_epi(d));
+                     make_epi(d), sk);
+  return fold || !tail;
 }
-void vfm_gemm_launch_pp128(const vfm_gemm_desc* d, hipStream_t s, bool vec) {
-  if (vec) launch_pp128_t<true>(d, s);
-  else launch_pp128_t<false>(d, s);
+bool vfm_gemm_launch_pp128(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail) {
+  if (vec) return launch_pp128_t<true>(d, s, tail);
+  return launch_pp128_t<false>(d, s, tail);
 }
 
 int g_pp_dbg = 0;
 template <bool VEC>
-static void launch_pp256_t(const vfm_gemm_desc* d, hipStream_t s) {
+static bool launch_pp256_t(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail) {
   const int tiles_m = cdiv(d->M, 256), tiles_n = cdiv(d->N, 256);
   const long batch = d->batch > 0 ? d->batch : 1;
   static bool attr = false;
@@ -402,12 +415,16 @@ static void launch_pp256_t(const vfm_gemm_desc* d, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)k_gemm_pp256<VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_SMEM);
     attr = true;
   }
-  hipLaunchKernelGGL((k_gemm_pp256<VEC>), dim3(tiles_m * tiles_n, (unsigned)batch), dim3(512), PP_SMEM, s, (const bf16_t*)d->A,
+  SkinnyTail sk;
+  sk.nblk = 0;
+  const bool fold = tail && batch == 1;
+  if (fold) sk.A = (const bf16_t*)tail->A, sk.lda = tail->sa_m, sk.M = tail->M, sk.nblk = cdiv(tail->N, 32), sk.e = make_epi(tail);
+  hipLaunchKernelGGL((k_gemm_pp256<VEC>), dim3(tiles_m * tiles_n + sk.nblk, (unsigned)batch), dim3(512), PP_SMEM, s, (const bf16_t*)d->A,
                      d->sa_m, (const bf16_t*)d->B, d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c, tiles_m, tiles_n,
-                     make_epi(d), g_pp_dbg);
+                     make_epi(d), g_pp_dbg, sk);
+  return fold || !tail;
 }
-
-void vfm_gemm_launch_pp256(const vfm_gemm_desc* d, hipStream_t s, bool vec) {
-  if (vec) launch_pp256_t<true>(d, s);
-  else launch_pp256_t<false>(d, s);
+bool vfm_gemm_launch_pp256(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail) {
+  if (vec) return launch_pp256_t<true>(d, s, tail);
+  return launch_pp256_t<false>(d, s, tail);
 }
