@@ -532,3 +532,19 @@ def test_seg_data_preprocessor_uint8():
         lab = out["data_samples"][i].gt_sem_seg.data
         assert lab.shape == (1, 64, 96) and torch.equal(lab[:, :h, :w], labs[i]) and (lab[:, h:, :] == 255).all() and (lab[:, :, w:] == 255).all()
         assert out["data_samples"][i].metainfo["padding_size"] == (0, 96 - w, 0, 64 - h)
+
+
+@pytest.mark.parametrize("P,M,Q,ld", [(64, 4100, 3072, 1088), (64, 4100, 1024, 64), (32, 700, 256, 40)])
+def test_gemm_bf16_tn_splitk(P, M, Q, ld):
+    """Weight-gradient form with BOTH operands token-major (no transposed copies): slabs.sum(0) = xs^T @ y; xs is a column
+    slice of a wider buffer, rows past M count as zeros."""
+    wide = rnd(M, ld, seed=62).bfloat16().to(DEV)
+    xs = wide[:, ld - P:] if ld - P >= 0 and (ld - P) % 8 == 0 else wide[:, :P]
+    y = rnd(M, Q, seed=63).bfloat16().to(DEV)
+    mp = (M + 63) // 64 * 64
+    steps = mp // 64
+    kch = max(d for d in range(1, 17) if steps % d == 0)
+    slabs = torch.full((kch, P, Q), float("nan"), device=DEV)
+    ops.gemm_splitk_tn(xs, y, slabs, kch)
+    ref = xs.double().t() @ y.double()
+    assert relerr(slabs.sum(0), ref) < 2e-5

@@ -534,15 +534,20 @@ def _wgrad_small_t(xs, y, out, alpha=1.0, scatter=None):
     M = xs.shape[0]
     if xs.dtype == torch.bfloat16:
         mp = (M + 63) // 64 * 64
-        xt = torch.empty(xs.shape[1], mp, dtype=xs.dtype, device=xs.device)
-        ops.transpose(xs, xt, pad_rows=mp)
         # few output tiles, long token reduction: split K into the largest divisor <= 16 of the 64-token steps
         steps = mp // 64
         kch = max(d for d in range(1, 17) if steps % d == 0)
+        tn = kch > 1 and xs.shape[1] % 8 == 0 and xs.data_ptr() % 16 == 0 and xs.stride(0) % 8 == 0
+        if not tn:
+            xt = torch.empty(xs.shape[1], mp, dtype=xs.dtype, device=xs.device)
+            ops.transpose(xs, xt, pad_rows=mp)
         if kch > 1:
-            P, Q = xt.shape[0], y.shape[1]
+            P, Q = xs.shape[1], y.shape[1]
             slabs = torch.empty(kch, P, Q, dtype=torch.float32, device=xs.device)
-            ops.gemm_splitk_bt(xt, y, slabs, kch)
+            if tn:
+                ops.gemm_splitk_tn(xs, y, slabs, kch)      # both operands token-major, consumed in place (no transposes)
+            else:
+                ops.gemm_splitk_bt(xt, y, slabs, kch)
             if scatter is not None:
                 dst, rows_used, sp, sq = scatter
                 ops.slab_reduce(slabs, rows_used, dst, sp, sq, alpha=alpha, accumulate=True)

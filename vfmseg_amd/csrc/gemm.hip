@@ -76,10 +76,12 @@ extern "C" int vfm_gemm(const vfm_gemm_desc* d, void* stream) {
     hipLaunchKernelGGL(k_gemm_f32, grid, dim3(256), 0, s, (const float*)d->A, (const float*)d->B, d->M, d->N, d->K, d->sa_m,
                        d->sa_k, d->sb_n, d->sb_k, d->stride_a, d->stride_b, d->stride_c, make_epi(d));
   } else if (d->in_dt == VFM_BF16) {
-    VFM_CHECK(d->sa_k == 1 && (d->sb_k == 1 || (d->sb_n == 1 && d->N % 8 == 0)), VFM_E_UNSUPPORTED,
-              "vfm_gemm(bf16): A must be K-contiguous; B either [N,K] K-contiguous or [K,N] N-contiguous with N %% 8 == 0");
+    const bool bt = d->sb_n == 1 && d->sb_k != 1, at = d->sa_m == 1 && d->sa_k != 1;
+    VFM_CHECK((d->sa_k == 1 || (at && bt && d->M % 8 == 0)) && (d->sb_k == 1 || (bt && d->N % 8 == 0)), VFM_E_UNSUPPORTED,
+              "vfm_gemm(bf16): A must be K-contiguous (or [K,M] together with a [K,N] B, M %% 8 == 0); B either [N,K] K-contiguous or "
+              "[K,N] N-contiguous with N %% 8 == 0");
     VFM_CHECK(d->K % 64 == 0 && d->K > 0, VFM_E_ALIGN, "vfm_gemm(bf16): K=%ld must be a positive multiple of 64 (zero-pad)", d->K);
-    VFM_CHECK(d->sa_m % 8 == 0 && (d->sb_k == 1 ? d->sb_n % 8 == 0 : d->sb_k % 8 == 0) && ((uintptr_t)d->A % 16 == 0) &&
+    VFM_CHECK((at ? d->sa_k : d->sa_m) % 8 == 0 && (d->sb_k == 1 ? d->sb_n % 8 == 0 : d->sb_k % 8 == 0) && ((uintptr_t)d->A % 16 == 0) &&
                   ((uintptr_t)d->B % 16 == 0) && d->stride_a % 8 == 0 && d->stride_b % 8 == 0,
               VFM_E_ALIGN, "vfm_gemm(bf16): operands must be 16-byte aligned with lda/ldb %% 8 == 0");
     const int rc = vfm_gemm_bf16_impl(d, s);

@@ -31,7 +31,10 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // BT = true: B is given as [K, N] row-major (N contiguous) - weight-gradient GEMMs reduce over tokens, so the activation
 // operand is consumed in place and its MFMA fragments come from transposed LDS reads (ds_read_b64_tr_b16); rows k >= kb_rows
 // are clamped (the A operand is zero there).
-template <int BM, int BN, int WM_W, int WN_W, int NS, bool VEC, bool BT>
+// AT = true (with BT): A is given as [K, M] row-major too (M contiguous): C = A^T B with BOTH operands token-major, the form
+// of a weight gradient dW = X^T dY - no transposed copy of either operand; k-rows past the valid tokens read a zero row.
+__device__ __attribute__((aligned(16))) unsigned char g_zero_row[512];
+template <int BM, int BN, int WM_W, int WN_W, int NS, bool VEC, bool BT, bool AT = false>
 __global__ void __launch_bounds__(WM_W* WN_W * 64)
     k_gemm_bf16(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, long M, long N, long K,
                 long stride_a, long stride_b, long stride_c, int tiles_m, int tiles_n, long kb_rows, EpiParams e, SkinnyTail sk) {
@@ -78,12 +81,24 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   const int lr = lane >> 3, pc = lane & 7;
   const bf16_t* a_src[C::A_PIECES];
   const bf16_t* b_src[C::B_PIECES];
+  int at_row[C::A_PIECES];
 #pragma unroll
   for (int j = 0; j < C::A_PIECES; ++j) {
-    const int r = (wave * C::A_PIECES + j) * 8 + lr;
-    long gm = m0 + r;
-    if (gm > M - 1) gm = M - 1;
-    a_src[j] = Ab + gm * lda + ((pc ^ ((r >> 1) & 7)) << 3);
+    if constexpr (!AT) {
+      const int r = (wave * C::A_PIECES + j) * 8 + lr;
+      long gm = m0 + r;
+      if (gm > M - 1) gm = M - 1;
+      a_src[j] = Ab + gm * lda + ((pc ^ ((r >> 1) & 7)) << 3);
+    } else {
+      static_assert(!AT || (BT && BM == 128), "transposed-A path: BM = 128 (256-byte LDS rows), together with transposed B");
+      const int piece = wave * C::A_PIECES + j;          // 1 KiB = 4 k-rows x 256 B
+      const int r = piece * 4 + (lane >> 4);
+      const int c = (lane & 15) ^ ((r & 3) << 2);
+      long gm = m0 + c * 8;
+      if (gm > M - 8) gm = M - 8;                        // M % 8 == 0: clamped chunks are never stored
+      at_row[j] = r;
+      a_src[j] = Ab + gm;
+    }
   }
   int bt_row[C::B_PIECES];  // BT: k-row of this lane inside the tile, per piece
 #pragma unroll
@@ -108,7 +123,15 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
     char* sa = smem + slot * C::STAGE_BYTES;
     char* sb = sa + C::A_BYTES;
 #pragma unroll
-    for (int j = 0; j < C::A_PIECES; ++j) glds16(a_src[j] + k0, sa + (wave * C::A_PIECES + j) * 1024);
+    for (int j = 0; j < C::A_PIECES; ++j) {
+      if constexpr (!AT) {
+        glds16(a_src[j] + k0, sa + (wave * C::A_PIECES + j) * 1024);
+      } else {
+        const long kr = k0 + at_row[j];
+        const bf16_t* src = kr < kb_valid ? a_src[j] + kr * lda : reinterpret_cast<const bf16_t*>(g_zero_row) + (lane & 15) * 8;
+        glds16(src, sa + (wave * C::A_PIECES + j) * 1024);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < C::B_PIECES; ++j) {
       if constexpr (!BT) {
@@ -179,9 +202,26 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
         return u.v;
       }
     };
+    auto read_a = [&](int s2, int i) -> bf16x8 {
+      if constexpr (!AT) {
+        return *reinterpret_cast<const bf16x8*>(sa + a_off[i] + (((2 * s2 + fh) ^ a_sw[i]) << 4));
+      } else {
+        const int g = lane >> 4, i2 = lane & 15, q = i2 >> 2, p = i2 & 3, h2 = g >> 1;
+        const int chunk = (wm * C::WM + i * 32) / 8 + 2 * (g & 1) + (p >> 1);
+        const int r0 = 16 * s2 + 8 * h2 + q, r1 = r0 + 4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(sa + r0 * 256 + ((chunk ^ ((r0 & 3) << 2)) << 4) + ((p & 1) << 3)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(sa + r1 * 256 + ((chunk ^ ((r1 & 3) << 2)) << 4) + ((p & 1) << 3)));
+        union { struct { s16x4 a, b; } st; bf16x8 v; } u;
+        u.st.a = lo;
+        u.st.b = hi;
+        return u.v;
+      }
+    };
     bf16x8 af[2][C::MI], bfr[2][C::NI];
 #pragma unroll
-    for (int i = 0; i < C::MI; ++i) af[0][i] = *reinterpret_cast<const bf16x8*>(sa + a_off[i] + (((fh) ^ a_sw[i]) << 4));
+    for (int i = 0; i < C::MI; ++i) af[0][i] = read_a(0, i);
 #pragma unroll
     for (int j = 0; j < C::NI; ++j) bfr[0][j] = read_b(0, j);
 #pragma unroll
@@ -190,7 +230,7 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
       if (s + 1 < BK / 16) {
 #pragma unroll
         for (int i = 0; i < C::MI; ++i)
-          af[nxt][i] = *reinterpret_cast<const bf16x8*>(sa + a_off[i] + (((2 * (s + 1) + fh) ^ a_sw[i]) << 4));
+          af[nxt][i] = read_a(s + 1, i);
 #pragma unroll
         for (int j = 0; j < C::NI; ++j) bfr[nxt][j] = read_b(s + 1, j);
       }
@@ -212,14 +252,14 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
 
 // tail != null: the <= 32 rows past the last full 128-row block run as extra blocks of the same launch when the
 // configuration can host them (512 threads, >= 64 KiB LDS); returns false when the caller has to launch them separately
-template <int BM, int BN, int WM_W, int WN_W, int NS, bool VEC, bool BT>
+template <int BM, int BN, int WM_W, int WN_W, int NS, bool VEC, bool BT, bool AT = false>
 static bool launch_one(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail = nullptr) {
   using C = Cfg<BM, BN, WM_W, WN_W, NS>;
   const int tiles_m = cdiv(d->M, BM), tiles_n = cdiv(d->N, BN);
   const long batch = d->batch > 0 ? d->batch : 1;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_gemm_bf16<BM, BN, WM_W, WN_W, NS, VEC, BT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+    (void)hipFuncSetAttribute((const void*)k_gemm_bf16<BM, BN, WM_W, WN_W, NS, VEC, BT, AT>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
     attr = true;
   }
   SkinnyTail sk;
@@ -231,7 +271,7 @@ static bool launch_one(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_des
   dim3 grid(tiles_m * tiles_n + sk.nblk, (unsigned)batch), blk(C::THREADS);
   const long ldb = BT ? d->sb_k : d->sb_n;
   const long kb_rows = d->kb_rows > 0 ? d->kb_rows : 0;
-  hipLaunchKernelGGL((k_gemm_bf16<BM, BN, WM_W, WN_W, NS, VEC, BT>), grid, blk, C::SMEM, s, (const bf16_t*)d->A, d->sa_m,
+  hipLaunchKernelGGL((k_gemm_bf16<BM, BN, WM_W, WN_W, NS, VEC, BT, AT>), grid, blk, C::SMEM, s, (const bf16_t*)d->A, AT ? d->sa_k : d->sa_m,
                      (const bf16_t*)d->B, ldb, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c, tiles_m, tiles_n, kb_rows,
                      make_epi(d), sk);
   return fold || !tail;
@@ -350,6 +390,11 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
   const bool vec = vec_ok(d);
   bool fd = false;
   if (d->sb_n == 1 && d->sb_k != 1) {  // B given as [K, N]: transposed-B kernels (BN = 128)
+    if (d->sa_m == 1 && d->sa_k != 1) {  // ... and A given as [K, M]: C = A^T B, both operands consumed in place
+      if (vec) launch_one<128, 128, 2, 4, 2, true, true, true>(d, s);
+      else launch_one<128, 128, 2, 4, 2, false, true, true>(d, s);
+      return VFM_OK;
+    }
     if (d->M <= 64) launch_bt<64, 1, 4>(d, s, vec);
     else launch_bt<128, 2, 4>(d, s, vec);
     return VFM_OK;

@@ -126,7 +126,7 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
   return fmaf(x, pdf, cdf);
 }
 
-// RES: 0 none, 1 fp32 residual.  MODE: VFM_EP_*; modes 3/4 read a bf16 aux.  CDT: dtype of C.  HASC2: bf16 copy of the
+// RES: 0 none, 1 fp32 residual, 2 bf16 residual.  MODE: VFM_EP_*; modes 3/4 read a bf16 aux.  CDT: dtype of C.  HASC2: bf16 copy of the
 // pre-activation value.
 template <int MODE, int CDT, int RES, bool HASC2, int MI, int NI, int GROUP>
 __device__ __forceinline__ void epi_fast(const EpiParams& e, long zoff, f32x16 (&acc)[MI][NI], float* img, int lane, long m_base,
@@ -157,6 +157,7 @@ __device__ __forceinline__ void epi_fast(const EpiParams& e, long zoff, f32x16 (
 
   // ---- every load of the wave tile, before any store
   float4 res[RES == 1 ? NP : 1];
+  ushort4 resh[RES == 2 ? NP : 1];
   ushort4 aux[AUX ? NP : 1];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
@@ -165,6 +166,10 @@ __device__ __forceinline__ void epi_fast(const EpiParams& e, long zoff, f32x16 (
     if constexpr (RES == 1) {
       res[p] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok) res[p] = *reinterpret_cast<const float4*>((const float*)e.residual + zoff + m * e.ldr + n);
+    }
+    if constexpr (RES == 2) {
+      resh[p] = make_ushort4(0, 0, 0, 0);
+      if (ok) resh[p] = *reinterpret_cast<const ushort4*>((const bf16_t*)e.residual + zoff + m * e.ldr + n);
     }
     if constexpr (AUX) {
       aux[p] = make_ushort4(0, 0, 0, 0);
@@ -211,6 +216,8 @@ __device__ __forceinline__ void epi_fast(const EpiParams& e, long zoff, f32x16 (
       }
       x[0] *= s4.x, x[1] *= s4.y, x[2] *= s4.z, x[3] *= s4.w;
       if constexpr (RES == 1) x[0] += res[p].x, x[1] += res[p].y, x[2] += res[p].z, x[3] += res[p].w;
+      if constexpr (RES == 2)
+        x[0] += bf16_to_f32(resh[p].x), x[1] += bf16_to_f32(resh[p].y), x[2] += bf16_to_f32(resh[p].z), x[3] += bf16_to_f32(resh[p].w);
       if (ok) {
         const long o = zoff + m * e.ldc + n;
         if constexpr (CDT == VFM_BF16) {
@@ -283,6 +290,10 @@ __device__ __forceinline__ void epi_wave_tile(const EpiParams& e, long zoff, f32
     epi_fast<VFM_EP_GELU, VFM_BF16, 0, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
   else if (mode == VFM_EP_MUL_GELU_GRAD && e.aux_dt == VFM_BF16 && plain && e.c_dt == VFM_BF16)
     epi_fast<VFM_EP_MUL_GELU_GRAD, VFM_BF16, 0, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+  else if (mode == VFM_EP_MUL && e.aux_dt == VFM_BF16 && !e.C2 && e.residual && e.r_dt == VFM_BF16 && e.c_dt == VFM_BF16)
+    epi_fast<VFM_EP_MUL, VFM_BF16, 2, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);  // LoRA: dx += mask * (dT A)
+  else if (mode == VFM_EP_NONE && !e.C2 && e.residual && e.r_dt == VFM_BF16 && e.c_dt == VFM_BF16)
+    epi_fast<VFM_EP_NONE, VFM_BF16, 2, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
   else if (mode == VFM_EP_QGELU && e.C2 && e.c2_dt == VFM_BF16 && !e.residual && e.c_dt == VFM_BF16)
     epi_fast<VFM_EP_QGELU, VFM_BF16, 0, true, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
   else if (mode == VFM_EP_MUL_QGELU_GRAD && e.aux_dt == VFM_BF16 && plain && e.c_dt == VFM_BF16)

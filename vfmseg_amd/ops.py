@@ -366,6 +366,31 @@ def gemm_splitk_bt(at, y, slabs, kch):
     return slabs
 
 
+def gemm_splitk_tn(xs, y, slabs, kch):
+    """Split-K weight gradient with BOTH operands token-major: slabs[z] = xs[z*ck:(z+1)*ck, :]^T @ y[z*ck:(z+1)*ck, :]
+    (xs [M, P], y [M, Q] bf16 views consumed in place, P % 8 == 0; token rows >= M read as zeros), slabs fp32 [kch, P, Q],
+    ck = ceil64(M) / kch."""
+    lib = L.load()
+    d = L.GemmDesc()
+    M, P = xs.shape
+    M2, Q = y.shape
+    assert M == M2 and xs.stride(1) == 1 and y.stride(1) == 1
+    mp = (M + 63) // 64 * 64
+    ck = mp // kch
+    assert ck * kch == mp and ck % 64 == 0 and slabs.shape == (kch, P, Q)
+    d.A, d.B, d.C = L.ptr(xs), L.ptr(y), L.ptr(slabs)
+    d.in_dt, d.c_dt = L.dt_of(xs), L.dt_of(slabs)
+    d.M, d.N, d.K = P, Q, ck
+    d.sa_m, d.sa_k = 1, xs.stride(0)
+    d.sb_n, d.sb_k = 1, y.stride(0)
+    d.ldc = slabs.stride(1)
+    d.alpha = 1.0
+    d.batch, d.stride_a, d.stride_b, d.stride_c = kch, ck * xs.stride(0), ck * y.stride(0), slabs.stride(0)
+    d.kb_rows = int(M)
+    L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
+    return slabs
+
+
 def tune(key, value):
     lib = L.load()
     L.check(lib.vfm_tune(key.encode(), int(value)), "vfm_tune")
