@@ -197,16 +197,20 @@ class LinearFn(torch.autograd.Function):
                 ops.colsum(gv, dbias)
         dws = [None] * len(weights)
         if any(ctx.needs_input_grad[4:]):
-            gw = torch.empty(N, Kp, dtype=torch.float32, device=dy.device)
+            gw = torch.empty(npad if cd == torch.bfloat16 else N, Kp, dtype=torch.float32, device=dy.device)
             if cd == torch.bfloat16:
                 mp = _pad64(M)
                 tiles = ((N + 127) // 128) * ((Kp + 127) // 128)
                 kch = 1
                 while tiles * kch < 256 and (mp // (kch * 2)) % 64 == 0 and mp // (kch * 2) >= 256:
                     kch *= 2
-                dyt = torch.empty(N, mp, dtype=cd, device=dy.device)
-                ops.transpose(gv, dyt, pad_rows=mp)
-                _splitk_wgrad(dyt, x, gw, kch, M)
+                # dW = g^T x with both operands token-major (TN form of vfm_gemm): no transposed copy of the gradient
+                if kch > 1:
+                    slabs = torch.empty(kch, npad, Kp, dtype=torch.float32, device=dy.device)
+                    ops.gemm_splitk_tn(g, x, slabs, kch)
+                    ops.colsum(slabs.view(kch, npad * Kp), gw.view(npad * Kp))
+                else:
+                    ops.gemm_splitk_tn(g, x, gw.view(1, npad, Kp), 1)
             else:
                 ops.gemm(gv, x, gw, trans_a=True, trans_b=True)
             r0 = 0
