@@ -50,6 +50,15 @@ int vfm_axpby(const float* x, float a, float* y, float b, long n, void* stream);
 int vfm_scale_by_device_scalar(float* y, const float* scalar, long n, void* stream);
 /* out[c] (+)= sum_r x[r,c]  (bias gradients); deterministic two-stage reduction, ws >= 64*cols floats */
 int vfm_colsum(const void* x, int dt, long ld, long rows, long cols, float* out, int accumulate, float* ws, void* stream);
+/* Re-pack of the LoRA factors (peft lora.Linear, lora_backbone.py:16-23) of ALL adapter sites into their K-concatenated GEMM
+ * operands, one launch: a[:r,:K] = A, at[:K,:r] = A^T, w[:N,Kw:Kw+r] = B, wt[Kw:Kw+r,:N] = B^T (wt may be null).  The
+ * table is an array of nsites entries in DEVICE memory; dst dtype dt; max_elems = max over sites of r*(K+N). */
+typedef struct vfm_lora_site {
+  const float* A; const float* B;     /* fp32 [r,K], [N,r] */
+  void* a; void* at; void* w; void* wt;
+  long r, K, N, Kw, ld_a, ld_at, ld_w, ld_wt;
+} vfm_lora_site;
+int vfm_lora_pack(const vfm_lora_site* table_dev, int nsites, long max_elems, int dt, void* stream);
 /* Split-K combine fused with the scatter into the parameter-gradient layout:
  * dst[p*sp + q*sq] (+)= alpha * sum_k slabs[k][p][q], p < rows_used (slabs fp32 [kch, P, Q]).  LoRA dA/dB (peft lora.Linear
  * backward) from the transposed-B weight-gradient GEMM of vfm_gemm. */

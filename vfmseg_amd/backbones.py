@@ -313,19 +313,15 @@ class DinoEngine:
         return P
 
     def refresh_lora(self, P):
-        """LoRA factors change every optimiser step: re-pack them into the concatenated QKV operand."""
+        """LoRA factors change every optimiser step: re-pack them into the concatenated QKV operand (one launch)."""
         D = self.vit.embed_dim
-        with torch.no_grad():
-            for blk, Lp in zip(self.vit.blocks, P["layers"]):
-                q = blk.attn.qkv
-                if not isinstance(q, LoraLinear):
-                    continue
-                A, Bm, r = q.lora_A["default"].weight.detach(), q.lora_B["default"].weight.detach(), q.r
-                ops.cast(A, Lp["a"][:r])
-                _pack_at(A, Lp["at"], r)
-                ops.cast(Bm, Lp["qkv"].w[:, D:D + r])
-                if Lp["qkv"].wt is not None:
-                    ops.transpose(Bm, Lp["qkv"].wt[D:D + r], pad_rows=Bm.shape[0])
+        sites = []
+        for blk, Lp in zip(self.vit.blocks, P["layers"]):
+            q = blk.attn.qkv
+            if isinstance(q, LoraLinear):
+                A, Bm = q.lora_A["default"].weight.detach(), q.lora_B["default"].weight.detach()
+                sites.append((A, Bm, Lp["a"], Lp["at"], Lp["qkv"].w, Lp["qkv"].wt, q.r, A.shape[1], Bm.shape[0], D))
+        _refresh_sites(P, sites)
 
     def pos_tokens(self, hp, wp):
         v = self.vit
@@ -518,6 +514,25 @@ class DinoEngine:
             if BACKWARD_EVENTS["block_done"] is not None:
                 BACKWARD_EVENTS["block_done"](li)
         return grads
+
+
+def _refresh_sites(P, sites):
+    """sites: (A, B, a, at, w, wt, r, K, N, Kw) per adapter; fp32 contiguous parameters go through the batched pack kernel."""
+    if not sites:
+        return
+    with torch.no_grad():
+        if all(s_[0].dtype == torch.float32 and s_[0].is_contiguous() and s_[1].dtype == torch.float32 and s_[1].is_contiguous() for s_ in sites):
+            tab = P.get("lora_table")
+            if tab is None or not tab.valid_for(sites):
+                tab = P["lora_table"] = ops.LoraPackTable(sites, sites[0][2])
+            tab.run()
+            return
+        for (A, Bm, a, at, w, wt, r, K, N, Kw) in sites:
+            ops.cast(A, a[:r])
+            _pack_at(A, at, r)
+            ops.cast(Bm, w[:, Kw:Kw + r])
+            if wt is not None:
+                ops.transpose(Bm, wt[Kw:Kw + r], pad_rows=Bm.shape[0])
 
 
 def _pack_at(A, at, r):

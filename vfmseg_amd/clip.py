@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .backbones import BACKWARD_EVENTS, R_PAD, LoraLinear, Packed, _BackboneFn, _Lin, _pack_at, _wgrad_small_t
+from .backbones import BACKWARD_EVENTS, R_PAD, LoraLinear, Packed, _BackboneFn, _Lin, _pack_at, _refresh_sites, _wgrad_small_t
 from .precision import compute_dtype
 from .registry import MODELS
 
@@ -182,16 +182,13 @@ class ClipEngine:
 
     def refresh_lora(self, P):
         D = self.vit.embed_dim
-        with torch.no_grad():
-            for blk, Lp in zip(self.vit.blocks, P["layers"]):
-                for nm, ka, kat, kw, K in (("c_fc", "a1", "at1", "fc", D), ("c_proj", "a2", "at2", "pr", Lp["hid"])):
-                    q = getattr(blk.mlp, nm)
-                    A, Bm, r = q.lora_A["default"].weight.detach(), q.lora_B["default"].weight.detach(), q.r
-                    ops.cast(A, Lp[ka][:r])
-                    _pack_at(A, Lp[kat], r)
-                    ops.cast(Bm, Lp[kw].w[:, K:K + r])
-                    if Lp[kw].wt is not None:
-                        ops.transpose(Bm, Lp[kw].wt[K:K + r], pad_rows=Bm.shape[0])
+        sites = []
+        for blk, Lp in zip(self.vit.blocks, P["layers"]):
+            for nm, ka, kat, kw, K in (("c_fc", "a1", "at1", "fc", D), ("c_proj", "a2", "at2", "pr", Lp["hid"])):
+                q = getattr(blk.mlp, nm)
+                A, Bm = q.lora_A["default"].weight.detach(), q.lora_B["default"].weight.detach()
+                sites.append((A, Bm, Lp[ka], Lp[kat], Lp[kw].w, Lp[kw].wt, q.r, A.shape[1], Bm.shape[0], K))
+        _refresh_sites(P, sites)
 
     def pos_tokens(self, hp, wp):
         """[1 + hp*wp, D]: row 0 = positional_embedding[0], rows 1.. = the spatial table bilinearly resized (clip.py:327-336)."""

@@ -224,6 +224,39 @@ extern "C" int vfm_slab_reduce(const float* slabs, int kch, long P, long Q, long
   return VFM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ LoRA factor re-pack
+// After every optimiser step the fp32 LoRA factors are re-packed into the K-concatenated GEMM operands of their layer:
+//   a[:r, :K] = A            at[:K, :r] = A^T          w[:N, Kw:Kw+r] = B          wt[Kw:Kw+r, :N] = B^T   (wt may be null)
+// One launch for ALL adapter sites of the model (blockIdx.y = site), instead of four small kernels per site and step.
+__global__ void k_lora_pack(const vfm_lora_site* __restrict__ tab, int dt) {
+  const vfm_lora_site t = tab[blockIdx.y];
+  const long na = t.r * t.K, nb = t.N * t.r;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < na + nb; i += (long)gridDim.x * blockDim.x) {
+    if (i < na) {
+      const long rr = i / t.K, k = i - rr * t.K;
+      const float v = t.A[i];
+      st_any(t.a, rr * t.ld_a + k, dt, v);
+      st_any(t.at, k * t.ld_at + rr, dt, v);
+    } else {
+      const long j = i - na;
+      const long n = j / t.r, rr = j - n * t.r;
+      const float v = t.B[j];
+      st_any(t.w, n * t.ld_w + t.Kw + rr, dt, v);
+      if (t.wt) st_any(t.wt, (t.Kw + rr) * t.ld_wt + n, dt, v);
+    }
+  }
+}
+extern "C" int vfm_lora_pack(const vfm_lora_site* table_dev, int nsites, long max_elems, int dt, void* stream) {
+  VFM_CHECK(table_dev && nsites >= 0 && (dt == VFM_F32 || dt == VFM_BF16), VFM_E_INVAL, "vfm_lora_pack: bad args");
+  if (nsites == 0) return VFM_OK;
+  int gx = (int)((max_elems + 255) / 256);
+  if (gx > 256) gx = 256;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(k_lora_pack, dim3(gx, nsites), dim3(256), 0, (hipStream_t)stream, table_dev, dt);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ dropout
 template <typename T>
 __global__ void k_dropout_mask(T* __restrict__ out, long n, float p, float keep_scale, uint64_t seed, uint64_t offset) {

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .backbones import R_PAD, LoraLinear, Packed, _BackboneFn, _Lin, _PatchEmbed, _pack_at, _wgrad_small_t
+from .backbones import R_PAD, LoraLinear, Packed, _BackboneFn, _Lin, _PatchEmbed, _pack_at, _refresh_sites, _wgrad_small_t
 from .precision import compute_dtype
 from .registry import MODELS
 
@@ -194,17 +194,13 @@ class EvaEngine:
 
     def refresh_lora(self, P):
         D = self.vit.embed_dim
-        with torch.no_grad():
-            for blk, Lp in zip(self.vit.blocks, P["layers"]):
-                q = blk.attn.proj
-                if not isinstance(q, LoraLinear):
-                    continue
-                A, Bm, r = q.lora_A["default"].weight.detach(), q.lora_B["default"].weight.detach(), q.r
-                ops.cast(A, Lp["a"][:r])
-                _pack_at(A, Lp["at"], r)
-                ops.cast(Bm, Lp["proj"].w[:, D:D + r])
-                if Lp["proj"].wt is not None:
-                    ops.transpose(Bm, Lp["proj"].wt[D:D + r], pad_rows=Bm.shape[0])
+        sites = []
+        for blk, Lp in zip(self.vit.blocks, P["layers"]):
+            q = blk.attn.proj
+            if isinstance(q, LoraLinear):
+                A, Bm = q.lora_A["default"].weight.detach(), q.lora_B["default"].weight.detach()
+                sites.append((A, Bm, Lp["a"], Lp["at"], Lp["proj"].w, Lp["proj"].wt, q.r, A.shape[1], Bm.shape[0], D))
+        _refresh_sites(P, sites)
 
     def forward(self, jobs, training, seed):
         v, P = self.vit, self.packed()

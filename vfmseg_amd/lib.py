@@ -55,6 +55,7 @@ SIGNATURES = {
     "vfm_scale_by_device_scalar": [vp, vp, cl, vp],
     "vfm_colsum": [vp, ci, cl, cl, cl, vp, ci, vp, vp],
     "vfm_preprocess_u8": [vp, ci, ci, vp, ci, ci, C.POINTER(C.c_float), C.POINTER(C.c_float), ci, cf, vp],
+    "vfm_lora_pack": [vp, ci, cl, ci, vp],
     "vfm_slab_reduce": [vp, ci, cl, cl, cl, cf, vp, cl, cl, ci, vp],
     "vfm_dropout_mask": [vp, ci, cl, cf, u64, u64, vp],
     "vfm_mul_mask": [vp, ci, cl, vp, ci, cl, cl, vp, ci, cl, cl, cl, vp],

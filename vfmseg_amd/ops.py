@@ -333,6 +333,37 @@ def gemm(a, b, c, *, alpha=1.0, bias=None, bias_mod=0, colscale=None, residual=N
     return c
 
 
+class LoraPackTable:
+    """Device-resident table for vfm_lora_pack: one entry per adapter site (A, B fp32 parameters and the packed operands they
+    feed).  Built once per packing (pointers are stable: parameters live in the optimiser's flat buffer, operands in the
+    engine's packed dict); `run()` re-packs every site with one launch."""
+
+    def __init__(self, sites, dt_tensor):
+        import struct
+        buf = bytearray()
+        self.max_elems = 0
+        self.keep = []
+        for (A, B, a, at, w, wt, r, K, N, Kw) in sites:
+            assert A.dtype == torch.float32 and B.dtype == torch.float32 and A.is_contiguous() and B.is_contiguous()
+            self.keep += [A, B, a, at, w, wt]
+            buf += struct.pack("6Q8q", A.data_ptr(), B.data_ptr(), a.data_ptr(), at.data_ptr(), w.data_ptr(),
+                               wt.data_ptr() if wt is not None else 0, r, K, N, Kw, a.stride(0), at.stride(0), w.stride(0),
+                               wt.stride(0) if wt is not None else 0)
+            self.max_elems = max(self.max_elems, r * (K + N))
+        self.n = len(sites)
+        self.dt = L.dt_of(dt_tensor)
+        dev = sites[0][2].device
+        self.table = torch.frombuffer(bytes(buf), dtype=torch.uint8).clone().to(dev)
+        self.ptrs = [s_[0].data_ptr() for s_ in sites] + [s_[1].data_ptr() for s_ in sites]
+
+    def valid_for(self, sites):
+        return self.n == len(sites) and self.ptrs == [s_[0].data_ptr() for s_ in sites] + [s_[1].data_ptr() for s_ in sites]
+
+    def run(self):
+        lib = L.load()
+        L.check(lib.vfm_lora_pack(L.ptr(self.table), self.n, self.max_elems, self.dt, L.stream()), "vfm_lora_pack")
+
+
 def slab_reduce(slabs, rows_used, dst, sp, sq, alpha=1.0, accumulate=False):
     """dst[p*sp + q*sq] (+)= alpha * sum_k slabs[k, p, q] for p < rows_used (slabs fp32 [kch, P, Q], dst fp32)."""
     lib = L.load()

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .backbones import BACKWARD_EVENTS, R_PAD, LoraLinear, Packed, _BackboneFn, _Lin, _PatchEmbed, _pack_at, _wgrad_small_t
+from .backbones import BACKWARD_EVENTS, R_PAD, LoraLinear, Packed, _BackboneFn, _Lin, _PatchEmbed, _pack_at, _refresh_sites, _wgrad_small_t
 from .precision import compute_dtype
 from .registry import MODELS
 
@@ -146,16 +146,13 @@ class SamEngine:
 
     def refresh_lora(self, P):
         D = self.vit.embed_dim
-        with torch.no_grad():
-            for blk, Lp in zip(self.vit.blocks, P["layers"]):
-                q = blk.attn.qkv
-                if isinstance(q, LoraLinear):
-                    A, Bm = q.lora_A["default"].weight.detach(), q.lora_B["default"].weight.detach()
-                    ops.cast(A, Lp["a"][:q.r])
-                    _pack_at(A, Lp["at"], q.r)
-                    ops.cast(Bm, Lp["qkv"].w[:, D:D + q.r])
-                    if Lp["qkv"].wt is not None:
-                        ops.transpose(Bm, Lp["qkv"].wt[D:D + q.r], pad_rows=Bm.shape[0])
+        sites = []
+        for blk, Lp in zip(self.vit.blocks, P["layers"]):
+            q = blk.attn.qkv
+            if isinstance(q, LoraLinear):
+                A, Bm = q.lora_A["default"].weight.detach(), q.lora_B["default"].weight.detach()
+                sites.append((A, Bm, Lp["a"], Lp["at"], Lp["qkv"].w, Lp["qkv"].wt, q.r, A.shape[1], Bm.shape[0], D))
+        _refresh_sites(P, sites)
 
     def attention(self, qkv, Lp, nimg, G, H, d, cd, dev, keep=False):
         """-> token-major attention output [nimg*G*G, H*d] (+ the probabilities [nb, NP, NP] when keep=True: rows / columns
