@@ -184,7 +184,9 @@ __device__ void attn_extra_dq(const AttnP& p, int b, int hh, int qi, char* smem)
   const long qrow = tok_row(b, qi, p.nq_main, p.B);
   const uint4 q8 = *reinterpret_cast<const uint4*>((const bf16_t*)p.q + qrow * p.ldq + col0 + sub * 8);
   const uint4 g8 = *reinterpret_cast<const uint4*>((const bf16_t*)p.dout + qrow * p.ld_do + col0 + sub * 8);
-  const float lse = p.lse[((long)b * p.H + hh) * nq + qi], delta = p.delta[((long)b * p.H + hh) * nq + qi];
+  const uint4 o8 = *reinterpret_cast<const uint4*>((const bf16_t*)p.o + qrow * p.ldo + col0 + sub * 8);
+  const float lse = p.lse[((long)b * p.H + hh) * nq + qi], delta = sum8(dot8(g8, o8));
+  if (tid == 0) p.delta[((long)b * p.H + hh) * nq + qi] = delta;
   const bf16_t* Kc = (const bf16_t*)p.k + col0 + sub * 8;
   const bf16_t* Vc = (const bf16_t*)p.v + col0 + sub * 8;
   for (int k0 = 0; k0 < nk; k0 += 128) {
@@ -279,7 +281,17 @@ __global__ void __launch_bounds__(256, 2) k_attn_bf16_q(AttnP p) {
   if (DQ) {
     load_stationary((const bf16_t*)p.dout, p.ld_do, qrow, col0, h, dof);
     lse_l = p.lse[((long)b * p.H + hh) * nq + (qvalid ? qi : nq - 1)] * LOG2E;
-    delta_l = p.delta[((long)b * p.H + hh) * nq + (qvalid ? qi : nq - 1)];
+    // delta = rowsum(dO o O), computed here (each lane holds half of the row's 64 columns) and published for the dK/dV
+    // kernel that runs next - no separate delta launch
+    bf16x8 of[4];
+    load_stationary((const bf16_t*)p.o, p.ldo, qrow, col0, h, of);
+    float dsum = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int e2 = 0; e2 < 8; ++e2) dsum = fmaf((float)dof[kk][e2], (float)of[kk][e2], dsum);
+    delta_l = dsum + __shfl_xor(dsum, 32, 64);
+    if (qvalid && h == 0) p.delta[((long)b * p.H + hh) * nq + qi] = delta_l;
   }
   const float c = p.scale * LOG2E;
   f32x16 oacc[2] = {zero16(), zero16()};
@@ -561,7 +573,6 @@ int vfm_attn_bf16_bwd_impl(const vfm_attn_desc* d, hipStream_t s) {
   const AttnP p = to_p(d);
   const int nq = d->nq_main + d->nq_extra, nk = d->nk_main + d->nk_extra;
   const long total = (long)d->B * d->H * nq;
-  hipLaunchKernelGGL(k_attn_delta_bf16, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p);
   hipLaunchKernelGGL(k_attn_bf16_q<true>, dim3(cdiv(nq, 128), d->B * d->H), dim3(256), 4 * TILE_BYTES, s, p);
   hipLaunchKernelGGL(k_attn_bf16_dkv, dim3(cdiv(nk, 128), d->B * d->H), dim3(256), 2 * (2 * TILE_BYTES + 1024), s, p);
   VFM_LAUNCH_CHECK();
