@@ -353,7 +353,7 @@ class LoraPackTable:
         self.n = len(sites)
         self.dt = L.dt_of(dt_tensor)
         dev = sites[0][2].device
-        self.table = torch.frombuffer(bytes(buf), dtype=torch.uint8).clone().to(dev)
+        self.table = torch.frombuffer(buf, dtype=torch.uint8).clone().to(dev)
         self.ptrs = [s_[0].data_ptr() for s_ in sites] + [s_[1].data_ptr() for s_ in sites]
 
     def valid_for(self, sites):

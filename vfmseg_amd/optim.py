@@ -91,16 +91,21 @@ class FusedAdamW:
         self.params = [named[n] for n in self.names]
         dev = self.params[0].device
         sizes = [p.numel() for p in self.params]
+        # every parameter starts on a 64-byte boundary of the flat buffers: bias / gamma slices then satisfy the 16-byte
+        # operand alignment of the vector GEMM epilogues (a 19-float conv_seg bias used to knock every later bias off it and
+        # sent a dozen head GEMMs per step down the scalar epilogue); the pad elements stay zero (zero grad -> zero update)
+        self.sizes = sizes
         self.offsets = [0]
         for s in sizes:
-            self.offsets.append(self.offsets[-1] + s)
+            self.offsets.append((self.offsets[-1] + s + 15) // 16 * 16)
         n = self.offsets[-1]
-        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.gflat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         with torch.no_grad():
-            for p, a, b in zip(self.params, self.offsets[:-1], self.offsets[1:]):
+            for p, a, sz in zip(self.params, self.offsets[:-1], sizes):
+                b = a + sz
                 view = self.flat[a:b].view(p.shape)
                 ops.cast(p.detach().reshape(1, -1).contiguous(), self.flat[a:b].view(1, -1))
                 p.data = view
@@ -132,9 +137,9 @@ class FusedAdamW:
 
     def zero_grad(self):
         self.gflat.zero_()
-        for p, a, b in zip(self.params, self.offsets[:-1], self.offsets[1:]):
+        for p, a, sz in zip(self.params, self.offsets[:-1], self.sizes):
             if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + a * 4:
-                p.grad = self.gflat[a:b].view(p.shape)
+                p.grad = self.gflat[a:a + sz].view(p.shape)
 
     def state_dict(self):
         return dict(step=self.step_count, m=self.m, v=self.v, names=self.names)
