@@ -329,7 +329,9 @@ def test_gemm_bf16_transposed_b(P, M, Q):
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("nq_extra,nk_extra,nq,nk", [(1, 1, 200, 200), (0, 0, 256, 256), (0, 0, 130, 70), (1, 1, 1024, 1024), (1, 1, 128, 384)])
 def test_attention(dt, nq_extra, nk_extra, nq, nk):
-    B, H, d = 2, 3, 64
+    # (B, H) = (2, 3): short grids -> the 2-wave-per-block kernels; the 1024-token case runs with 40 (image, head) pairs so that
+    # the 4-wave kernels and their single-row [cls] blocks (last linear block ids) are exercised as in the backbones
+    B, H, d = (2, 3, 64) if nq < 1024 else (5, 8, 64)
     hd = H * d
     tol = 2e-5 if dt == torch.float32 else 2e-2
     # token-major buffers: main tokens first, then the per-image extra (cls) rows

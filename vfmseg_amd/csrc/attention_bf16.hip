@@ -29,11 +29,12 @@ __device__ __forceinline__ void glds4(const void* g, void* l) {
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
 // stage one [64 x 64] bf16 tile: sequence positions s0..s0+63 of image b (clamped), columns col0..col0+63
+template <int NW = 4>
 __device__ __forceinline__ void stage_tile(const bf16_t* base, long ld, int col0, int b, int s0, int n, int n_main, int B, char* tile,
                                            int wave, int lane) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int piece = wave * 2 + j;
+  for (int j = 0; j < 8 / NW; ++j) {
+    const int piece = wave * (8 / NW) + j;
     const int r = piece * 8 + (lane >> 3);
     const int c = (lane & 7) ^ swz(r);
     int s = s0 + r;
@@ -246,14 +247,16 @@ __device__ void attn_extra_dkv(const AttnP& p, int b, int hh, int ki, char* smem
 }
 
 // ------------------------------------------------------------------------------------------------------ forward
-template <bool DQ>
-__global__ void __launch_bounds__(256, 2) k_attn_bf16_q(AttnP p) {
+// NW = waves per block (32 stationary positions each): 4, or 2 for short problems whose 4-wave grid would leave CUs idle
+// (the decoder's 16 (image, head) pairs x 1024 queries are only 128 blocks of 128 queries).
+template <bool DQ, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K tile, V tile)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nq = p.nq_main + p.nq_extra, nk = p.nk_main + p.nk_extra;
   int bx = blockIdx.x, bh = blockIdx.y;
-  if (p.nq_extra == 1 && (p.nq_main & 127) == 0 && nk <= ATTN_EXTRA_MAX) {
+  if (NW == 4 && p.nq_extra == 1 && (p.nq_main & 127) == 0 && nk <= ATTN_EXTRA_MAX) {
     // The [cls] query gets a block of its own that runs the VALU path.  Those blocks take the LAST linear ids: workgroups
     // are placed on the CUs in id order at launch, and a light block in the middle of the order pushes a third full block
     // onto some CUs (measured: +8 us on a 39-us kernel even when the light block returns at once).
@@ -269,7 +272,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bf16_q(AttnP p) {
   const int b = bh / p.H, hh = bh % p.H;
   const int col0 = hh * 64;
   const int h = lane >> 5;
-  const int q0 = bx * 128 + wave * 32;
+  const int q0 = bx * (NW * 32) + wave * 32;
   const int qi = q0 + (lane & 31);
   const bool qvalid = qi < nq;
   const long qrow = tok_row(b, qvalid ? qi : nq - 1, p.nq_main, p.B);
@@ -299,15 +302,16 @@ __global__ void __launch_bounds__(256, 2) k_attn_bf16_q(AttnP p) {
   const int nt = (nk + TROWS - 1) / TROWS;
   auto stage = [&](int buf, int t) {
     char* kt = smem + buf * 2 * TILE_BYTES;
-    stage_tile(Kb, p.ldk, col0, b, t * TROWS, nk, p.nk_main, p.B, kt, wave, lane);
-    stage_tile(Vb, p.ldv, col0, b, t * TROWS, nk, p.nk_main, p.B, kt + TILE_BYTES, wave, lane);
+    stage_tile<NW>(Kb, p.ldk, col0, b, t * TROWS, nk, p.nk_main, p.B, kt, wave, lane);
+    stage_tile<NW>(Vb, p.ldv, col0, b, t * TROWS, nk, p.nk_main, p.B, kt + TILE_BYTES, wave, lane);
   };
   stage(0, 0);
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     if (t + 1 < nt) {
       stage(buf ^ 1, t + 1);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -411,14 +415,15 @@ __global__ void __launch_bounds__(256, 2) k_attn_bf16_q(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------------------------------ dK / dV
-__global__ void __launch_bounds__(256, 2) k_attn_bf16_dkv(AttnP p) {
+template <int NW = 4>
+__global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (Q tile, dO tile, lse[64], delta[64] (+dummy))
   constexpr int STAGE = 2 * TILE_BYTES + 1024;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nq = p.nq_main + p.nq_extra, nk = p.nk_main + p.nk_extra;
   int bx = blockIdx.x, bh = blockIdx.y;
-  if (p.nk_extra == 1 && (p.nk_main & 127) == 0 && nq <= ATTN_EXTRA_MAX) {  // [cls] key: VALU path, last linear ids
+  if (NW == 4 && p.nk_extra == 1 && (p.nk_main & 127) == 0 && nq <= ATTN_EXTRA_MAX) {  // [cls] key: VALU path, last linear ids
     const int gx = gridDim.x, nfull = (gx - 1) * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
     if (lin >= nfull) {
       const int e = lin - nfull;
@@ -430,7 +435,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bf16_dkv(AttnP p) {
   const int b = bh / p.H, hh = bh % p.H;
   const int col0 = hh * 64;
   const int h = lane >> 5;
-  const int k0 = bx * 128 + wave * 32;
+  const int k0 = bx * (NW * 32) + wave * 32;
   const int ki = k0 + (lane & 31);
   const bool kvalid = ki < nk;
   const long krow = tok_row(b, kvalid ? ki : nk - 1, p.nk_main, p.B);
@@ -446,8 +451,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_bf16_dkv(AttnP p) {
   const int nt = (nq + TROWS - 1) / TROWS;
   auto stage = [&](int buf, int t) {
     char* qt = smem + buf * STAGE;
-    stage_tile(Qb, p.ldq, col0, b, t * TROWS, nq, p.nq_main, p.B, qt, wave, lane);
-    stage_tile(Ob, p.ld_do, col0, b, t * TROWS, nq, p.nq_main, p.B, qt + TILE_BYTES, wave, lane);
+    stage_tile<NW>(Qb, p.ldq, col0, b, t * TROWS, nq, p.nq_main, p.B, qt, wave, lane);
+    stage_tile<NW>(Ob, p.ld_do, col0, b, t * TROWS, nq, p.nq_main, p.B, qt + TILE_BYTES, wave, lane);
     int qq = t * TROWS + lane;
     if (qq > nq - 1) qq = nq - 1;
     // one 256-byte piece per wave: wave 0 -> lse, wave 1 -> delta, waves 2,3 -> scratch (keeps vmcnt uniform)
@@ -459,7 +464,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_bf16_dkv(AttnP p) {
     const int buf = t & 1;
     if (t + 1 < nt) {
       stage(buf ^ 1, t + 1);
-      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -527,30 +533,6 @@ __global__ void __launch_bounds__(256, 2) k_attn_bf16_dkv(AttnP p) {
   }
 }
 
-// delta[b,h,i] = sum_j dO[i,j] * O[i,j]  (one wave per 4 rows x all heads would be faster; this is ~1% of backward)
-__global__ void k_attn_delta_bf16(AttnP p) {
-  const int nq = p.nq_main + p.nq_extra;
-  const long total = (long)p.B * p.H * nq;
-  const bf16_t* dO = (const bf16_t*)p.dout;
-  const bf16_t* O = (const bf16_t*)p.o;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int hh = (int)(i % p.H);
-    const long t = i / p.H;
-    const int qi = (int)(t % nq);
-    const int b = (int)(t / nq);
-    const long row = tok_row(b, qi, p.nq_main, p.B);
-    float a = 0.f;
-#pragma unroll
-    for (int j = 0; j < 64; j += 8) {
-      const bf16x8 x = *reinterpret_cast<const bf16x8*>(dO + row * p.ld_do + hh * 64 + j);
-      const bf16x8 y = *reinterpret_cast<const bf16x8*>(O + row * p.ldo + hh * 64 + j);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) a += (float)x[e] * (float)y[e];
-    }
-    p.delta[((long)b * p.H + hh) * nq + qi] = a;
-  }
-}
-
 static bool aligned_ok(const vfm_attn_desc* d, bool bwd) {
   auto ok = [](const void* ptr, long ld) { return ((uintptr_t)ptr % 16 == 0) && (ld % 8 == 0); };
   bool r = ok(d->q, d->ldq) && ok(d->k, d->ldk) && ok(d->v, d->ldv) && ok(d->o, d->ldo);
@@ -558,12 +540,16 @@ static bool aligned_ok(const vfm_attn_desc* d, bool bwd) {
   return r;
 }
 
+// 2-wave blocks when the 4-wave grid would not even give every CU one block
+static bool short_grid(const vfm_attn_desc* d, int n) { return (long)cdiv(n, 128) * d->B * d->H < 256; }
+
 int vfm_attn_bf16_fwd_impl(const vfm_attn_desc* d, hipStream_t s) {
   VFM_CHECK(aligned_ok(d, false), VFM_E_ALIGN, "vfm_attn_fwd(bf16): operands must be 16-byte aligned, ld %% 8 == 0");
   const AttnP p = to_p(d);
   const int nq = d->nq_main + d->nq_extra;
   const size_t shm = 4 * TILE_BYTES;
-  hipLaunchKernelGGL(k_attn_bf16_q<false>, dim3(cdiv(nq, 128), d->B * d->H), dim3(256), shm, s, p);
+  if (short_grid(d, nq)) hipLaunchKernelGGL((k_attn_bf16_q<false, 2>), dim3(cdiv(nq, 64), d->B * d->H), dim3(128), shm, s, p);
+  else hipLaunchKernelGGL((k_attn_bf16_q<false, 4>), dim3(cdiv(nq, 128), d->B * d->H), dim3(256), shm, s, p);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }
@@ -572,9 +558,10 @@ int vfm_attn_bf16_bwd_impl(const vfm_attn_desc* d, hipStream_t s) {
   VFM_CHECK(aligned_ok(d, true), VFM_E_ALIGN, "vfm_attn_bwd(bf16): operands must be 16-byte aligned, ld %% 8 == 0");
   const AttnP p = to_p(d);
   const int nq = d->nq_main + d->nq_extra, nk = d->nk_main + d->nk_extra;
-  const long total = (long)d->B * d->H * nq;
-  hipLaunchKernelGGL(k_attn_bf16_q<true>, dim3(cdiv(nq, 128), d->B * d->H), dim3(256), 4 * TILE_BYTES, s, p);
-  hipLaunchKernelGGL(k_attn_bf16_dkv, dim3(cdiv(nk, 128), d->B * d->H), dim3(256), 2 * (2 * TILE_BYTES + 1024), s, p);
+  if (short_grid(d, nq)) hipLaunchKernelGGL((k_attn_bf16_q<true, 2>), dim3(cdiv(nq, 64), d->B * d->H), dim3(128), 4 * TILE_BYTES, s, p);
+  else hipLaunchKernelGGL((k_attn_bf16_q<true, 4>), dim3(cdiv(nq, 128), d->B * d->H), dim3(256), 4 * TILE_BYTES, s, p);
+  if (short_grid(d, nk)) hipLaunchKernelGGL((k_attn_bf16_dkv<2>), dim3(cdiv(nk, 64), d->B * d->H), dim3(128), 2 * (2 * TILE_BYTES + 1024), s, p);
+  else hipLaunchKernelGGL((k_attn_bf16_dkv<4>), dim3(cdiv(nk, 128), d->B * d->H), dim3(256), 2 * (2 * TILE_BYTES + 1024), s, p);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }
