@@ -23,6 +23,16 @@ SHAPES = [  # (M, N, K, out_dtype, label)
 ]
 
 
+if os.environ.get("SHAPES") == "small":
+    SHAPES = [
+        (4096, 64, 1024, torch.bfloat16, "lora T fwd"),
+        (4096, 1024, 64, torch.bfloat16, "lora dgrad"),
+        (4096, 256, 1024, torch.bfloat16, "head 256"),
+        (2048, 256, 1024, torch.bfloat16, "head 2048x256"),
+        (8192, 256, 256, torch.bfloat16, "head 8192x256"),
+    ]
+
+
 def timeit(fn, iters=20):
     for _ in range(3):
         fn()

@@ -28,6 +28,7 @@ __device__ __forceinline__ void glds4(const void* g, void* l) {
 }
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 // stage one [64 x 64] bf16 tile: sequence positions s0..s0+63 of image b (clamped), columns col0..col0+63
 template <int NW = 4>
 __device__ __forceinline__ void stage_tile(const bf16_t* base, long ld, int col0, int b, int s0, int n, int n_main, int B, char* tile,
@@ -327,13 +328,17 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
     if (!DQ) {
       // ---- online softmax over this lane's 32 keys of the tile (the other 32 live in lane ^ 32)
       float mx = -INFINITY;
+      if (tail) {  asm volatile("" ::: "memory");  // keeps this a real branch; wave-uniform: only the ragged last tile pays for the key mask
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (t * TROWS + kb * 32 + acc_row(r, h) >= nk) sacc[kb][r] = -INFINITY;
+      }
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (tail && (t * TROWS + kb * 32 + acc_row(r, h) >= nk)) sacc[kb][r] = -INFINITY;
-          mx = fmaxf(mx, sacc[kb][r]);
-        }
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       // lazy rescale: the reference maximum m only moves when the tile maximum exceeds it by more than 2^8 in the exp2
       // domain (p <= 256 stays exact enough in bf16 / fp32 sums); after the first tiles the 32 accumulator rescales and
@@ -342,16 +347,21 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
       const float mn = need ? mx : m;
       const float alpha = need ? __builtin_amdgcn_exp2f((m - mn) * c) : 1.0f;
       const float mnc = mn * c;
-      float rs = 0.f;
+      // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): two scores per VALU issue around the exp
+      const f32x2 c2 = {c, c}, mnc2 = {mnc, mnc};
+      f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -mnc));
-          sacc[kb][r] = pv;
-          rs += pv;
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 sv = {sacc[kb][r], sacc[kb][r + 1]};
+          const f32x2 x = sv * c2 - mnc2;
+          const f32x2 pv = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+          sacc[kb][r] = pv[0];
+          sacc[kb][r + 1] = pv[1];
+          rs2 += pv;
         }
-      l = l * alpha + rs;
+      l = l * alpha + (rs2[0] + rs2[1]);
       m = mn;
       if (__ballot(alpha != 1.0f) != 0ull) {  // the running maximum settles after the first tiles: skip the 32 rescales
 #pragma unroll
@@ -370,10 +380,16 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -lse_l));
-          if (tail && (t * TROWS + kb * 32 + acc_row(r, h) >= nk)) pv = 0.f;
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -lse_l));
           sacc[kb][r] = pv * (dpacc[kb][r] - delta_l);
         }
+      if (tail) {  asm volatile("" ::: "memory");  // keeps this a real branch; wave-uniform: clamped duplicate keys of the ragged last tile contribute nothing
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (t * TROWS + kb * 32 + acc_row(r, h) >= nk) sacc[kb][r] = 0.f;
+      }
     }
     // ---- second product: acc^T[col, query] += tile^T[col x key] * X[key x query]
     const char* t2 = DQ ? kt : vt;
@@ -492,11 +508,15 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          float pv = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -lsv[e] * LOG2E));
-          if (tail && (t * TROWS + qb * 32 + acc_row(r, h) >= nq)) pv = 0.f;
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -lsv[e] * LOG2E));
           pacc[r] = pv;
           sacc[r] = pv * (dpacc[r] - dlv[e]);
         }
+      }
+      if (tail) {  asm volatile("" ::: "memory");  // keeps this a real branch; wave-uniform: clamped duplicate queries of the ragged last tile contribute nothing
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t * TROWS + qb * 32 + acc_row(r, h) >= nq) pacc[r] = 0.f, sacc[r] = 0.f;
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {

@@ -307,7 +307,13 @@ static void launch_skinny(const vfm_gemm_desc* d, hipStream_t s) {
 static int g_force_cfg = -1;
 static int g_split_tail = 1;
 static int g_fold_tail = 1;  // run the tail rows as extra blocks of the tile kernel's launch
-static int g_use_pp = 3;  // bit 0: 256x256 ping-pong kernel instead of config 16; bit 1: 128x128 ping-pong kernel (gemm_pp.hip)
+// bit 0: 256x256 ping-pong kernel instead of config 16; bit 1: 128x128 ping-pong kernel (gemm_pp.hip); bit 3: N >= 2048 stays
+// on the 128x128 tiles; bit 4: whole waves of 256x256 tiles go to the 8-wave 64-wide-K-tile kernel (gemm_w4.hip).
+// Default 8: measured inside the train step (bench.py --tune gemm_use_pp=...) the 128x128 / 8-wave / 2-blocks-per-CU kernel
+// wins on every shape of the path - its co-resident blocks overlap one tile's epilogue traffic (fc1 writes 64 MB per call)
+// with another tile's main loop, which a one-block-per-CU kernel cannot; the big-tile kernels win on long-K / light-epilogue
+// shapes (4096^3: 1.26 PF vs 0.97) and stay selectable per call (vfm_tune gemm_cfg 30..33).
+static int g_use_pp = 8;
 extern "C" int vfm_tune(const char* key, int value) {
   if (key && strcmp(key, "gemm_cfg") == 0) {
     g_force_cfg = value;
@@ -353,6 +359,7 @@ static bool vec_ok(const vfm_gemm_desc* d) {
 static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail = nullptr, bool* folded = nullptr);
 bool vfm_gemm_launch_pp256(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail);  // gemm_pp.hip
 bool vfm_gemm_launch_pp128(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail);  // gemm_pp.hip
+bool vfm_gemm_launch_w4(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail, int waves);  // gemm_w4.hip
 
 int vfm_gemm_bf16_impl(const vfm_gemm_desc* d0, hipStream_t s) {
   // A few rows past a 128-row boundary (M = B*1024 patch tokens + B [cls] tokens) would cost a whole extra row of
@@ -408,6 +415,9 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
     else if (t128 <= 160) cfg = 18;                                  // small problems: 64x128 tiles fill more CUs
     else if ((g_use_pp & 2) && t128 > 160 && t128 <= 272 && d->K >= 256 && (d->M + 128) * d->sa_m < (1l << 31) && (d->N + 128) * d->sb_n < (1l << 31))
       cfg = 31;  // about one 128x128 tile per CU: the ping-pong kernel (one block per CU, 4-slot DMA ring)
+    else if ((g_use_pp & 16) && d->N >= 2048 && (t256 % 256 == 0 || t256 >= 768) && d->K >= 128 && (d->M + 256) * d->sa_m < (1l << 31) &&
+             (d->N + 256) * d->sb_n < (1l << 31))
+      cfg = 33;  // whole waves of 256x256 tiles: 8 waves, 64-wide K-tiles (whole-line LDS-DMA), 5-chunk ring
     else if (d->N >= 2048 && (t256 % 256 == 0 || t256 >= 768) && !(g_use_pp & 8))
       cfg = ((g_use_pp & 1) && d->K >= 128 && (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31)) ? 30 : 16;  // 256x256 tiles
     else cfg = 17;                                                   // 128x128, 8 waves, 2 blocks per CU
@@ -438,9 +448,20 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
     case 22: fd = launch_cfg<256, 128, 4, 4, 2>(d, s, vec, tail); break;
     case 23: fd = launch_cfg<128, 128, 4, 4, 3>(d, s, vec, tail); break;
     case 24: fd = launch_cfg<128, 128, 4, 4, 2>(d, s, vec, tail); break;
+    case 25: fd = launch_cfg<64, 128, 2, 2, 4>(d, s, vec, tail); break;
+    case 26: fd = launch_cfg<32, 64, 1, 2, 4>(d, s, vec, tail); break;
+    case 27: fd = launch_cfg<32, 128, 1, 4, 4>(d, s, vec, tail); break;
+    case 28: fd = launch_cfg<64, 64, 2, 2, 6>(d, s, vec, tail); break;
+    case 29: fd = launch_cfg<32, 64, 1, 2, 8>(d, s, vec, tail); break;
     case 31:
       VFM_CHECK(d->K >= 256, VFM_E_UNSUPPORTED, "vfm_gemm(bf16): the 128x128 ping-pong kernel needs K >= 256");
       fd = vfm_gemm_launch_pp128(d, s, vec, tail);
+      break;
+    case 32:
+    case 33:
+      VFM_CHECK(d->K >= 128 && d->K % 64 == 0 && (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31), VFM_E_UNSUPPORTED,
+                "vfm_gemm(bf16): the 4-wave 256x256 kernel needs K >= 128 and operands spanning < 4 GiB");
+      fd = vfm_gemm_launch_w4(d, s, vec, tail, cfg == 32 ? 4 : 8);
       break;
     case 30:
       VFM_CHECK(d->K >= 128, VFM_E_UNSUPPORTED, "vfm_gemm(bf16): the ping-pong kernel needs K >= 128");

@@ -1,0 +1,224 @@
+// Large-wave-tile bf16 MFMA GEMM for gfx950:  C[M,N] = epilogue(alpha * A[M,K] * B[N,K]^T), 256 x 256 tiles, 4 waves.
+//
+// Why another tile kernel: the LDS pipe moves 128 B/clk/CU and one ds_read_b128 of a wave is 1 KiB = 8 clk, while one
+// 32x32x16 MFMA keeps a SIMD's matrix pipe busy for 32 clk.  A wave tile of (MI x NI) 32x32 blocks reads MI + NI fragments
+// for MI * NI MFMAs per 16-wide k-step, so with all four SIMDs busy the LDS pipe is loaded to
+//     4 SIMDs * (MI + NI) * 8 clk / (MI * NI * 32 clk)   (+ the LDS-DMA writes of the operands themselves, 1/8 .. 1/4)
+// = 150 % for the 64x32 wave tiles of the 128x128 kernel, 75 % for 128x64 (ping-pong kernel) and 50 % for the 128x128
+// wave tile used here: one wave per SIMD, 16 MFMAs per k-step, the 256-register accumulator in AGPRs.
+//
+// Operand staging: K-tiles of 64, i.e. 128-byte rows, so that every LDS-DMA request is a whole cache line.  (Measured: the
+// same bytes requested as 64-B half lines - 32-wide K-tiles - stream at 54-58 GB/s per CU from L2, as whole lines at
+// ~100 GB/s; a 256 x 256 tile needs 32 B per matrix-pipe clock, which the half-line form cannot deliver.)
+// LDS: ring of five 32-KiB chunk slots (160 KiB); chunk c = 2u -> B rows of K-tile u, c = 2u+1 -> A rows, at slot c % 5.
+// A chunk is 256 rows x 128 B; 16-B piece p of row r is stored at p ^ ((r>>1)&7) (applied to the DMA SOURCE address and to
+// the fragment reads).  Wave w moves pieces 8w .. 8w+7 (8 rows each) of a chunk: 8 global_load_lds_dwordx4.
+//
+// Schedule (iteration v = K-tile v = four k-steps of 16 MFMAs; fragments double-buffered per k-step; chunks are issued in
+// chunk order, four DMA instructions per k-step):
+//     step 0: MFMAs (v,s0) | reads (v,s1)   | DMA chunk 2v+3 [4..7]
+//     step 1: MFMAs (v,s1) | reads (v,s2)   | DMA chunk 2v+4 [0..3]
+//     step 2: MFMAs (v,s2) | reads (v,s3)   | DMA chunk 2v+4 [4..7]
+//     beta_v: lgkmcnt(0) (all of K-tile v has been read), vmcnt(8) (chunks <= 2v+3 = K-tile v+1 landed), s_barrier
+//     step 3: MFMAs (v,s3) | reads (v+1,s0) | DMA chunk 2v+5 [0..3]
+// RAW: K-tile v+1 is first read in step 3, behind beta_v.  WAR: chunks 2v+5 / 2v+6 replace chunks 2v / 2v+1 (K-tile v) and are
+// issued after beta_v.  Every memory instruction sits between two MFMAs: the matrix pipe never waits for an issue.
+#include "gemm_dev.h"
+
+namespace {
+constexpr int W4_CH = 32768;
+constexpr int W4_NCH = 5;
+constexpr int W4_RING = W4_NCH * W4_CH;               // 160 KiB
+constexpr int W4_EPI_BYTES = 8 * 64 * (64 + 4) * 4;  // per wave: two 32-row slabs of a 64-row half of its tile (8-wave form is larger)
+constexpr int W4_SMEM = W4_EPI_BYTES > W4_RING ? W4_EPI_BYTES : W4_RING;
+}  // namespace
+
+// NI = 32-column blocks per wave: 4 -> 4 waves (2 x 2, 128 x 128 wave tiles, AGPR accumulator, one wave per SIMD);
+//                                 2 -> 8 waves (2 x 4, 128 x 64 wave tiles, two waves per SIMD: one issues its LDS-DMA - ~60 clk
+//                                      of issue per piece - while the other one feeds the matrix pipe)
+template <bool VEC, int NI, int DBG = 0>
+__global__ void __launch_bounds__(1024 / NI)
+    k_gemm_w4(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, long M, long N, long K, long stride_a,
+              long stride_b, long stride_c, int tiles_m, int tiles_n, EpiParams e, SkinnyTail sk) {
+  constexpr int BM = 256, BN = 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (NI == 2) {  // 8 waves: the tail rows of M run as extra blocks at the end of the grid
+    if (sk.nblk > 0 && (int)blockIdx.x >= tiles_m * tiles_n) {
+      skinny_tile(sk.A, sk.lda, B, ldb, sk.M, N, K, (long)((int)blockIdx.x - tiles_m * tiles_n) * 32, sk.e, 0, smem);
+      return;
+    }
+  }
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int WAVES = 16 / NI, WN_W = 8 / NI, PPC = 32 / WAVES, PPS = PPC / 2;  // DMA pieces per wave: per chunk, per k-step
+  const int wm = wave / WN_W, wn = wave % WN_W;
+
+  // ---- XCD-aware tile mapping (same as k_gemm_bf16)
+  const int ntiles = tiles_m * tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GM = 8;
+  const int group = bid / (GM * tiles_n);
+  const int first_m = group * GM;
+  const int gsz = min(tiles_m - first_m, GM);
+  const int tm = first_m + (bid % (GM * tiles_n)) % gsz;
+  const int tn = (bid % (GM * tiles_n)) / gsz;
+  const long m0 = (long)tm * BM, n0 = (long)tn * BN;
+  const long z = blockIdx.y;
+  const bf16_t* Ab = A + z * stride_a;
+  const bf16_t* Bb = B + z * stride_b;
+
+  // ---- per-lane DMA sources (32-bit byte offsets from the scalar matrix base; the dispatcher checks the span < 4 GiB)
+  unsigned soff[2][PPC];  // [0: B, 1: A][piece]
+#pragma unroll
+  for (int j = 0; j < PPC; ++j) {
+    const int r = (wave * PPC + j) * 8 + (lane >> 3);
+    const int sw = ((lane & 7) ^ ((r >> 1) & 7)) << 3;
+    long gm = m0 + r, gn = n0 + r;
+    if (gm > M - 1) gm = M - 1;
+    if (gn > N - 1) gn = N - 1;
+    soff[0][j] = (unsigned)((gn * ldb + sw) * 2);
+    soff[1][j] = (unsigned)((gm * lda + sw) * 2);
+  }
+  auto dma = [&](auto Cc, auto Jc, int u, int pos) {  // piece J of chunk type C (0 B, 1 A) of K-tile u -> chunk slot pos
+    constexpr int c = decltype(Cc)::value, j = decltype(Jc)::value;
+    char* dst = smem + pos * W4_CH + (wave * PPC + j) * 1024;
+    const unsigned long long bv = (unsigned long long)(c ? Ab : Bb) + (unsigned long long)u * 128;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)bv), hi = __builtin_amdgcn_readfirstlane((unsigned)(bv >> 32));
+    const char* base = (const char*)(((unsigned long long)hi << 32) | lo);  // pinned to SGPRs
+    glds16(base + soff[c][j], dst);
+  };
+  auto dma_half = [&](auto Cc, auto Hc, int u, int pos) {  // half H of this wave's pieces of a chunk
+    constexpr int j0 = decltype(Hc)::value * PPS;
+    dma(Cc, IC<j0>{}, u, pos), dma(Cc, IC<j0 + 1>{}, u, pos);
+    if constexpr (PPS == 4) dma(Cc, IC<j0 + 2>{}, u, pos), dma(Cc, IC<j0 + 3>{}, u, pos);
+  };
+
+  f32x16 acc[2][2][NI];  // [half h][i][j]: rows wm*128 + (2h+i)*32, columns wn*NI*32 + j*32
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  // fragment read offsets inside a chunk (bytes): row * 128 + swizzled 16-B piece; [s] = k-step inside the K-tile
+  int ra[4], rb[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int kx = ((2 * s + fh) ^ ((fr >> 1) & 7)) << 4;
+    ra[s] = (wm * 128 + fr) * 128 + kx;
+    rb[s] = (wn * NI * 32 + fr) * 128 + kx;
+  }
+  const int nk = (int)(K / 64);  // >= 2 (checked by the dispatcher)
+  bf16x8 fa[2][4], fb[2][NI];    // [buffer][block]
+
+  // one k-step: 16 MFMAs on buffer CUR; between them the 8 fragment reads of the next k-step (READ: k-step rs of the chunks
+  // at slots pb / pa) and 4 DMA pieces (ISSUE: pieces J0.. of chunk type CH of K-tile u into slot dpos)
+  auto kstep = [&](auto CURc, auto READc, auto ISSUEc, auto CHc, auto Hc, int pb_slot, int pa_slot, auto RSc, int u, int dpos) {
+    constexpr int cur = decltype(CURc)::value, nxt = cur ^ 1, ch = decltype(CHc)::value, j0 = decltype(Hc)::value * PPS;
+    constexpr int rs = decltype(RSc)::value;
+    constexpr bool READ = decltype(READc)::value, ISSUE = decltype(ISSUEc)::value;
+    const char* pa = smem + pa_slot * W4_CH + ra[rs];
+    const char* pb = smem + pb_slot * W4_CH + rb[rs];
+    auto one = [&](auto Mc) {
+      constexpr int m = decltype(Mc)::value, i4 = m / NI, j = m % NI;
+      acc[i4 >> 1][i4 & 1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i4], fb[cur][j], acc[i4 >> 1][i4 & 1][j], 0, 0, 0);
+      if constexpr (READ && m < 4) fa[nxt][m] = *reinterpret_cast<const bf16x8*>(pa + m * 4096);
+      if constexpr (READ && m >= 4 && m < 4 + NI) fb[nxt][m - 4] = *reinterpret_cast<const bf16x8*>(pb + (m - 4) * 4096);
+      if constexpr (ISSUE && m >= 4 + NI && m < 4 + NI + PPS) dma(IC<ch>{}, IC<j0 + m - 4 - NI>{}, u, dpos);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    one(IC<0>{}), one(IC<1>{}), one(IC<2>{}), one(IC<3>{}), one(IC<4>{}), one(IC<5>{}), one(IC<6>{}), one(IC<7>{});
+    if constexpr (NI == 4) one(IC<8>{}), one(IC<9>{}), one(IC<10>{}), one(IC<11>{}), one(IC<12>{}), one(IC<13>{}), one(IC<14>{}), one(IC<15>{});
+  };
+  auto wrap = [](int p) { return p >= W4_NCH ? p - W4_NCH : p; };
+  // X: 0 steady (v <= nk-3); 1 = last but one K-tile (only chunk 2nk-1 [4..7] left to issue); 2 = last K-tile
+  auto iter = [&](auto Xc, int v, int q) {  // q = slot of chunk 2v
+    constexpr int X = decltype(Xc)::value;
+    const int q1 = wrap(q + 1), q2 = wrap(q + 2), q3 = wrap(q + 3), q4 = wrap(q + 4);
+    kstep(IC<0>{}, IC<true>{}, IC<(X <= 1)>{}, IC<1>{}, IC<1>{}, q, q1, IC<1>{}, v + 1, q3);
+    kstep(IC<1>{}, IC<true>{}, IC<(X == 0)>{}, IC<0>{}, IC<0>{}, q, q1, IC<2>{}, v + 2, q4);
+    kstep(IC<0>{}, IC<true>{}, IC<(X == 0)>{}, IC<0>{}, IC<1>{}, q, q1, IC<3>{}, v + 2, q4);
+    if constexpr (X != 2) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+      if constexpr (X == 0) wait_vmcnt<PPC>();
+      if constexpr (X == 1) wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    kstep(IC<1>{}, IC<(X != 2)>{}, IC<(X == 0)>{}, IC<1>{}, IC<0>{}, q2, q3, IC<0>{}, v + 2, q);
+  };
+
+  // ---- prologue: chunks 0, 1, 2 and the first half of chunk 3 in flight; K-tile 0 landed; fragments of (0, s0)
+  dma_half(IC<0>{}, IC<0>{}, 0, 0), dma_half(IC<0>{}, IC<1>{}, 0, 0);
+  dma_half(IC<1>{}, IC<0>{}, 0, 1), dma_half(IC<1>{}, IC<1>{}, 0, 1);
+  dma_half(IC<0>{}, IC<0>{}, 1, 2), dma_half(IC<0>{}, IC<1>{}, 1, 2);
+  dma_half(IC<1>{}, IC<0>{}, 1, 3);
+  wait_vmcnt<PPC + PPS>();
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + W4_CH + ra[0] + i * 4096);
+#pragma unroll
+  for (int j = 0; j < NI; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(smem + rb[0] + j * 4096);
+  __builtin_amdgcn_sched_barrier(0);
+
+  int v = 0, q = 0;
+  for (; v < nk - 2; ++v) {
+    iter(IC<0>{}, v, q);
+    q = wrap(q + 2);
+  }
+  iter(IC<1>{}, v, q);
+  iter(IC<2>{}, v + 1, wrap(q + 2));
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- epilogue (accumulators -> per-wave fp32 LDS image -> 16-byte rows), one 64-row half of the wave tile at a time
+  const long zoff = z * stride_c;
+  if constexpr (DBG & 1) return;
+  __syncthreads();
+  float* img = reinterpret_cast<float*>(smem) + wave * 64 * (NI * 32 + 4);
+  const long mw = m0 + wm * 128, nw = n0 + wn * NI * 32;
+  if constexpr (VEC) {
+    epi_wave_tile<2, NI, 2>(e, zoff, acc[0], img, lane, mw, nw, M, N);
+    epi_wave_tile<2, NI, 2>(e, zoff, acc[1], img, lane, mw + 64, nw, M, N);
+  } else {
+    epi_scalar<2, NI, 2>(e, zoff, acc[0], img, lane, mw, nw, M, N);
+    epi_scalar<2, NI, 2>(e, zoff, acc[1], img, lane, mw + 64, nw, M, N);
+  }
+}
+
+extern int g_pp_dbg;
+template <bool VEC, int NI, int DBG>
+static bool launch_w4_t(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail) {
+  const int tiles_m = cdiv(d->M, 256), tiles_n = cdiv(d->N, 256);
+  const long batch = d->batch > 0 ? d->batch : 1;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_gemm_w4<VEC, NI, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_SMEM);
+    attr = true;
+  }
+  SkinnyTail sk;
+  sk.nblk = 0;
+  const bool fold = tail && batch == 1 && NI == 2;
+  if (fold) sk.A = (const bf16_t*)tail->A, sk.lda = tail->sa_m, sk.M = tail->M, sk.nblk = cdiv(tail->N, 32), sk.e = make_epi(tail);
+  hipLaunchKernelGGL((k_gemm_w4<VEC, NI, DBG>), dim3(tiles_m * tiles_n + sk.nblk, (unsigned)batch), dim3(1024 / NI), W4_SMEM, s,
+                     (const bf16_t*)d->A, d->sa_m, (const bf16_t*)d->B, d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c,
+                     tiles_m, tiles_n, make_epi(d), sk);
+  return fold || !tail;
+}
+// returns whether the tail rows were folded into the launch (8-wave form only; otherwise the caller runs the skinny kernel)
+bool vfm_gemm_launch_w4(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail, int waves) {
+  if (waves == 4) {
+    if (!vec) return launch_w4_t<false, 4, 0>(d, s, tail);
+    return g_pp_dbg == 1 ? launch_w4_t<true, 4, 1>(d, s, tail) : launch_w4_t<true, 4, 0>(d, s, tail);
+  }
+  if (!vec) return launch_w4_t<false, 2, 0>(d, s, tail);
+  return g_pp_dbg == 1 ? launch_w4_t<true, 2, 1>(d, s, tail) : launch_w4_t<true, 2, 0>(d, s, tail);
+}
