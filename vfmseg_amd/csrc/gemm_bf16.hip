@@ -412,6 +412,8 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
     const long t128 = (long)cdiv(d->M, 128) * cdiv(d->N, 128);
     const long t256 = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
     if (d->N <= 32) cfg = 10;                                        // 64x64 tiles: many rows, few columns
+    else if (t128 <= 160 && d->K >= 512 && (long)cdiv(d->M, 64) * cdiv(d->N, 64) <= 512)
+      cfg = 10;  // few tiles, long K (LoRA T GEMM 4096x64x1024, decoder projections): 64x64 tiles with the 4-stage ring
     else if (t128 <= 160) cfg = 18;                                  // small problems: 64x128 tiles fill more CUs
     else if ((g_use_pp & 2) && t128 > 160 && t128 <= 272 && d->K >= 256 && (d->M + 128) * d->sa_m < (1l << 31) && (d->N + 128) * d->sb_n < (1l << 31))
       cfg = 31;  // about one 128x128 tile per CU: the ping-pong kernel (one block per CU, 4-slot DMA ring)

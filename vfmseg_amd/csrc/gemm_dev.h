@@ -108,9 +108,16 @@ __device__ __forceinline__ float erf_fast(float x) {  // Abramowitz-Stegun 7.1.2
 }
 __device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_fast(float x) {
-  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return fmaf(x, pdf, cdf);
+  // Phi(x) + x phi(x): the exponential inside erf(x / sqrt 2) IS exp(-x^2 / 2), so one v_exp serves both terms
+  const float az = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+  float p = fmaf(t, 1.061405429f, -1.453152027f);
+  p = fmaf(t, p, 1.421413741f);
+  p = fmaf(t, p, -0.284496736f);
+  p = fmaf(t, p, 0.254829592f);
+  const float ex = __expf(-az * az);
+  const float erfv = copysignf(1.0f - p * t * ex, x);
+  return fmaf(x, 0.39894228040143267794f * ex, fmaf(0.5f, erfv, 0.5f));
 }
 
 // RES: 0 none, 1 fp32 residual, 2 bf16 residual.  MODE: VFM_EP_*; modes 3/4 read a bf16 aux.  CDT: dtype of C.  HASC2: bf16 copy of the
