@@ -308,12 +308,14 @@ static int g_force_cfg = -1;
 static int g_split_tail = 1;
 static int g_fold_tail = 1;  // run the tail rows as extra blocks of the tile kernel's launch
 // bit 0: 256x256 ping-pong kernel instead of config 16; bit 1: 128x128 ping-pong kernel (gemm_pp.hip); bit 3: N >= 2048 stays
-// on the 128x128 tiles; bit 4: whole waves of 256x256 tiles go to the 8-wave 64-wide-K-tile kernel (gemm_w4.hip).
-// Default 8: measured inside the train step (bench.py --tune gemm_use_pp=...) the 128x128 / 8-wave / 2-blocks-per-CU kernel
-// wins on every shape of the path - its co-resident blocks overlap one tile's epilogue traffic (fc1 writes 64 MB per call)
-// with another tile's main loop, which a one-block-per-CU kernel cannot; the big-tile kernels win on long-K / light-epilogue
-// shapes (4096^3: 1.26 PF vs 0.97) and stay selectable per call (vfm_tune gemm_cfg 30..33).
-static int g_use_pp = 8;
+// on the 128x128 tiles; bit 4: whole waves of 256x256 tiles go to the 8-wave 64-wide-K-tile kernel (gemm_w4.hip); bit 5: the
+// 128x128 tiles run through the five-chunk ring kernel (config 34) instead of the two-stage kernel (config 17).
+// Default 40, measured inside the train step (bench.py --tune gemm_use_pp=...): 128x128 tiles / 8 waves / two blocks per CU win
+// on every shape of the path - co-resident blocks overlap one tile's epilogue traffic (fc1 writes 64 MB per call) with another
+// tile's main loop, which a one-block-per-CU kernel cannot - and the 2.5-K-tile ring beats the two-stage pipeline by 5-18 %
+// per shape (+2.6 % images/s).  The big-tile kernels win on long-K / light-epilogue shapes (4096^3: 1.26 PF vs 1.0) and stay
+// selectable per call (vfm_tune gemm_cfg 30..33).
+static int g_use_pp = 40;
 extern "C" int vfm_tune(const char* key, int value) {
   if (key && strcmp(key, "gemm_cfg") == 0) {
     g_force_cfg = value;
@@ -423,6 +425,8 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
     else if (d->N >= 2048 && (t256 % 256 == 0 || t256 >= 768) && !(g_use_pp & 8))
       cfg = ((g_use_pp & 1) && d->K >= 128 && (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31)) ? 30 : 16;  // 256x256 tiles
     else cfg = 17;                                                   // 128x128, 8 waves, 2 blocks per CU
+    if (cfg == 17 && (g_use_pp & 32) && d->K >= 128 && (d->M + 128) * d->sa_m < (1l << 31) && (d->N + 128) * d->sb_n < (1l << 31))
+      cfg = 34;  // same tile and wave layout, operands through the five-chunk (2.5 K-tile) LDS-DMA ring of gemm_w4.hip
   }
   switch (cfg) {
     case 0: fd = launch_cfg<128, 128, 2, 2, 2>(d, s, vec, tail); break;
@@ -461,9 +465,10 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
       break;
     case 32:
     case 33:
+    case 34:
       VFM_CHECK(d->K >= 128 && d->K % 64 == 0 && (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31), VFM_E_UNSUPPORTED,
                 "vfm_gemm(bf16): the 4-wave 256x256 kernel needs K >= 128 and operands spanning < 4 GiB");
-      fd = vfm_gemm_launch_w4(d, s, vec, tail, cfg == 32 ? 4 : 8);
+      fd = vfm_gemm_launch_w4(d, s, vec, tail, cfg == 32 ? 4 : (cfg == 33 ? 8 : 2));
       break;
     case 30:
       VFM_CHECK(d->K >= 128, VFM_E_UNSUPPORTED, "vfm_gemm(bf16): the ping-pong kernel needs K >= 128");

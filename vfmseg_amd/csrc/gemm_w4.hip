@@ -26,23 +26,36 @@
 #include "gemm_dev.h"
 
 namespace {
-constexpr int W4_CH = 32768;
-constexpr int W4_NCH = 5;
-constexpr int W4_RING = W4_NCH * W4_CH;               // 160 KiB
-constexpr int W4_EPI_BYTES = 8 * 64 * (64 + 4) * 4;  // per wave: two 32-row slabs of a 64-row half of its tile (8-wave form is larger)
-constexpr int W4_SMEM = W4_EPI_BYTES > W4_RING ? W4_EPI_BYTES : W4_RING;
+constexpr int W4_NCH = 5;  // chunk slots in the ring
 }  // namespace
 
-// NI = 32-column blocks per wave: 4 -> 4 waves (2 x 2, 128 x 128 wave tiles, AGPR accumulator, one wave per SIMD);
-//                                 2 -> 8 waves (2 x 4, 128 x 64 wave tiles, two waves per SIMD: one issues its LDS-DMA - ~60 clk
-//                                      of issue per piece - while the other one feeds the matrix pipe)
-template <bool VEC, int NI, int DBG = 0>
-__global__ void __launch_bounds__(1024 / NI)
+// The kernel is generic in the wave tile (MI x NI blocks of 32 x 32) and the wave grid (WM_W x WN_W); the block tile is square
+// (T = WM_W * MI * 32 = WN_W * NI * 32 rows and columns) so that A and B chunks have one size (T rows x 128 B):
+//     <4, 4, 2, 2>  256 x 256, 4 waves, 128 x 128 wave tiles, AGPR accumulator, one wave per SIMD             (config 32)
+//     <4, 2, 2, 4>  256 x 256, 8 waves, 128 x 64 wave tiles, two waves per SIMD                               (config 33)
+//     <2, 1, 2, 4>  128 x 128, 8 waves, 64 x 32 wave tiles, 80-KiB ring: two blocks per CU (the layout of the 128 x 128 kernel
+//                   of gemm_bf16.hip with the 2.5-K-tile chunk ring instead of two whole-K-tile stages)       (config 34)
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(IC<N - 1>{});
+  }
+}
+
+template <bool VEC, int MI, int NI, int WM_W, int WN_W, int DBG = 0>
+__global__ void __launch_bounds__(WM_W* WN_W * 64)
     k_gemm_w4(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, long M, long N, long K, long stride_a,
               long stride_b, long stride_c, int tiles_m, int tiles_n, EpiParams e, SkinnyTail sk) {
-  constexpr int BM = 256, BN = 256;
+  constexpr int T = WM_W * MI * 32;
+  static_assert(T == WN_W * NI * 32 && MI % 2 == 0, "square block tile, wave tile of 64-row halves");
+  constexpr int WAVES = WM_W * WN_W;
+  constexpr int CH = T * 128;                        // bytes per chunk (T rows x one 128-B K-tile row)
+  constexpr int PPC = T / 8 / WAVES, PPS = PPC / 2;  // DMA pieces per wave: per chunk, per k-step
+  static_assert(PPC >= 2 && PPC % 2 == 0, "a wave moves whole halves of a chunk");
+  constexpr int NMF = MI * NI, NRD = MI + NI, NOPS = NRD + PPS;  // per k-step: MFMAs, fragment reads, memory ops
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if constexpr (NI == 2) {  // 8 waves: the tail rows of M run as extra blocks at the end of the grid
+  if constexpr (WAVES == 8 && 5 * CH >= 65536) {  // the tail rows of M run as extra blocks at the end of the grid
     if (sk.nblk > 0 && (int)blockIdx.x >= tiles_m * tiles_n) {
       skinny_tile(sk.A, sk.lda, B, ldb, sk.M, N, K, (long)((int)blockIdx.x - tiles_m * tiles_n) * 32, sk.e, 0, smem);
       return;
@@ -50,7 +63,6 @@ __global__ void __launch_bounds__(1024 / NI)
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int WAVES = 16 / NI, WN_W = 8 / NI, PPC = 32 / WAVES, PPS = PPC / 2;  // DMA pieces per wave: per chunk, per k-step
   const int wm = wave / WN_W, wn = wave % WN_W;
 
   // ---- XCD-aware tile mapping (same as k_gemm_bf16)
@@ -66,7 +78,7 @@ __global__ void __launch_bounds__(1024 / NI)
   const int gsz = min(tiles_m - first_m, GM);
   const int tm = first_m + (bid % (GM * tiles_n)) % gsz;
   const int tn = (bid % (GM * tiles_n)) / gsz;
-  const long m0 = (long)tm * BM, n0 = (long)tn * BN;
+  const long m0 = (long)tm * T, n0 = (long)tn * T;
   const long z = blockIdx.y;
   const bf16_t* Ab = A + z * stride_a;
   const bf16_t* Bb = B + z * stride_b;
@@ -85,7 +97,7 @@ __global__ void __launch_bounds__(1024 / NI)
   }
   auto dma = [&](auto Cc, auto Jc, int u, int pos) {  // piece J of chunk type C (0 B, 1 A) of K-tile u -> chunk slot pos
     constexpr int c = decltype(Cc)::value, j = decltype(Jc)::value;
-    char* dst = smem + pos * W4_CH + (wave * PPC + j) * 1024;
+    char* dst = smem + pos * CH + (wave * PPC + j) * 1024;
     const unsigned long long bv = (unsigned long long)(c ? Ab : Bb) + (unsigned long long)u * 128;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)bv), hi = __builtin_amdgcn_readfirstlane((unsigned)(bv >> 32));
     const char* base = (const char*)(((unsigned long long)hi << 32) | lo);  // pinned to SGPRs
@@ -93,13 +105,12 @@ __global__ void __launch_bounds__(1024 / NI)
   };
   auto dma_half = [&](auto Cc, auto Hc, int u, int pos) {  // half H of this wave's pieces of a chunk
     constexpr int j0 = decltype(Hc)::value * PPS;
-    dma(Cc, IC<j0>{}, u, pos), dma(Cc, IC<j0 + 1>{}, u, pos);
-    if constexpr (PPS == 4) dma(Cc, IC<j0 + 2>{}, u, pos), dma(Cc, IC<j0 + 3>{}, u, pos);
+    static_for<PPS>([&](auto Jc) { dma(Cc, IC<j0 + decltype(Jc)::value>{}, u, pos); });
   };
 
-  f32x16 acc[2][2][NI];  // [half h][i][j]: rows wm*128 + (2h+i)*32, columns wn*NI*32 + j*32
+  f32x16 acc[MI / 2][2][NI];  // [half h][i][j]: rows wm*MI*32 + (2h+i)*32, columns wn*NI*32 + j*32
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+  for (int h = 0; h < MI / 2; ++h)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -113,33 +124,42 @@ __global__ void __launch_bounds__(1024 / NI)
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int kx = ((2 * s + fh) ^ ((fr >> 1) & 7)) << 4;
-    ra[s] = (wm * 128 + fr) * 128 + kx;
+    ra[s] = (wm * MI * 32 + fr) * 128 + kx;
     rb[s] = (wn * NI * 32 + fr) * 128 + kx;
   }
   const int nk = (int)(K / 64);  // >= 2 (checked by the dispatcher)
-  bf16x8 fa[2][4], fb[2][NI];    // [buffer][block]
+  bf16x8 fa[2][MI], fb[2][NI];   // [buffer][block]
 
-  // one k-step: 16 MFMAs on buffer CUR; between them the 8 fragment reads of the next k-step (READ: k-step rs of the chunks
-  // at slots pb / pa) and 4 DMA pieces (ISSUE: pieces J0.. of chunk type CH of K-tile u into slot dpos)
+  // one k-step: NMF MFMAs on buffer CUR; spread between them the fragment reads of the next k-step (READ: k-step rs of the
+  // chunks at slots pb / pa) and PPS DMA pieces (ISSUE: half H of chunk type CH of K-tile u into slot dpos)
   auto kstep = [&](auto CURc, auto READc, auto ISSUEc, auto CHc, auto Hc, int pb_slot, int pa_slot, auto RSc, int u, int dpos) {
     constexpr int cur = decltype(CURc)::value, nxt = cur ^ 1, ch = decltype(CHc)::value, j0 = decltype(Hc)::value * PPS;
     constexpr int rs = decltype(RSc)::value;
     constexpr bool READ = decltype(READc)::value, ISSUE = decltype(ISSUEc)::value;
-    const char* pa = smem + pa_slot * W4_CH + ra[rs];
-    const char* pb = smem + pb_slot * W4_CH + rb[rs];
-    auto one = [&](auto Mc) {
+    const char* pa = smem + pa_slot * CH + ra[rs];
+    const char* pb = smem + pb_slot * CH + rb[rs];
+    auto memop = [&](auto Kc) {  // memory op k of the step: MI A reads, NI B reads, PPS DMA pieces
+      constexpr int k = decltype(Kc)::value;
+      if constexpr (k < MI) {
+        if constexpr (READ) fa[nxt][k] = *reinterpret_cast<const bf16x8*>(pa + k * 4096);
+      } else if constexpr (k < NRD) {
+        if constexpr (READ) fb[nxt][k - MI] = *reinterpret_cast<const bf16x8*>(pb + (k - MI) * 4096);
+      } else {
+        if constexpr (ISSUE && !(DBG & 2)) dma(IC<ch>{}, IC<j0 + k - NRD>{}, u, dpos);
+      }
+    };
+    static_for<NMF>([&](auto Mc) {
       constexpr int m = decltype(Mc)::value, i4 = m / NI, j = m % NI;
       acc[i4 >> 1][i4 & 1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i4], fb[cur][j], acc[i4 >> 1][i4 & 1][j], 0, 0, 0);
-      if constexpr (READ && m < 4) fa[nxt][m] = *reinterpret_cast<const bf16x8*>(pa + m * 4096);
-      if constexpr (READ && m >= 4 && m < 4 + NI) fb[nxt][m - 4] = *reinterpret_cast<const bf16x8*>(pb + (m - 4) * 4096);
-      if constexpr (ISSUE && m >= 4 + NI && m < 4 + NI + PPS) dma(IC<ch>{}, IC<j0 + m - 4 - NI>{}, u, dpos);
+      // memory op k goes behind MFMA floor(k * NMF / NOPS): one per gap where there are more MFMAs than ops
+      static_for<NOPS>([&](auto Kc) {
+        if constexpr (decltype(Kc)::value * NMF / NOPS == m) memop(Kc);
+      });
       __builtin_amdgcn_sched_barrier(0);
-    };
-    one(IC<0>{}), one(IC<1>{}), one(IC<2>{}), one(IC<3>{}), one(IC<4>{}), one(IC<5>{}), one(IC<6>{}), one(IC<7>{});
-    if constexpr (NI == 4) one(IC<8>{}), one(IC<9>{}), one(IC<10>{}), one(IC<11>{}), one(IC<12>{}), one(IC<13>{}), one(IC<14>{}), one(IC<15>{});
+    });
   };
   auto wrap = [](int p) { return p >= W4_NCH ? p - W4_NCH : p; };
-  // X: 0 steady (v <= nk-3); 1 = last but one K-tile (only chunk 2nk-1 [4..7] left to issue); 2 = last K-tile
+  // X: 0 steady (v <= nk-3); 1 = last but one K-tile (only the second half of chunk 2nk-1 left to issue); 2 = last K-tile
   auto iter = [&](auto Xc, int v, int q) {  // q = slot of chunk 2v
     constexpr int X = decltype(Xc)::value;
     const int q1 = wrap(q + 1), q2 = wrap(q + 2), q3 = wrap(q + 3), q4 = wrap(q + 4);
@@ -165,7 +185,7 @@ __global__ void __launch_bounds__(1024 / NI)
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + W4_CH + ra[0] + i * 4096);
+  for (int i = 0; i < MI; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + CH + ra[0] + i * 4096);
 #pragma unroll
   for (int j = 0; j < NI; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(smem + rb[0] + j * 4096);
   __builtin_amdgcn_sched_barrier(0);
@@ -184,41 +204,46 @@ __global__ void __launch_bounds__(1024 / NI)
   if constexpr (DBG & 1) return;
   __syncthreads();
   float* img = reinterpret_cast<float*>(smem) + wave * 64 * (NI * 32 + 4);
-  const long mw = m0 + wm * 128, nw = n0 + wn * NI * 32;
-  if constexpr (VEC) {
-    epi_wave_tile<2, NI, 2>(e, zoff, acc[0], img, lane, mw, nw, M, N);
-    epi_wave_tile<2, NI, 2>(e, zoff, acc[1], img, lane, mw + 64, nw, M, N);
-  } else {
-    epi_scalar<2, NI, 2>(e, zoff, acc[0], img, lane, mw, nw, M, N);
-    epi_scalar<2, NI, 2>(e, zoff, acc[1], img, lane, mw + 64, nw, M, N);
-  }
+  const long mw = m0 + wm * MI * 32, nw = n0 + wn * NI * 32;
+  static_for<MI / 2>([&](auto Hc) {
+    constexpr int h = decltype(Hc)::value;
+    if constexpr (VEC) epi_wave_tile<2, NI, 2>(e, zoff, acc[h], img, lane, mw + h * 64, nw, M, N);
+    else epi_scalar<2, NI, 2>(e, zoff, acc[h], img, lane, mw + h * 64, nw, M, N);
+  });
 }
 
 extern int g_pp_dbg;
-template <bool VEC, int NI, int DBG>
+template <bool VEC, int MI, int NI, int WM_W, int WN_W, int DBG>
 static bool launch_w4_t(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail) {
-  const int tiles_m = cdiv(d->M, 256), tiles_n = cdiv(d->N, 256);
+  constexpr int T = WM_W * MI * 32, WAVES = WM_W * WN_W;
+  constexpr int RING = W4_NCH * T * 128, EPI = WAVES * 64 * (NI * 32 + 4) * 4, SMEM = RING > EPI ? RING : EPI;
+  const int tiles_m = cdiv(d->M, T), tiles_n = cdiv(d->N, T);
   const long batch = d->batch > 0 ? d->batch : 1;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_gemm_w4<VEC, NI, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, W4_SMEM);
+    (void)hipFuncSetAttribute((const void*)k_gemm_w4<VEC, MI, NI, WM_W, WN_W, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr = true;
   }
   SkinnyTail sk;
   sk.nblk = 0;
-  const bool fold = tail && batch == 1 && NI == 2;
+  const bool fold = tail && batch == 1 && WAVES == 8 && RING >= 65536;
   if (fold) sk.A = (const bf16_t*)tail->A, sk.lda = tail->sa_m, sk.M = tail->M, sk.nblk = cdiv(tail->N, 32), sk.e = make_epi(tail);
-  hipLaunchKernelGGL((k_gemm_w4<VEC, NI, DBG>), dim3(tiles_m * tiles_n + sk.nblk, (unsigned)batch), dim3(1024 / NI), W4_SMEM, s,
+  hipLaunchKernelGGL((k_gemm_w4<VEC, MI, NI, WM_W, WN_W, DBG>), dim3(tiles_m * tiles_n + sk.nblk, (unsigned)batch), dim3(WAVES * 64), SMEM, s,
                      (const bf16_t*)d->A, d->sa_m, (const bf16_t*)d->B, d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c,
                      tiles_m, tiles_n, make_epi(d), sk);
   return fold || !tail;
 }
-// returns whether the tail rows were folded into the launch (8-wave form only; otherwise the caller runs the skinny kernel)
-bool vfm_gemm_launch_w4(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail, int waves) {
-  if (waves == 4) {
-    if (!vec) return launch_w4_t<false, 4, 0>(d, s, tail);
-    return g_pp_dbg == 1 ? launch_w4_t<true, 4, 1>(d, s, tail) : launch_w4_t<true, 4, 0>(d, s, tail);
+// form: 4 = 256x256 / 4 waves, 8 = 256x256 / 8 waves, 2 = 128x128 / 8 waves (two blocks per CU).  Returns whether the tail rows
+// were folded into the launch (8-wave forms; otherwise the caller runs the skinny kernel).
+bool vfm_gemm_launch_w4(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail, int form) {
+  if (form == 4) {
+    if (!vec) return launch_w4_t<false, 4, 4, 2, 2, 0>(d, s, tail);
+    return g_pp_dbg == 1 ? launch_w4_t<true, 4, 4, 2, 2, 1>(d, s, tail) : launch_w4_t<true, 4, 4, 2, 2, 0>(d, s, tail);
   }
-  if (!vec) return launch_w4_t<false, 2, 0>(d, s, tail);
-  return g_pp_dbg == 1 ? launch_w4_t<true, 2, 1>(d, s, tail) : launch_w4_t<true, 2, 0>(d, s, tail);
+  if (form == 8) {
+    if (!vec) return launch_w4_t<false, 4, 2, 2, 4, 0>(d, s, tail);
+    return g_pp_dbg == 1 ? launch_w4_t<true, 4, 2, 2, 4, 1>(d, s, tail) : launch_w4_t<true, 4, 2, 2, 4, 0>(d, s, tail);
+  }
+  if (!vec) return launch_w4_t<false, 2, 1, 2, 4, 0>(d, s, tail);
+  return launch_w4_t<true, 2, 1, 2, 4, 0>(d, s, tail);
 }
