@@ -210,9 +210,16 @@ def main():
         s = timer.summary()
         if s is not None:
             ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
+            traffic, traffic_src = None, None
+            tj = os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")
+            if os.path.exists(tj):  # PMC counters cannot be read from inside the timed run: committed rocprofv3 --pmc passes
+                with open(tj) as f:
+                    tr = json.load(f)
+                traffic = tr.get("mean_bytes_per_launch")
+                traffic_src = "profiles/r01_pmc_gemm_traffic.json: mean FETCH_SIZE*2 + WRITE_SIZE bytes per launch over the four backbone GEMM shapes"
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                               "kernel": "k_gemm_bf16 (all bf16 MFMA GEMM launches of the timed steps)",
+                               "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                               "kernel": "bf16 MFMA GEMM (k_gemm_w4 128x128 ring tiles + k_gemm_bf16: every GEMM launch of the timed steps)",
                                "launches_timed": s["launches"], "sampled_every": s["sampled_every"],
                                "gemm_ms_per_step_est": round(s["ms"] * s["sampled_every"] / a.steps, 3)}
         # end-to-end model-FLOP utilisation (722.4 GFLOP fwd per image-pass, train ~2.2x, 2 passes/sample)
