@@ -26,7 +26,7 @@ PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md "Peak B
 PEAK_HBM_GBS = 8000.0
 
 
-def build(device, batch, seed=0):
+def build(device, batch, seed=0, workload="ms1024"):
     import vfmseg_amd  # noqa: F401  (registers the model classes)
     from vfmseg_amd import presets
     from vfmseg_amd.optim import PEFTOptimWrapperConstructor
@@ -34,7 +34,7 @@ def build(device, batch, seed=0):
     from vfmseg_amd.synth import synth_like
 
     torch.manual_seed(seed)
-    model = MODELS.build(presets.dinov2_ms_masked())
+    model = MODELS.build(presets.dinov2_ms_masked() if workload == "ms1024" else presets.dinov2_linear())
     # random-init weights of the named architecture (no checkpoints offline): key-hashed synthetic values
     sd = synth_like(model.state_dict())
     model.load_state_dict(sd)
@@ -45,11 +45,11 @@ def build(device, batch, seed=0):
     return model, ow
 
 
-def make_batch(batch, rank, step, device):
+def make_batch(batch, rank, step, device, size=1024):
     from vfmseg_amd.segmentors import SegDataSample
     from vfmseg_amd.synth import synth_image, synth_label
-    img = synth_image(batch, 1024, seed=100 + rank).to(device)
-    lab = synth_label(batch, 1024, seed=100 + rank).to(device)
+    img = synth_image(batch, size, seed=100 + rank).to(device)
+    lab = synth_label(batch, size, seed=100 + rank).to(device)
     return dict(inputs=img, data_samples=[SegDataSample(gt_sem_seg=lab[i]) for i in range(batch)])
 
 
@@ -114,7 +114,7 @@ def cpu_baseline(seconds_cap=40.0):
     cores = max(1, min(cores, int(os.environ.get("VFMSEG_CPU_THREADS", "16"))))  # a GPU box grants a 16-core share
     torch.set_num_threads(cores)
     print(f"[bench] cpu_baseline: oracle train step on {cores} threads ...", file=sys.stderr, flush=True)
-    model = MODELS.build(presets.dinov2_ms_masked())
+    model = MODELS.build(presets.dinov2_ms_masked() if workload == "ms1024" else presets.dinov2_linear())
     sd = synth_like(model.state_dict())
     del model
     tk = R.trainable_keys(sd)
@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--workload", default="ms1024", choices=["ms1024", "single512"],
+                    help="ms1024: BASELINE configs[1] (1024^2 sample -> LR + HR 512^2 passes, both heads; the headline metric); "
+                         "single512: one 512^2 pass per sample, DINOv2-L + LoRA + LinearHead (SURVEY 8: the labelled single-pass step)")
     ap.add_argument("--tune", action="append", default=[], help="kernel tuning knob KEY=INT (vfm_tune), repeatable")
     a = ap.parse_args()
 
@@ -164,11 +167,11 @@ def main():
         k, v = kv.split("=")
         _ops.tune(k, int(v))
 
-    model, ow = build(device, a.batch)
+    model, ow = build(device, a.batch, workload=a.workload)
     parallel.attach(model, ow)
     from vfmseg_amd import functional as Fh
     Fh.manual_seed(1234 + rank)
-    data = make_batch(a.batch, rank, 0, device)
+    data = make_batch(a.batch, rank, 0, device, size=1024 if a.workload == "ms1024" else 512)
     timer = GemmTimer()
     if not a.no_roofline:
         timer.install()
@@ -206,13 +209,16 @@ def main():
                                "bs=%d/GPU, full train step (fwd+bwd+allreduce+AdamW), LoRA dropout on" % a.batch,
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world},
     }
+    if a.workload == "single512":
+        out["metric"] = "train images/sec @512x512 DINOv2-L+LoRA + LinearHead, single 512^2 pass per sample (not the headline metric)"
+        out["config"]["workload"] = "single-pass variant of configs[1]: EncoderDecoder(LoRABackbone(DINOv2-L), LinearHead), 512^2 inputs, bs=%d/GPU" % a.batch
     if rank == 0:
         s = timer.summary()
         if s is not None:
             ach = s["flops"] / (s["ms"] * 1e-3) / 1e12
             traffic, traffic_src = None, None
             tj = os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")
-            if os.path.exists(tj):  # PMC counters cannot be read from inside the timed run: committed rocprofv3 --pmc passes
+            if os.path.exists(tj) and a.workload == "ms1024":  # PMC counters cannot be read from inside the timed run: committed rocprofv3 --pmc passes
                 with open(tj) as f:
                     tr = json.load(f)
                 traffic = tr.get("mean_bytes_per_launch")
@@ -223,8 +229,8 @@ def main():
                                "launches_timed": s["launches"], "sampled_every": s["sampled_every"],
                                "gemm_ms_per_step_est": round(s["ms"] * s["sampled_every"] / a.steps, 3)}
         # end-to-end model-FLOP utilisation (722.4 GFLOP fwd per image-pass, train ~2.2x, 2 passes/sample)
-        out["model_tflops"] = round(value / world * 2 * 722.4e9 * 2.2 / 1e12, 2)
-        if world == 1 and not a.no_cpu_baseline:
+        out["model_tflops"] = round(value / world * (2 if a.workload == "ms1024" else 1) * 722.4e9 * 2.2 / 1e12, 2)
+        if world == 1 and not a.no_cpu_baseline and a.workload == "ms1024":
             try:
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline must never take the GPU number down with it

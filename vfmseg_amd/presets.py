@@ -110,6 +110,20 @@ def dinov2_ms_masked(depth=24, embed_dim=1024, num_heads=16, checkpoint=None, wo
     )
 
 
+def dinov2_linear(depth=24, embed_dim=1024, num_heads=16, checkpoint=None):
+    """Single-scale segmentor of BASELINE config 1 (DINOv2-L + LoRA + LinearHead, one 512^2 pass per sample): the
+    `EncoderDecoder` form of configs/_base_/models/lora_*_linear.py with the DINOv2 backbone block of lora_dinov2_ms_masked.py."""
+    return dict(
+        type="EncoderDecoder",
+        data_preprocessor=dict(_PREPROC, size=(512, 512)),
+        backbone=dict(type="LoRABackbone", backbone=dinov2_backbone(depth, embed_dim, num_heads), checkpoint=checkpoint,
+                      Lora_config=lora_cfg()),
+        decode_head=linear_head(embed_dim),
+        train_cfg=dict(),
+        test_cfg=dict(mode="whole"),
+    )
+
+
 def optim_cfg():
     embed_multi = dict(lr_mult=1.0, decay_mult=0.0)
     return dict(
