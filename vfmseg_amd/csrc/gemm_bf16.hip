@@ -305,7 +305,7 @@ static void launch_skinny(const vfm_gemm_desc* d, hipStream_t s) {
 }
 
 static int g_force_cfg = -1;
-static int g_split_tail = 1;
+static int g_split_tail = 3;  // bit 0: peel the tail rows of M off; bit 1: ... except for shapes on the 64-row tiles
 static int g_fold_tail = 1;  // run the tail rows as extra blocks of the tile kernel's launch
 // bit 0: 256x256 ping-pong kernel instead of config 16; bit 1: 128x128 ping-pong kernel (gemm_pp.hip); bit 3: N >= 2048 stays
 // on the 128x128 tiles; bit 4: whole waves of 256x256 tiles go to the 8-wave 64-wide-K-tile kernel (gemm_w4.hip); bit 5: the
@@ -369,7 +369,11 @@ int vfm_gemm_bf16_impl(const vfm_gemm_desc* d0, hipStream_t s) {
   const long tail = d0->M % 128;
   const bool bt = (d0->sb_n == 1 && d0->sb_k != 1);
   if (bt) return gemm_main(d0, s);
-  if (g_split_tail && d0->M > 512 && tail > 0 && tail <= 32 && (d0->batch <= 1)) {
+  // shapes that go to the 64-row tiles (few column tiles, long K: the LoRA T GEMM [4100 x 64 x 1024]) take the tail as one
+  // more row tile of the same launch - cheaper than a launch of its own
+  const bool rows64 = d0->N > 32 && d0->K >= 512 && (long)cdiv(d0->M, 128) * cdiv(d0->N, 128) <= 160 &&
+                      (long)cdiv(d0->M, 64) * cdiv(d0->N, 64) <= 512;
+  if (g_split_tail && !(rows64 && (g_split_tail & 2)) && d0->M > 512 && tail > 0 && tail <= 32 && (d0->batch <= 1)) {
     vfm_gemm_desc dm = *d0, dt = *d0;
     const long mm = d0->M - tail;
     dm.M = mm;
