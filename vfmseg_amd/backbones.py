@@ -13,6 +13,8 @@ The nn.Modules below are *parameter containers* that reproduce the reference's s
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -540,6 +542,9 @@ def _pack_at(A, at, r):
     ops.strided_copy(A, at, (A.shape[1], r), (1, A.stride(0)), (at.stride(0), 1))
 
 
+_KCH_MAX = int(os.environ.get("VFMSEG_WGRAD_KCH_MAX", "16"))
+
+
 def _wgrad_small_t(xs, y, out, alpha=1.0, scatter=None):
     """out[P, Q] = alpha * xs^T @ y   with xs [M, P] small (P <= 64) and y [M, Q] large, consumed in place.
     bf16: only the small operand is transposed (zero-padded to a multiple of 64 tokens); the large one is the
@@ -551,7 +556,7 @@ def _wgrad_small_t(xs, y, out, alpha=1.0, scatter=None):
         mp = (M + 63) // 64 * 64
         # few output tiles, long token reduction: split K into the largest divisor <= 16 of the 64-token steps
         steps = mp // 64
-        kch = max(d for d in range(1, 17) if steps % d == 0)
+        kch = max(d for d in range(1, _KCH_MAX + 1) if steps % d == 0)
         tn = kch > 1 and xs.shape[1] % 8 == 0 and xs.data_ptr() % 16 == 0 and xs.stride(0) % 8 == 0
         if not tn:
             xt = torch.empty(xs.shape[1], mp, dtype=xs.dtype, device=xs.device)

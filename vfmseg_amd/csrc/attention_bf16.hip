@@ -252,7 +252,7 @@ __device__ void attn_extra_dkv(const AttnP& p, int b, int hh, int ki, char* smem
 // (the decoder's 16 (image, head) pairs x 1024 queries are only 128 blocks of 128 queries).
 template <bool DQ, int NW = 4>
 __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (K tile, V tile)
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 3 stages x (K tile, V tile)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nq = p.nq_main + p.nq_extra, nk = p.nk_main + p.nk_extra;
@@ -306,11 +306,14 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
     stage_tile<NW>(Kb, p.ldk, col0, b, t * TROWS, nk, p.nk_main, p.B, kt, wave, lane);
     stage_tile<NW>(Vb, p.ldv, col0, b, t * TROWS, nk, p.nk_main, p.B, kt + TILE_BYTES, wave, lane);
   };
+  // three K/V stages, ONE barrier per tile: the barrier that publishes tile t also certifies that every wave is done with tile
+  // t-1, whose stage is the one tile t+2 will be written to (by the stage() call of the NEXT iteration)
   stage(0, 0);
+  int buf = 0;
   for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
+    const int nbuf = buf == 2 ? 0 : buf + 1;
     if (t + 1 < nt) {
-      stage(buf ^ 1, t + 1);
+      stage(nbuf, t + 1);
       if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
@@ -335,10 +338,14 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
           for (int r = 0; r < 16; ++r)
             if (t * TROWS + kb * 32 + acc_row(r, h) >= nk) sacc[kb][r] = -INFINITY;
       }
+      {  // four independent max chains (a single 32-deep dependent chain leaves the VALU idle at two waves per SIMD)
+        float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+          for (int r = 0; r < 16; ++r) m4[r & 3] = fmaxf(m4[r & 3], sacc[kb][r]);
+        mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       // lazy rescale: the reference maximum m only moves when the tile maximum exceeds it by more than 2^8 in the exp2
       // domain (p <= 256 stays exact enough in bf16 / fp32 sums); after the first tiles the 32 accumulator rescales and
@@ -347,21 +354,16 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
       const float mn = need ? mx : m;
       const float alpha = need ? __builtin_amdgcn_exp2f((m - mn) * c) : 1.0f;
       const float mnc = mn * c;
-      // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32): two scores per VALU issue around the exp
-      const f32x2 c2 = {c, c}, mnc2 = {mnc, mnc};
-      f32x2 rs2 = {0.f, 0.f};
+      float rs4[4] = {0.f, 0.f, 0.f, 0.f};  // four independent row-sum chains
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const f32x2 sv = {sacc[kb][r], sacc[kb][r + 1]};
-          const f32x2 x = sv * c2 - mnc2;
-          const f32x2 pv = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-          sacc[kb][r] = pv[0];
-          sacc[kb][r + 1] = pv[1];
-          rs2 += pv;
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -mnc));
+          sacc[kb][r] = pv;
+          rs4[r & 3] += pv;
         }
-      l = l * alpha + (rs2[0] + rs2[1]);
+      l = l * alpha + ((rs4[0] + rs4[1]) + (rs4[2] + rs4[3]));
       m = mn;
       if (__ballot(alpha != 1.0f) != 0ull) {  // the running maximum settles after the first tiles: skip the 32 rescales
 #pragma unroll
@@ -401,8 +403,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) oacc[j] = MFMA(tr_frag(t2, kb, s, j, lane), pb, oacc[j]);
       }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    buf = nbuf;
   }
   // ---- epilogue: lane = query, registers = output columns acc_row(r, h) + 32 j
   float mult;
@@ -433,7 +434,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
 // ------------------------------------------------------------------------------------------------------ dK / dV
 template <int NW = 4>
 __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x (Q tile, dO tile, lse[64], delta[64] (+dummy))
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 3 stages x (Q tile, dO tile, lse[64], delta[64] (+dummy))
   constexpr int STAGE = 2 * TILE_BYTES + 1024;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -476,10 +477,11 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
     glds4(src + qq, qt + 2 * TILE_BYTES + wave * 256);
   };
   stage(0, 0);
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
+  int buf = 0;
+  for (int t = 0; t < nt; ++t) {  // three stages, one barrier per tile (see k_attn_bf16_q)
+    const int nbuf = buf == 2 ? 0 : buf + 1;
     if (t + 1 < nt) {
-      stage(buf ^ 1, t + 1);
+      stage(nbuf, t + 1);
       if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
     } else {
@@ -528,8 +530,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
         }
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    buf = nbuf;
   }
   if (kvalid) {
     bf16_t* odk = (bf16_t*)p.dk;
@@ -567,7 +568,7 @@ int vfm_attn_bf16_fwd_impl(const vfm_attn_desc* d, hipStream_t s) {
   VFM_CHECK(aligned_ok(d, false), VFM_E_ALIGN, "vfm_attn_fwd(bf16): operands must be 16-byte aligned, ld %% 8 == 0");
   const AttnP p = to_p(d);
   const int nq = d->nq_main + d->nq_extra;
-  const size_t shm = 4 * TILE_BYTES;
+  const size_t shm = 6 * TILE_BYTES;
   if (short_grid(d, nq)) hipLaunchKernelGGL((k_attn_bf16_q<false, 2>), dim3(cdiv(nq, 64), d->B * d->H), dim3(128), shm, s, p);
   else hipLaunchKernelGGL((k_attn_bf16_q<false, 4>), dim3(cdiv(nq, 128), d->B * d->H), dim3(256), shm, s, p);
   VFM_LAUNCH_CHECK();
@@ -578,10 +579,10 @@ int vfm_attn_bf16_bwd_impl(const vfm_attn_desc* d, hipStream_t s) {
   VFM_CHECK(aligned_ok(d, true), VFM_E_ALIGN, "vfm_attn_bwd(bf16): operands must be 16-byte aligned, ld %% 8 == 0");
   const AttnP p = to_p(d);
   const int nq = d->nq_main + d->nq_extra, nk = d->nk_main + d->nk_extra;
-  if (short_grid(d, nq)) hipLaunchKernelGGL((k_attn_bf16_q<true, 2>), dim3(cdiv(nq, 64), d->B * d->H), dim3(128), 4 * TILE_BYTES, s, p);
-  else hipLaunchKernelGGL((k_attn_bf16_q<true, 4>), dim3(cdiv(nq, 128), d->B * d->H), dim3(256), 4 * TILE_BYTES, s, p);
-  if (short_grid(d, nk)) hipLaunchKernelGGL((k_attn_bf16_dkv<2>), dim3(cdiv(nk, 64), d->B * d->H), dim3(128), 2 * (2 * TILE_BYTES + 1024), s, p);
-  else hipLaunchKernelGGL((k_attn_bf16_dkv<4>), dim3(cdiv(nk, 128), d->B * d->H), dim3(256), 2 * (2 * TILE_BYTES + 1024), s, p);
+  if (short_grid(d, nq)) hipLaunchKernelGGL((k_attn_bf16_q<true, 2>), dim3(cdiv(nq, 64), d->B * d->H), dim3(128), 6 * TILE_BYTES, s, p);
+  else hipLaunchKernelGGL((k_attn_bf16_q<true, 4>), dim3(cdiv(nq, 128), d->B * d->H), dim3(256), 6 * TILE_BYTES, s, p);
+  if (short_grid(d, nk)) hipLaunchKernelGGL((k_attn_bf16_dkv<2>), dim3(cdiv(nk, 64), d->B * d->H), dim3(128), 3 * (2 * TILE_BYTES + 1024), s, p);
+  else hipLaunchKernelGGL((k_attn_bf16_dkv<4>), dim3(cdiv(nk, 128), d->B * d->H), dim3(256), 3 * (2 * TILE_BYTES + 1024), s, p);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }
