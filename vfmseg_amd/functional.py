@@ -208,6 +208,11 @@ class LinearFn(torch.autograd.Function):
                 if kch > 1:
                     slabs = torch.empty(kch, npad, Kp, dtype=torch.float32, device=dy.device)
                     ops.gemm_splitk_tn(g, x, slabs, kch)
+                    tgt = direct_grad_target(weights[0]) if len(weights) == 1 and ctx.needs_input_grad[4] else None
+                    if tgt is not None and layouts[0] in ("linear", "conv1x1") and Kp == dims[0][1]:
+                        # the split-K combine adds straight into the parameter's slot of the flat gradient buffer
+                        ops.slab_reduce(slabs, N, tgt, Kp, 1, accumulate=True)
+                        return (dx, d_res, dbias, None, None)
                     ops.colsum(slabs.view(kch, npad * Kp), gw.view(npad * Kp))
                 else:
                     ops.gemm_splitk_tn(g, x, gw.view(1, npad, Kp), 1)
