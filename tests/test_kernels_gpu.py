@@ -304,6 +304,33 @@ def test_gemm_bf16_configs_fast_epilogues(cfg, M, N, K):
         ops.tune("gemm_cfg", -1)
 
 
+@pytest.mark.parametrize("cfg", [-1, 17, 32, 33, 34])
+def test_gemm_bf16_batched_ragged(cfg):
+    """Batched bf16 GEMMs (SAM's per-window products) with ragged M / N, a batch stride wider than the matrix, a bf16 residual
+    and the scalar (N % 4 != 0) epilogue, through the default dispatch and the ring kernels; K = 128 and 192 are the shortest
+    pipelines of the five-chunk ring (two and three K-tiles)."""
+    ops.tune("gemm_cfg", cfg)
+    try:
+        for (Bt, M, N, K) in [(3, 200, 328, 192), (5, 196, 196, 128), (2, 130, 19, 256), (4, 257, 260, 1088)]:
+            a, b = rnd(Bt, M, K, seed=70).bfloat16().to(DEV), rnd(Bt, N, K, seed=71).bfloat16().to(DEV)
+            ref = a.double() @ b.double().transpose(1, 2)
+            for rep in range(2):
+                wide = torch.full((Bt, M + 3, N), float("nan"), dtype=torch.bfloat16, device=DEV)  # batch stride > M * N
+                c = wide[:, :M]
+                ops.gemm(a, b, c, alpha=0.25)
+                assert relerr(c.float(), 0.25 * ref) < 1e-2 and torch.isnan(wide[:, M:].float()).all()
+                cf = torch.full((Bt, M, N), float("nan"), device=DEV)
+                ops.gemm(a, b, cf)
+                assert relerr(cf, ref) < 2e-5
+                if N % 4 == 0:
+                    res = rnd(Bt, M, N, seed=72).bfloat16().to(DEV)
+                    cr = torch.full((Bt, M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+                    ops.gemm(a, b, cr, residual=res)
+                    assert relerr(cr.float(), ref + res.double()) < 1e-2
+    finally:
+        ops.tune("gemm_cfg", -1)
+
+
 @pytest.mark.parametrize("P,M,Q", [(64, 4100, 3072), (64, 4100, 1024), (1024, 2048, 4096), (19, 1000, 256), (200, 333, 128)])
 def test_gemm_bf16_transposed_b(P, M, Q):
     """Weight-gradient form: out[P,Q] = xs^T[P,M] @ y[M,Q], y consumed in place ([K,N] operand), tokens zero-padded."""
