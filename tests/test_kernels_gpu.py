@@ -266,14 +266,14 @@ def test_gemm_bf16(M, N, K):
     assert relerr(cw[:, :N], a.double() @ b.double().t()) < 2e-5 and cw[:, N:].abs().sum() == 0
 
 
-@pytest.mark.parametrize("cfg", [17, 16, 30, 31, 32, 33, 34, 10])
+@pytest.mark.parametrize("cfg", [17, 16, 30, 31, 32, 33, 34, 35, 36, 10])
 @pytest.mark.parametrize("M,N,K", [(4100, 1024, 1024), (300, 520, 320), (1024, 2048, 448), (256, 256, 4096), (512, 512, 128)])
 def test_gemm_bf16_configs_fast_epilogues(cfg, M, N, K):
     """Every tile configuration incl. the ping-pong kernels (30: 256x256, 31: 128x128) and the 64-wide-K-tile 256x256 kernels
     (32: 4 waves / AGPR accumulator, 33: 8 waves; K = 128 is their shortest pipeline) x the specialised epilogue instances the
     backbones use; repeated launches double as a race screen for the LDS-DMA rings."""
-    if cfg == 31 and K < 256:
-        pytest.skip("the 128x128 ping-pong kernel needs K >= 256 (the dispatcher rejects shorter K)")
+    if cfg in (31, 35, 36) and K < 256:
+        pytest.skip("the 128x128 ping-pong and deep-ring kernels need K >= 256 (the dispatcher rejects shorter K)")
     a, b = rnd(M, K, seed=80).bfloat16().to(DEV), rnd(N, K, seed=81).bfloat16().to(DEV)
     bias, cs, res = rnd(N, seed=82).to(DEV), (rnd(N, seed=83) * 0.2 + 1).to(DEV), rnd(M, N, seed=84).to(DEV)
     aux = rnd(M, N, seed=85).bfloat16().to(DEV)
@@ -304,7 +304,7 @@ def test_gemm_bf16_configs_fast_epilogues(cfg, M, N, K):
         ops.tune("gemm_cfg", -1)
 
 
-@pytest.mark.parametrize("cfg", [-1, 17, 32, 33, 34])
+@pytest.mark.parametrize("cfg", [-1, 17, 32, 33, 34])  # (35 / 36 need K >= 256)
 def test_gemm_bf16_batched_ragged(cfg):
     """Batched bf16 GEMMs (SAM's per-window products) with ragged M / N, a batch stride wider than the matrix, a bf16 residual
     and the scalar (N % 4 != 0) epilogue, through the default dispatch and the ring kernels; K = 128 and 192 are the shortest

@@ -431,6 +431,8 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
     else cfg = 17;                                                   // 128x128, 8 waves, 2 blocks per CU
     if (cfg == 17 && (g_use_pp & 32) && d->K >= 128 && (d->M + 128) * d->sa_m < (1l << 31) && (d->N + 128) * d->sb_n < (1l << 31))
       cfg = 34;  // same tile and wave layout, operands through the five-chunk (2.5 K-tile) LDS-DMA ring of gemm_w4.hip
+    // at most one tile per CU and no tail blocks to squeeze in: the second block's LDS buys a seven-chunk ring instead
+    if (cfg == 34 && !tail && t128 <= 256 && d->K >= 256 && d->M % 128 == 0) cfg = 35;
   }
   switch (cfg) {
     case 0: fd = launch_cfg<128, 128, 2, 2, 2>(d, s, vec, tail); break;
@@ -470,9 +472,12 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
     case 32:
     case 33:
     case 34:
+    case 35:
+    case 36:
       VFM_CHECK(d->K >= 128 && d->K % 64 == 0 && (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31), VFM_E_UNSUPPORTED,
                 "vfm_gemm(bf16): the 4-wave 256x256 kernel needs K >= 128 and operands spanning < 4 GiB");
-      fd = vfm_gemm_launch_w4(d, s, vec, tail, cfg == 32 ? 4 : (cfg == 33 ? 8 : 2));
+      VFM_CHECK(cfg < 35 || d->K >= 256, VFM_E_UNSUPPORTED, "vfm_gemm(bf16): the deep-ring 128x128 kernels need K >= 256");
+      fd = vfm_gemm_launch_w4(d, s, vec, tail, cfg == 32 ? 4 : (cfg == 33 ? 8 : (cfg == 34 ? 2 : (cfg == 35 ? 3 : 5))));
       break;
     case 30:
       VFM_CHECK(d->K >= 128, VFM_E_UNSUPPORTED, "vfm_gemm(bf16): the ping-pong kernel needs K >= 128");

@@ -25,10 +25,6 @@
 // issued after beta_v.  Every memory instruction sits between two MFMAs: the matrix pipe never waits for an issue.
 #include "gemm_dev.h"
 
-namespace {
-constexpr int W4_NCH = 5;  // chunk slots in the ring
-}  // namespace
-
 // The kernel is generic in the wave tile (MI x NI blocks of 32 x 32) and the wave grid (WM_W x WN_W); the block tile is square
 // (T = WM_W * MI * 32 = WN_W * NI * 32 rows and columns) so that A and B chunks have one size (T rows x 128 B):
 //     <4, 4, 2, 2>  256 x 256, 4 waves, 128 x 128 wave tiles, AGPR accumulator, one wave per SIMD             (config 32)
@@ -43,19 +39,22 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <bool VEC, int MI, int NI, int WM_W, int WN_W, int DBG = 0>
+// P = prefetch depth: the ring has NCH = 2P + 1 chunk slots (P = 2: the five-chunk ring described above; chunk 2v+2P-1 .. 2v+2P+1
+// are issued during iteration v, and the wait before the last k-step leaves 2P-3 whole chunks in flight).  P = 4 (nine slots, 144 KiB
+// for 128 x 128 tiles) is for launches with at most one tile per CU, where the LDS of the second block would lie idle.
+template <bool VEC, int MI, int NI, int WM_W, int WN_W, int P = 2, int DBG = 0>
 __global__ void __launch_bounds__(WM_W* WN_W * 64)
     k_gemm_w4(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, long M, long N, long K, long stride_a,
               long stride_b, long stride_c, int tiles_m, int tiles_n, EpiParams e, SkinnyTail sk) {
   constexpr int T = WM_W * MI * 32;
   static_assert(T == WN_W * NI * 32 && MI % 2 == 0, "square block tile, wave tile of 64-row halves");
-  constexpr int WAVES = WM_W * WN_W;
+  constexpr int WAVES = WM_W * WN_W, NCH = 2 * P + 1;
   constexpr int CH = T * 128;                        // bytes per chunk (T rows x one 128-B K-tile row)
   constexpr int PPC = T / 8 / WAVES, PPS = PPC / 2;  // DMA pieces per wave: per chunk, per k-step
   static_assert(PPC >= 2 && PPC % 2 == 0, "a wave moves whole halves of a chunk");
   constexpr int NMF = MI * NI, NRD = MI + NI, NOPS = NRD + PPS;  // per k-step: MFMAs, fragment reads, memory ops
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if constexpr (WAVES == 8 && 5 * CH >= 65536) {  // the tail rows of M run as extra blocks at the end of the grid
+  if constexpr (WAVES == 8 && NCH * CH >= 65536) {  // the tail rows of M run as extra blocks at the end of the grid
     if (sk.nblk > 0 && (int)blockIdx.x >= tiles_m * tiles_n) {
       skinny_tile(sk.A, sk.lda, B, ldb, sk.M, N, K, (long)((int)blockIdx.x - tiles_m * tiles_n) * 32, sk.e, 0, smem);
       return;
@@ -127,7 +126,7 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
     ra[s] = (wm * MI * 32 + fr) * 128 + kx;
     rb[s] = (wn * NI * 32 + fr) * 128 + kx;
   }
-  const int nk = (int)(K / 64);  // >= 2 (checked by the dispatcher)
+  const int nk = (int)(K / 64);  // >= P (checked by the dispatcher)
   bf16x8 fa[2][MI], fb[2][NI];   // [buffer][block]
 
   // one k-step: NMF MFMAs on buffer CUR; spread between them the fragment reads of the next k-step (READ: k-step rs of the
@@ -158,30 +157,34 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
       __builtin_amdgcn_sched_barrier(0);
     });
   };
-  auto wrap = [](int p) { return p >= W4_NCH ? p - W4_NCH : p; };
-  // X: 0 steady (v <= nk-3); 1 = last but one K-tile (only the second half of chunk 2nk-1 left to issue); 2 = last K-tile
+  auto wrap = [](int p) { return p >= NCH ? p - NCH : p; };
+  // X: 0 steady (v <= nk-P-1); X = j+1 for the last P K-tiles v = nk-P+j (j = 0: only the second half of the last chunk is left
+  // to issue; afterwards nothing; X = P is the last K-tile: no barrier, no fragments to prefetch)
   auto iter = [&](auto Xc, int v, int q) {  // q = slot of chunk 2v
     constexpr int X = decltype(Xc)::value;
-    const int q1 = wrap(q + 1), q2 = wrap(q + 2), q3 = wrap(q + 3), q4 = wrap(q + 4);
-    kstep(IC<0>{}, IC<true>{}, IC<(X <= 1)>{}, IC<1>{}, IC<1>{}, q, q1, IC<1>{}, v + 1, q3);
-    kstep(IC<1>{}, IC<true>{}, IC<(X == 0)>{}, IC<0>{}, IC<0>{}, q, q1, IC<2>{}, v + 2, q4);
-    kstep(IC<0>{}, IC<true>{}, IC<(X == 0)>{}, IC<0>{}, IC<1>{}, q, q1, IC<3>{}, v + 2, q4);
-    if constexpr (X != 2) {
+    constexpr bool LAST = X == P;
+    const int q1 = wrap(q + 1), q2 = wrap(q + 2), q3 = wrap(q + 3);
+    const int d0 = wrap(q + 2 * P - 1), d1 = wrap(q + 2 * P);
+    kstep(IC<0>{}, IC<true>{}, IC<(X <= 1)>{}, IC<1>{}, IC<1>{}, q, q1, IC<1>{}, v + P - 1, d0);
+    kstep(IC<1>{}, IC<true>{}, IC<(X == 0)>{}, IC<0>{}, IC<0>{}, q, q1, IC<2>{}, v + P, d1);
+    kstep(IC<0>{}, IC<true>{}, IC<(X == 0)>{}, IC<0>{}, IC<1>{}, q, q1, IC<3>{}, v + P, d1);
+    if constexpr (!LAST) {
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-      if constexpr (X == 0) wait_vmcnt<PPC>();
-      if constexpr (X == 1) wait_vmcnt<0>();
+      constexpr int live = X == 0 ? 2 * P - 3 : (2 * P - 4 - 2 * (X - 1) > 0 ? 2 * P - 4 - 2 * (X - 1) : 0);  // whole chunks in flight
+      wait_vmcnt<live * PPC>();
       __builtin_amdgcn_s_barrier();
     }
     __builtin_amdgcn_sched_barrier(0);
-    kstep(IC<1>{}, IC<(X != 2)>{}, IC<(X == 0)>{}, IC<1>{}, IC<0>{}, q2, q3, IC<0>{}, v + 2, q);
+    kstep(IC<1>{}, IC<!LAST>{}, IC<(X == 0)>{}, IC<1>{}, IC<0>{}, q2, q3, IC<0>{}, v + P, q);
   };
 
-  // ---- prologue: chunks 0, 1, 2 and the first half of chunk 3 in flight; K-tile 0 landed; fragments of (0, s0)
-  dma_half(IC<0>{}, IC<0>{}, 0, 0), dma_half(IC<0>{}, IC<1>{}, 0, 0);
-  dma_half(IC<1>{}, IC<0>{}, 0, 1), dma_half(IC<1>{}, IC<1>{}, 0, 1);
-  dma_half(IC<0>{}, IC<0>{}, 1, 2), dma_half(IC<0>{}, IC<1>{}, 1, 2);
-  dma_half(IC<1>{}, IC<0>{}, 1, 3);
-  wait_vmcnt<PPC + PPS>();
+  // ---- prologue: chunks 0 .. 2P-2 and the first half of chunk 2P-1 in flight; K-tile 0 landed; fragments of (0, s0)
+  static_for<2 * P - 1>([&](auto Cc) {
+    constexpr int c = decltype(Cc)::value;
+    dma_half(IC<(c & 1)>{}, IC<0>{}, c >> 1, c), dma_half(IC<(c & 1)>{}, IC<1>{}, c >> 1, c);
+  });
+  dma_half(IC<1>{}, IC<0>{}, P - 1, 2 * P - 1);
+  wait_vmcnt<(2 * P - 3) * PPC + PPS>();
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -191,12 +194,15 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   __builtin_amdgcn_sched_barrier(0);
 
   int v = 0, q = 0;
-  for (; v < nk - 2; ++v) {
+  for (; v < nk - P; ++v) {
     iter(IC<0>{}, v, q);
     q = wrap(q + 2);
   }
-  iter(IC<1>{}, v, q);
-  iter(IC<2>{}, v + 1, wrap(q + 2));
+  static_for<P>([&](auto Jc) {
+    constexpr int j = decltype(Jc)::value;
+    iter(IC<j + 1>{}, v + j, q);
+    q = wrap(q + 2);
+  });
   __builtin_amdgcn_sched_barrier(0);
 
   // ---- epilogue (accumulators -> per-wave fp32 LDS image -> 16-byte rows), one 64-row half of the wave tile at a time
@@ -213,37 +219,40 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
 }
 
 extern int g_pp_dbg;
-template <bool VEC, int MI, int NI, int WM_W, int WN_W, int DBG>
+template <bool VEC, int MI, int NI, int WM_W, int WN_W, int P, int DBG>
 static bool launch_w4_t(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail) {
   constexpr int T = WM_W * MI * 32, WAVES = WM_W * WN_W;
-  constexpr int RING = W4_NCH * T * 128, EPI = WAVES * 64 * (NI * 32 + 4) * 4, SMEM = RING > EPI ? RING : EPI;
+  constexpr int RING = (2 * P + 1) * T * 128, EPI = WAVES * 64 * (NI * 32 + 4) * 4, SMEM = RING > EPI ? RING : EPI;
   const int tiles_m = cdiv(d->M, T), tiles_n = cdiv(d->N, T);
   const long batch = d->batch > 0 ? d->batch : 1;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_gemm_w4<VEC, MI, NI, WM_W, WN_W, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipFuncSetAttribute((const void*)k_gemm_w4<VEC, MI, NI, WM_W, WN_W, P, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr = true;
   }
   SkinnyTail sk;
   sk.nblk = 0;
   const bool fold = tail && batch == 1 && WAVES == 8 && RING >= 65536;
   if (fold) sk.A = (const bf16_t*)tail->A, sk.lda = tail->sa_m, sk.M = tail->M, sk.nblk = cdiv(tail->N, 32), sk.e = make_epi(tail);
-  hipLaunchKernelGGL((k_gemm_w4<VEC, MI, NI, WM_W, WN_W, DBG>), dim3(tiles_m * tiles_n + sk.nblk, (unsigned)batch), dim3(WAVES * 64), SMEM, s,
+  hipLaunchKernelGGL((k_gemm_w4<VEC, MI, NI, WM_W, WN_W, P, DBG>), dim3(tiles_m * tiles_n + sk.nblk, (unsigned)batch), dim3(WAVES * 64), SMEM, s,
                      (const bf16_t*)d->A, d->sa_m, (const bf16_t*)d->B, d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c,
                      tiles_m, tiles_n, make_epi(d), sk);
   return fold || !tail;
 }
-// form: 4 = 256x256 / 4 waves, 8 = 256x256 / 8 waves, 2 = 128x128 / 8 waves (two blocks per CU).  Returns whether the tail rows
+// form: 4 = 256x256 / 4 waves, 8 = 256x256 / 8 waves, 2 = 128x128 / 8 waves (two blocks per CU), 3 / 5 = 128x128 with the
+// seven- / nine-chunk ring (one block per CU).  Returns whether the tail rows
 // were folded into the launch (8-wave forms; otherwise the caller runs the skinny kernel).
 bool vfm_gemm_launch_w4(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail, int form) {
   if (form == 4) {
-    if (!vec) return launch_w4_t<false, 4, 4, 2, 2, 0>(d, s, tail);
-    return g_pp_dbg == 1 ? launch_w4_t<true, 4, 4, 2, 2, 1>(d, s, tail) : launch_w4_t<true, 4, 4, 2, 2, 0>(d, s, tail);
+    if (!vec) return launch_w4_t<false, 4, 4, 2, 2, 2, 0>(d, s, tail);
+    return g_pp_dbg == 1 ? launch_w4_t<true, 4, 4, 2, 2, 2, 1>(d, s, tail) : launch_w4_t<true, 4, 4, 2, 2, 2, 0>(d, s, tail);
   }
   if (form == 8) {
-    if (!vec) return launch_w4_t<false, 4, 2, 2, 4, 0>(d, s, tail);
-    return g_pp_dbg == 1 ? launch_w4_t<true, 4, 2, 2, 4, 1>(d, s, tail) : launch_w4_t<true, 4, 2, 2, 4, 0>(d, s, tail);
+    if (!vec) return launch_w4_t<false, 4, 2, 2, 4, 2, 0>(d, s, tail);
+    return g_pp_dbg == 1 ? launch_w4_t<true, 4, 2, 2, 4, 2, 1>(d, s, tail) : launch_w4_t<true, 4, 2, 2, 4, 2, 0>(d, s, tail);
   }
-  if (!vec) return launch_w4_t<false, 2, 1, 2, 4, 0>(d, s, tail);
-  return launch_w4_t<true, 2, 1, 2, 4, 0>(d, s, tail);
+  if (form == 5) return vec ? launch_w4_t<true, 2, 1, 2, 4, 4, 0>(d, s, tail) : launch_w4_t<false, 2, 1, 2, 4, 4, 0>(d, s, tail);
+  if (form == 3) return vec ? launch_w4_t<true, 2, 1, 2, 4, 3, 0>(d, s, tail) : launch_w4_t<false, 2, 1, 2, 4, 3, 0>(d, s, tail);
+  if (!vec) return launch_w4_t<false, 2, 1, 2, 4, 2, 0>(d, s, tail);
+  return launch_w4_t<true, 2, 1, 2, 4, 2, 0>(d, s, tail);
 }
