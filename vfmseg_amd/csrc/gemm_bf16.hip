@@ -283,10 +283,10 @@ static bool launch_cfg(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vf
   return launch_one<BM, BN, WM_W, WN_W, NS, false, false>(d, s, tail);
 }
 
-template <int BM, int WM_W, int WN_W>
+template <int BM, int WM_W, int WN_W, int NS = 2>
 static void launch_bt(const vfm_gemm_desc* d, hipStream_t s, bool vec) {
-  if (vec) launch_one<BM, 128, WM_W, WN_W, 2, true, true>(d, s);
-  else launch_one<BM, 128, WM_W, WN_W, 2, false, true>(d, s);
+  if (vec) launch_one<BM, 128, WM_W, WN_W, NS, true, true>(d, s);
+  else launch_one<BM, 128, WM_W, WN_W, NS, false, true>(d, s);
 }
 
 // ------------------------------------------------------------------------------------------------ skinny tail
@@ -306,6 +306,7 @@ static void launch_skinny(const vfm_gemm_desc* d, hipStream_t s) {
 
 static int g_force_cfg = -1;
 static int g_split_tail = 3;  // bit 0: peel the tail rows of M off; bit 1: ... except for shapes on the 64-row tiles
+static int g_bt64 = 1;       // transposed-B GEMMs with few tiles use 64-row tiles
 static int g_fold_tail = 1;  // run the tail rows as extra blocks of the tile kernel's launch
 // bit 0: 256x256 ping-pong kernel instead of config 16; bit 1: 128x128 ping-pong kernel (gemm_pp.hip); bit 3: N >= 2048 stays
 // on the 128x128 tiles; bit 4: whole waves of 256x256 tiles go to the 8-wave 64-wide-K-tile kernel (gemm_w4.hip); bit 5: the
@@ -328,6 +329,10 @@ extern "C" int vfm_tune(const char* key, int value) {
   }
   if (key && strcmp(key, "gemm_use_pp") == 0) {
     g_use_pp = value;
+    return VFM_OK;
+  }
+  if (key && strcmp(key, "gemm_bt64") == 0) {
+    g_bt64 = value;
     return VFM_OK;
   }
   if (key && strcmp(key, "gemm_fold_tail") == 0) {
@@ -408,7 +413,9 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
       else launch_one<128, 128, 2, 4, 2, false, true, true>(d, s);
       return VFM_OK;
     }
-    if (d->M <= 64) launch_bt<64, 1, 4>(d, s, vec);
+    // few 128-row tiles (decoder dgrads: 2048 x 256 outputs over K = 1024..2048): 64-row tiles double the blocks in flight
+    const bool few = (long)cdiv(d->M, 128) * cdiv(d->N, 128) * (d->batch > 0 ? d->batch : 1) < 128;
+    if (d->M <= 64 || (g_bt64 && few)) launch_bt<64, 1, 4>(d, s, vec);  // (a four-stage ring measured no faster: one wave per SIMD)
     else launch_bt<128, 2, 4>(d, s, vec);
     return VFM_OK;
   }
