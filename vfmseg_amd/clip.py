@@ -333,16 +333,24 @@ class ClipEngine:
         dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
         lora = self.lora_on()
         grads = [None] * (4 * len(v.blocks))
-        t = torch.empty(M, D, dtype=cd, device=dev)
-        for li in range(len(v.blocks) - 1, -1, -1):
-            blk, Lp, S = v.blocks[li], P["layers"][li], ctx["saved"][li]
-            hid = Lp["hid"]
+        fuse_t = cd == torch.bfloat16 and D % 256 == 0  # LN backward emits the next dgrad operand bf16(dx) itself
+        if fuse_t and "ones" not in P:
+            P["ones"] = torch.ones(D, dtype=torch.float32, device=dev)
+
+        def add_tap(li):
             if li in v.out_indices:
                 i = v.out_indices.index(li)
                 src = dxcat[:, i * D:(i + 1) * D]
                 ops.strided_copy(src, dx, (Mp, D), (src.stride(0), 1), (D, 1), accumulate=True)
+        t = None
+        for li in range(len(v.blocks) - 1, -1, -1):
+            blk, Lp, S = v.blocks[li], P["layers"][li], ctx["saved"][li]
+            hid = Lp["hid"]
             # ---- MLP branch: x_out = x_mid + c_proj([g | T2])
-            ops.cast(dx, t)
+            if t is None:  # (otherwise the previous iteration's LN1 backward already produced t = bf16(dx))
+                add_tap(li)
+                t = torch.empty(M, D, dtype=cd, device=dev)
+                ops.cast(dx, t)
             k2 = Lp["pr"].k
             dg = torch.empty(M, k2, dtype=cd, device=dev)                       # d[g | T2]
             Lp["pr"].dgrad(t, dg)
@@ -363,10 +371,13 @@ class ClipEngine:
                 self._lora_grads(q1, S["a2"][:, D:D + R_PAD], dh, dn[:, D:D + R_PAD], xd1, None, li, 0, grads)
                 ep = dict(ep_mode=ops.EP_MUL, aux=S["mask1"]) if S["mask1"] is not None else {}
                 ops.gemm(dn[:, D:D + R_PAD], Lp["at1"], dn[:, :D], alpha=q1.scaling, residual=dn[:, :D], **ep)
-            ops.layernorm_bwd(dn[:, :D], S["x_mid"], Lp["n2w"], S["st2"], dx, accumulate_dx=True)
+            if fuse_t:
+                ops.layernorm_bwd_scaled(dn[:, :D], S["x_mid"], Lp["n2w"], S["st2"], dx, t, P["ones"], accumulate_dx=True)
+            else:
+                ops.layernorm_bwd(dn[:, :D], S["x_mid"], Lp["n2w"], S["st2"], dx, accumulate_dx=True)
+                ops.cast(dx, t)
             del dg, dh, dn
             # ---- attention branch: x_mid = x_in + out_proj(attn(in_proj(LN1(x_in))))
-            ops.cast(dx, t)
             dao = torch.empty(M, D, dtype=cd, device=dev)
             Lp["out"].dgrad(t, dao)
             qkv = S["qkv"]
@@ -375,7 +386,12 @@ class ClipEngine:
                          dqkv[:, 2 * D:], nimg, H, hd, Np, 1, Np, 1, scale)
             dn1 = torch.empty(M, D, dtype=cd, device=dev)
             Lp["qkv"].dgrad(dqkv, dn1)
-            ops.layernorm_bwd(dn1, S["x_in"], Lp["n1w"], S["st1"], dx, accumulate_dx=True)
+            if fuse_t and li > 0:  # dx becomes d(x_out) of block li-1: its tap gradient goes in first, then LN1 backward
+                add_tap(li - 1)
+                ops.layernorm_bwd_scaled(dn1, S["x_in"], Lp["n1w"], S["st1"], dx, t, P["ones"], accumulate_dx=True)
+            else:
+                ops.layernorm_bwd(dn1, S["x_in"], Lp["n1w"], S["st1"], dx, accumulate_dx=True)
+                t = None
             ctx["saved"][li] = None
             if BACKWARD_EVENTS["block_done"] is not None:
                 BACKWARD_EVENTS["block_done"](li)

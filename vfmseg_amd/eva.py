@@ -289,16 +289,24 @@ class EvaEngine:
         M, Mp, nimg, Np = ctx["M"], ctx["Mp"], ctx["nimg"], ctx["Np"]
         dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
         grads = [None] * (2 * len(v.blocks))
-        for li in range(len(v.blocks) - 1, -1, -1):
-            blk, Lp, S = v.blocks[li], P["layers"][li], ctx["saved"][li]
-            hid, hid_p = Lp["hid"], Lp["hp"]
+        fuse_t = cd == torch.bfloat16 and D % 256 == 0  # LN backward emits the next dgrad operand bf16(dx) itself
+        if fuse_t and "ones" not in P:
+            P["ones"] = torch.ones(D, dtype=torch.float32, device=dev)
+
+        def add_tap(li):
             if li in v.out_indices:
                 i = v.out_indices.index(li)
                 src = dxcat[:, i * D:(i + 1) * D]
                 ops.strided_copy(src, dx, (Mp, D), (src.stride(0), 1), (D, 1), accumulate=True)
+        t = None
+        for li in range(len(v.blocks) - 1, -1, -1):
+            blk, Lp, S = v.blocks[li], P["layers"][li], ctx["saved"][li]
+            hid, hid_p = Lp["hid"], Lp["hp"]
             # ---- SwiGLU branch
-            t = torch.empty(M, D, dtype=cd, device=dev)
-            ops.cast(dx, t)
+            if t is None:  # (otherwise the previous iteration's LN1 backward already produced t = bf16(dx))
+                add_tap(li)
+                t = torch.empty(M, D, dtype=cd, device=dev)
+                ops.cast(dx, t)
             dhn = torch.empty(M, hid_p, dtype=cd, device=dev)
             Lp["w3"].dgrad(t, dhn)
             dhid = torch.zeros(M, hid_p, dtype=torch.float32, device=dev)
@@ -307,10 +315,13 @@ class EvaEngine:
             ops.swiglu_bwd(S["h12"], dhid, dh12, hid_p)
             dn = torch.empty(M, D, dtype=cd, device=dev)
             Lp["w12"].dgrad(dh12, dn)
-            ops.layernorm_bwd(dn, S["x_mid"], Lp["n2w"], S["st2"], dx, accumulate_dx=True)
+            if fuse_t:
+                ops.layernorm_bwd_scaled(dn, S["x_mid"], Lp["n2w"], S["st2"], dx, t, P["ones"], accumulate_dx=True)
+            else:
+                ops.layernorm_bwd(dn, S["x_mid"], Lp["n2w"], S["st2"], dx, accumulate_dx=True)
+                ops.cast(dx, t)
             del dhn, dhid, dh12
             # ---- attention branch
-            ops.cast(dx, t)
             kp = Lp["proj"].k
             dao = torch.empty(M, kp, dtype=cd, device=dev)
             Lp["proj"].dgrad(t, dao)
@@ -322,16 +333,22 @@ class EvaEngine:
                 xd = S["xd"] if S["xd"] is not None else ao[:, :D]
                 gBt = torch.empty(R_PAD, Bm.shape[0], dtype=torch.float32, device=dev)
                 gAp = torch.empty(R_PAD, A.shape[1], dtype=torch.float32, device=dev)
-                _wgrad_small_t(ao[:, D:D + R_PAD], t, gBt)                       # dB^T = T^T @ d(proj out)
-                _wgrad_small_t(dao[:, D:D + R_PAD], xd, gAp, alpha=q.scaling)    # dA = s * dT^T @ drop(attn_out)
                 tB, tA = direct_grad_target(Bm), direct_grad_target(A)
-                if tB is not None:
+                # with a flat gradient buffer the split-K combine scatters straight into B.grad [out, r] / A.grad [r, in]
+                doneB = _wgrad_small_t(ao[:, D:D + R_PAD], t, gBt, scatter=None if tB is None else (tB, r, 1, r))   # dB^T = T^T @ d(proj out)
+                doneA = _wgrad_small_t(dao[:, D:D + R_PAD], xd, gAp, alpha=q.scaling,
+                                       scatter=None if tA is None else (tA, r, A.shape[1], 1))                    # dA = s * dT^T @ drop(attn_out)
+                if doneB is True:
+                    pass
+                elif tB is not None:
                     ops.strided_copy(gBt, tB, (Bm.shape[0], r), (1, gBt.stride(0)), (r, 1), accumulate=True)
                 else:
                     gB = torch.empty_like(Bm, dtype=torch.float32)
                     ops.strided_copy(gBt, gB, (Bm.shape[0], r), (1, gBt.stride(0)), (r, 1))
                     grads[2 * li + 1] = gB
-                if tA is not None:
+                if doneA is True:
+                    pass
+                elif tA is not None:
                     ops.axpby(gAp[:r].reshape(-1), 1.0, tA.view(-1), 1.0)
                 else:
                     grads[2 * li] = gAp[:r]
@@ -344,7 +361,12 @@ class EvaEngine:
             ops.rope(dqkv[:, :2 * D], Mp, Np, 2 * D, hd, P["cos"], P["sin"], inverse=True)
             dn1 = torch.empty(M, D, dtype=cd, device=dev)
             Lp["qkv"].dgrad(dqkv, dn1)
-            ops.layernorm_bwd(dn1, S["x_in"], Lp["n1w"], S["st1"], dx, accumulate_dx=True)
+            if fuse_t and li > 0:  # dx becomes d(x_out) of block li-1: its tap gradient goes in first, then LN1 backward
+                add_tap(li - 1)     # accumulates and emits t = bf16(dx) for that block's w3 dgrad
+                ops.layernorm_bwd_scaled(dn1, S["x_in"], Lp["n1w"], S["st1"], dx, t, P["ones"], accumulate_dx=True)
+            else:
+                ops.layernorm_bwd(dn1, S["x_in"], Lp["n1w"], S["st1"], dx, accumulate_dx=True)
+                t = None
             ctx["saved"][li] = None
             from .backbones import BACKWARD_EVENTS
             if BACKWARD_EVENTS["block_done"] is not None:
