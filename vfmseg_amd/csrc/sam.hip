@@ -451,54 +451,6 @@ __global__ void k_sam_bwd_merge(SamBwdMergeP p) {
     st_any(p.dqkv, row * p.ld + 2 * p.C + h * p.d + c, p.dt, ld_any(p.dvT, tidx, p.dt));
   }
 }
-// Same outputs, one workgroup per (batch bz, window row iy): the S augmented-query gradient rows, the table slice Rh[iy] and the
-// [d, S] pieces of dK^T / dV^T of that row are staged in LDS (the transposed operands are read token-fastest), the column-term
-// table rows Rw[ix] are read from L2 with the output channel on the lane.
-#define SAM_BM_MAXS 32
-#define SAM_BM_MAXD 96
-#define SAM_BM_MAXDQ 160
-__global__ void __launch_bounds__(256) k_sam_bwd_merge_rows(SamBwdMergeP p) {
-  __shared__ float ga[SAM_BM_MAXS][SAM_BM_MAXDQ + 1];
-  __shared__ float rs[SAM_BM_MAXS][SAM_BM_MAXD + 1];
-  __shared__ float tk[SAM_BM_MAXD][SAM_BM_MAXS + 1], tv[SAM_BM_MAXD][SAM_BM_MAXS + 1];
-  const int S = p.S, d = p.d, nwin = p.nws * p.nws;
-  const int iy = (int)(blockIdx.x % S);
-  const long bz = blockIdx.x / S;
-  const int h = (int)(bz % p.H);
-  const long iw = bz / p.H;
-  const int win = (int)(iw % nwin), img = (int)(iw / nwin);
-  const int gy = (win / p.nws) * S + iy;
-  if (gy >= p.G) return;  // a padded window row: none of its tokens exists
-  const int used = d + 2 * S;
-  for (int e = threadIdx.x; e < S * used; e += 256) {
-    const int i = e / used, j = e % used;
-    ga[i][j] = ld_any(p.dqa, (bz * p.NP + iy * S + i) * p.Dq + j, p.dt);
-  }
-  for (int e = threadIdx.x; e < S * d; e += 256) rs[e / d][e % d] = p.rh[((long)iy * S) * d + e];
-  for (int e = threadIdx.x; e < d * S; e += 256) {
-    const int c = e / S, i = e % S;
-    const long tidx = (bz * p.dp + c) * p.NP + iy * S + i;
-    tk[c][i] = ld_any(p.dkT, tidx, p.dt);
-    tv[c][i] = ld_any(p.dvT, tidx, p.dt);
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < S * d; e += 256) {
-    const int i = e / d, c = e % d;
-    const int gx = (win % p.nws) * S + i;
-    if (gx >= p.G) continue;
-    float dq = ga[i][c] * p.scale;
-    const float* rw = p.rw + (long)i * S * d + c;
-    for (int k = 0; k < S; ++k) {
-      dq = fmaf(ga[i][d + k], rs[k][c], dq);
-      dq = fmaf(ga[i][d + S + k], rw[(long)k * d], dq);
-    }
-    const long row = ((long)img * p.G + gy) * p.G + gx;
-    st_any(p.dqkv, row * p.ld + h * d + c, p.dt, dq);
-    st_any(p.dqkv, row * p.ld + p.C + h * d + c, p.dt, tk[c][i]);
-    st_any(p.dqkv, row * p.ld + 2 * p.C + h * d + c, p.dt, tv[c][i]);
-  }
-}
-
 extern "C" int vfm_sam_attn_bwd_merge(const void* dqa, const void* dkT, const void* dvT, int dt, const float* rh, const float* rw,
                                       void* dqkv, long ld, int nimg, int G, int S, int H, int d, int dp, int NP, int Dq, float scale,
                                       void* stream) {
@@ -507,12 +459,6 @@ extern "C" int vfm_sam_attn_bwd_merge(const void* dqa, const void* dkT, const vo
   p.nimg = nimg; p.G = G; p.S = S; p.nws = (G + S - 1) / S; p.H = H; p.d = d; p.C = H * d; p.dp = dp; p.NP = NP; p.Dq = Dq; p.scale = scale;
   const long total = (long)nimg * G * G * H * d;
   if (total == 0) return VFM_OK;
-  if (S <= SAM_BM_MAXS && d <= SAM_BM_MAXD && d + 2 * S <= SAM_BM_MAXDQ) {
-    const long nb = (long)nimg * p.nws * p.nws * H;
-    hipLaunchKernelGGL(k_sam_bwd_merge_rows, dim3((unsigned)(nb * S)), dim3(256), 0, (hipStream_t)stream, p);
-    VFM_LAUNCH_CHECK();
-    return VFM_OK;
-  }
   const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
   hipLaunchKernelGGL(k_sam_bwd_merge, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   VFM_LAUNCH_CHECK();
