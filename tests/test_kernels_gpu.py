@@ -114,6 +114,37 @@ def test_layernorm(C):
     assert relerr(dw, wr.grad) < 2e-5 and relerr(db, br.grad) < 2e-5
 
 
+@pytest.mark.parametrize("C,ld", [(2730, 2752), (1366, 1366), (2731, 2752)])
+def test_layernorm_wide_ragged(C, ld):
+    """EVA02's SwiGLU sub-LN: C = 2730 columns inside 2752-wide buffers (pair-vectorised kernels); odd C takes the scalar path."""
+    rows = 70
+    x = rnd(rows, C, seed=24, scale=1.5) + 0.3
+    w, b = rnd(C, seed=25) * 0.1 + 1, rnd(C, seed=26) * 0.1
+    xr = x.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), w, b, 1e-5)
+    dy = rnd(rows, C, seed=27)
+    ref.backward(dy)
+    xw = torch.zeros(rows, ld, device=DEV)
+    xw[:, :C] = x.to(DEV)
+    yw = torch.full((rows, ld), 7.0, dtype=torch.bfloat16, device=DEV)
+    stats = torch.empty(rows, 2, device=DEV)
+    ops.layernorm_fwd(xw[:, :C], w.to(DEV), b.to(DEV), 1e-5, yw[:, :C], stats)
+    assert relerr(yw[:, :C].float(), ref) < 1e-2 and (yw[:, C:] == 7.0).all()
+    yf = torch.empty(rows, C, device=DEV)
+    ops.layernorm_fwd(xw[:, :C], w.to(DEV), b.to(DEV), 1e-5, yf, None)
+    assert relerr(yf, ref) < 1e-5
+    for dt in (torch.float32, torch.bfloat16):
+        dyw = torch.zeros(rows, ld, dtype=dt, device=DEV)
+        dyw[:, :C] = dy.to(DEV).to(dt)
+        dxw = torch.full((rows, ld), 3.0, device=DEV)
+        ops.layernorm_bwd(dyw[:, :C], xw[:, :C], w.to(DEV), stats, dxw[:, :C], accumulate_dx=False)
+        xr2 = x.clone().requires_grad_(True)
+        F.layer_norm(xr2, (C,), w, b, 1e-5).backward(dyw[:, :C].float().cpu())
+        assert relerr(dxw[:, :C], xr2.grad) < 3e-5 and (dxw[:, C:] == 3.0).all()
+        ops.layernorm_bwd(dyw[:, :C], xw[:, :C], w.to(DEV), stats, dxw[:, :C], accumulate_dx=True)
+        assert relerr(dxw[:, :C], 2 * xr2.grad) < 3e-5
+
+
 @pytest.mark.parametrize("C", [1024, 1280])
 def test_layernorm_fused_variants(C):
     """LN forward + LoRA dropout and LN backward + scaled bf16 copy: bit-identical to the separate kernels they replace."""

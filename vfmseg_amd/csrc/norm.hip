@@ -163,6 +163,52 @@ __global__ void k_ln_bwd_v4(const TD* __restrict__ dy, long ld_dy, const float* 
   }
 }
 
+template <typename TO, int MAXP2>
+__global__ void k_ln_fwd_v2(const float* __restrict__ x, long ld_x, const float* __restrict__ w, const float* __restrict__ b, float eps,
+                            TO* __restrict__ y, long ld_y, float* __restrict__ stats, long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ld_x;
+  float2 v[MAXP2];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP2; ++i) {
+    const int c = (i * 64 + lane) * 2;
+    v[i] = c < C ? *reinterpret_cast<const float2*>(xr + c) : make_float2(0.f, 0.f);
+    s += v[i].x + v[i].y;
+  }
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP2; ++i) {
+    const int c = (i * 64 + lane) * 2;
+    if (c < C) {
+      const float a = v[i].x - mean, bb = v[i].y - mean;
+      q += a * a + bb * bb;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+  if (stats && lane == 0) {
+    stats[row * 2] = mean;
+    stats[row * 2 + 1] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXP2; ++i) {
+    const int c = (i * 64 + lane) * 2;
+    if (c < C) {
+      const float2 ww = *reinterpret_cast<const float2*>(w + c), bv = *reinterpret_cast<const float2*>(b + c);
+      const float o0 = (v[i].x - mean) * rstd * ww.x + bv.x, o1 = (v[i].y - mean) * rstd * ww.y + bv.y;
+      if constexpr (sizeof(TO) == 2) {
+        const ushort2 pk = {f32_to_bf16(o0), f32_to_bf16(o1)};
+        *reinterpret_cast<ushort2*>(y + row * ld_y + c) = pk;
+      } else {
+        *reinterpret_cast<float2*>(y + row * ld_y + c) = make_float2(o0, o1);
+      }
+    }
+  }
+}
+
 extern "C" int vfm_layernorm_fwd(const float* x, long ld_x, const float* w, const float* b, float eps, void* y, int y_dt,
                                  long ld_y, float* stats, long rows, long C, void* stream) {
   VFM_CHECK(C > 0 && C <= 3072 && ld_x >= C && ld_y >= C, VFM_E_SHAPE, "vfm_layernorm_fwd: C=%ld unsupported", C);
@@ -180,6 +226,14 @@ extern "C" int vfm_layernorm_fwd(const float* x, long ld_x, const float* w, cons
     else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_fwd: dtype");
 #undef LV
     if (!(nv == 1 || nv == 2 || nv == 4 || nv == 5 || nv == 8)) VFM_FAIL(VFM_E_SHAPE, "vfm_layernorm_fwd: C=%ld", C);
+    VFM_LAUNCH_CHECK();
+    return VFM_OK;
+  }
+  if (C > 1024 && C % 2 == 0 && ld_x % 2 == 0 && ld_y % 2 == 0 && (uintptr_t)x % 8 == 0 && (uintptr_t)y % 8 == 0 && (uintptr_t)w % 8 == 0 &&
+      (uintptr_t)b % 8 == 0) {
+    if (y_dt == VFM_BF16) hipLaunchKernelGGL((k_ln_fwd_v2<bf16_t, 24>), grid, blk, 0, s, x, ld_x, w, b, eps, (bf16_t*)y, ld_y, stats, rows, (int)C);
+    else if (y_dt == VFM_F32) hipLaunchKernelGGL((k_ln_fwd_v2<float, 24>), grid, blk, 0, s, x, ld_x, w, b, eps, (float*)y, ld_y, stats, rows, (int)C);
+    else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_fwd: dtype");
     VFM_LAUNCH_CHECK();
     return VFM_OK;
   }
@@ -309,6 +363,54 @@ extern "C" int vfm_layernorm_bwd_scaled(const void* dy, int dy_dt, long ld_dy, c
   return ln_bwd_impl(dy, dy_dt, ld_dy, x, ld_x, w, stats, dx, ld_dx, accumulate_dx, nullptr, nullptr, nullptr, rows, C, t_out, ld_t,
                      t_scale, stream);
 }
+// wide rows whose width is not a multiple of 256 (EVA02's SwiGLU sub-LN: C = 2730): each lane owns PAIRS of columns, so the row
+// moves in 8-byte (fp32) / 4-byte (bf16) pieces instead of the scalar pieces of k_ln_bwd / k_ln_fwd.  C % 2 == 0.
+template <typename TD, int MAXP2>
+__global__ void k_ln_bwd_v2(const TD* __restrict__ dy, long ld_dy, const float* __restrict__ x, long ld_x, const float* __restrict__ w,
+                            const float* __restrict__ stats, float* __restrict__ dx, long ld_dx, int accumulate_dx, long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+  float2 g[MAXP2], xh[MAXP2];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP2; ++i) {
+    const int c = (i * 64 + lane) * 2;
+    g[i] = xh[i] = make_float2(0.f, 0.f);
+    if (c < C) {
+      float2 d;
+      if constexpr (sizeof(TD) == 2) {
+        const ushort2 pp = *reinterpret_cast<const ushort2*>(dy + row * ld_dy + c);
+        d = make_float2(bf16_to_f32(pp.x), bf16_to_f32(pp.y));
+      } else {
+        d = *reinterpret_cast<const float2*>(dy + row * ld_dy + c);
+      }
+      const float2 xv = *reinterpret_cast<const float2*>(x + row * ld_x + c);
+      const float2 ww = *reinterpret_cast<const float2*>(w + c);
+      xh[i] = make_float2((xv.x - mean) * rstd, (xv.y - mean) * rstd);
+      g[i] = make_float2(d.x * ww.x, d.y * ww.y);
+      s1 += g[i].x + g[i].y;
+      s2 += g[i].x * xh[i].x + g[i].y * xh[i].y;
+    }
+  }
+  s1 = wave_sum(s1) / C;
+  s2 = wave_sum(s2) / C;
+#pragma unroll
+  for (int i = 0; i < MAXP2; ++i) {
+    const int c = (i * 64 + lane) * 2;
+    if (c < C) {
+      float2 o = make_float2(rstd * (g[i].x - s1 - xh[i].x * s2), rstd * (g[i].y - s1 - xh[i].y * s2));
+      float2* pp = reinterpret_cast<float2*>(dx + row * ld_dx + c);
+      if (accumulate_dx) {
+        const float2 old = *pp;
+        o.x += old.x, o.y += old.y;
+      }
+      *pp = o;
+    }
+  }
+}
+
 static int ln_bwd_impl(const void* dy, int dy_dt, long ld_dy, const float* x, long ld_x, const float* w, const float* stats,
                        float* dx, long ld_dx, int accumulate_dx, float* dw, float* db, float* ws, long rows, long C, void* t_out,
                        long ld_t, const float* t_scale, void* stream) {
@@ -332,6 +434,17 @@ static int ln_bwd_impl(const void* dy, int dy_dt, long ld_dy, const float* x, lo
     return VFM_OK;
   }
   VFM_CHECK(!t_out, VFM_E_UNSUPPORTED, "vfm_layernorm_bwd_scaled: needs the vectorised path (C %% 256 == 0, aligned operands, no dw/db)");
+  if (!need_w && C > 1024 && C % 2 == 0 && ld_x % 2 == 0 && ld_dx % 2 == 0 && ld_dy % 2 == 0 && (uintptr_t)x % 8 == 0 &&
+      (uintptr_t)dx % 8 == 0 && (uintptr_t)dy % 8 == 0 && (uintptr_t)w % 8 == 0) {
+    dim3 grid(cdiv(rows, 4)), blk(256);
+    if (dy_dt == VFM_BF16)
+      hipLaunchKernelGGL((k_ln_bwd_v2<bf16_t, 24>), grid, blk, 0, s, (const bf16_t*)dy, ld_dy, x, ld_x, w, stats, dx, ld_dx, accumulate_dx, rows, (int)C);
+    else if (dy_dt == VFM_F32)
+      hipLaunchKernelGGL((k_ln_bwd_v2<float, 24>), grid, blk, 0, s, (const float*)dy, ld_dy, x, ld_x, w, stats, dx, ld_dx, accumulate_dx, rows, (int)C);
+    else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_bwd: dtype");
+    VFM_LAUNCH_CHECK();
+    return VFM_OK;
+  }
   const int parts = need_w ? 128 : cdiv(rows, 4);
   const size_t shm = need_w ? (size_t)4 * 2 * C * sizeof(float) : 0;
   float* wsp = need_w ? ws : nullptr;
