@@ -48,6 +48,9 @@ if __name__ == "__main__":
     if only == "sam":
         run("SAM-ViT-H + LoRA(qkv) + LinearHead + VFMHead (lora_sam_ms_masked)", "sam_ms_masked", steps=3, warmup=1)
         sys.exit(0)
+    if only == "clip":
+        run("CLIP ViT-L/16 + LoRA(mlp.c_fc, mlp.c_proj) + LinearHead + VFMHead (lora_clip_ms_masked)", "clip_ms_masked", steps=4, warmup=2)
+        sys.exit(0)
     if only == "eva":
         run("EVA02-L + LoRA(attn.proj) + LinearHead + VFMHead (lora_eva02_ms_masked)", "eva02_ms_masked", steps=4, warmup=2)
         sys.exit(0)

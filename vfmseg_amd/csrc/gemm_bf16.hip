@@ -306,6 +306,7 @@ static void launch_skinny(const vfm_gemm_desc* d, hipStream_t s) {
 
 static int g_force_cfg = -1;
 static int g_split_tail = 3;  // bit 0: peel the tail rows of M off; bit 1: ... except for shapes on the 64-row tiles
+static int g_batch_tiles = 1;  // count the batch in the tile-count heuristics
 static int g_bt64 = 1;       // transposed-B GEMMs with few tiles use 64-row tiles
 static int g_fold_tail = 1;  // run the tail rows as extra blocks of the tile kernel's launch
 // bit 0: 256x256 ping-pong kernel instead of config 16; bit 1: 128x128 ping-pong kernel (gemm_pp.hip); bit 3: N >= 2048 stays
@@ -329,6 +330,10 @@ extern "C" int vfm_tune(const char* key, int value) {
   }
   if (key && strcmp(key, "gemm_use_pp") == 0) {
     g_use_pp = value;
+    return VFM_OK;
+  }
+  if (key && strcmp(key, "gemm_batch_tiles") == 0) {
+    g_batch_tiles = value;
     return VFM_OK;
   }
   if (key && strcmp(key, "gemm_bt64") == 0) {
@@ -422,7 +427,8 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
   int cfg = g_force_cfg;
   if (cfg < 0) {
     // measured on MI355X (tools/bench_gemm.py): with ~one wave of tiles, occupancy (waves per SIMD) decides
-    const long t128 = (long)cdiv(d->M, 128) * cdiv(d->N, 128);
+    const long nbatch = d->batch > 0 ? d->batch : 1;  // batched launches (SAM's per-window products) fill the chip with their batch
+    const long t128 = (long)cdiv(d->M, 128) * cdiv(d->N, 128) * (g_batch_tiles ? nbatch : 1);
     const long t256 = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
     if (d->N <= 32) cfg = 10;                                        // 64x64 tiles: many rows, few columns
     else if (t128 <= 160 && d->K >= 512 && (long)cdiv(d->M, 64) * cdiv(d->N, 64) <= 512)
