@@ -325,6 +325,34 @@ class DinoEngine:
                 sites.append((A, Bm, Lp["a"], Lp["at"], Lp["qkv"].w, Lp["qkv"].wt, q.r, A.shape[1], Bm.shape[0], D))
         _refresh_sites(P, sites)
 
+    def merged_qkv(self, P):
+        """Inference only (no LoRA dropout): per layer the bf16 copy of W + s * B A, so that the QKV projection is ONE K = D GEMM
+        (no T = x A^T GEMM, no K extension).  Rebuilt when a LoRA factor changed (torch version counters, data pointers, and
+        the optimiser's epoch for the fused AdamW kernel that updates parameters behind torch's back)."""
+        from .optim import PARAM_EPOCH
+        key = [PARAM_EPOCH[0]]
+        for blk in self.vit.blocks:
+            q = blk.attn.qkv
+            A, Bm = q.lora_A["default"].weight, q.lora_B["default"].weight
+            key += [A._version, Bm._version, A.data_ptr(), Bm.data_ptr()]
+        key = tuple(key)
+        if P.get("merged_key") == key:
+            return P["merged"]
+        D, cd, dev = self.vit.embed_dim, P["cd"], P["dev"]
+        merged = []
+        with torch.no_grad():
+            for blk in self.vit.blocks:
+                q = blk.attn.qkv
+                A, Bm = q.lora_A["default"].weight.detach().float(), q.lora_B["default"].weight.detach().float()
+                w = q.base_layer.weight.detach().float()
+                weff = torch.empty_like(w)
+                ops.gemm(Bm.contiguous(), A.contiguous(), weff, alpha=q.scaling, residual=w, trans_b=True)   # W + s * B A   (fp32 MFMA)
+                wp = ops.empty_ld(w.shape[0], D, cd, dev)
+                ops.cast(weff, wp)
+                merged.append(wp)
+        P["merged"], P["merged_key"] = merged, key
+        return merged
+
     def pos_tokens(self, hp, wp):
         v = self.vit
         n = v.pos_embed.shape[1] - 1
@@ -352,7 +380,11 @@ class DinoEngine:
         dev = P["dev"]
         D, H, ps = v.embed_dim, v.num_heads, v.patch_size
         lora = self.lora_on()
-        if lora:
+        merged = None
+        if (lora and not training and not torch.is_grad_enabled() and cd == torch.bfloat16
+                and os.environ.get("VFMSEG_MERGE_LORA_EVAL", "1") != "0"):
+            merged = self.merged_qkv(P)
+        elif lora:
             self.refresh_lora(P)
         sizes = []
         for img, box in jobs:
@@ -382,7 +414,7 @@ class DinoEngine:
         scale = hd ** -0.5
         for li, (blk, Lp) in enumerate(zip(v.blocks, P["layers"])):
             S = {"x_in": x}
-            kq = Lp["qkv"].k
+            kq = D if merged is not None else Lp["qkv"].k
             a1 = torch.empty(M, kq, dtype=cd, device=dev)  # [LN(x) | T]: the T GEMM writes all R_PAD columns (A is zero-padded)
             st1 = torch.empty(M, 2, dtype=torch.float32, device=dev)
             q = blk.attn.qkv if lora else None
@@ -393,7 +425,7 @@ class DinoEngine:
                 ops.layernorm_dropout_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1, xd, mask, q.p, seed, offset=li * M * D)
             else:
                 ops.layernorm_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1)
-            if lora:
+            if lora and merged is None:
                 if not fused_drop:
                     xd, mask = a1[:, :D], None
                     if training and q.p > 0:
@@ -404,7 +436,10 @@ class DinoEngine:
                 ops.gemm(xd, Lp["a"], a1[:, D:D + R_PAD], alpha=q.scaling)  # T = s * drop(xn) A^T
                 S.update(xd=xd if mask is not None else None, mask=mask)
             qkv = torch.empty(M, 3 * D, dtype=cd, device=dev)
-            Lp["qkv"].fwd(a1, qkv, bias=Lp["qkv_b"])
+            if merged is not None:
+                ops.gemm(a1, merged[li], qkv, bias=Lp["qkv_b"])
+            else:
+                Lp["qkv"].fwd(a1, qkv, bias=Lp["qkv_b"])
             ao = torch.empty(M, D, dtype=cd, device=dev)
             lse = torch.empty(nimg, H, Np + 1, dtype=torch.float32, device=dev)
             ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ao, lse, nimg, H, hd, Np, 1, Np, 1, scale)

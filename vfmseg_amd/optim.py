@@ -70,6 +70,9 @@ def production_order(names):
     return sorted(names, key=key)
 
 
+# bumped by every FusedAdamW.step(): caches derived from parameter values (merged LoRA weights for inference) key on it
+PARAM_EPOCH = [0]
+
 class PolyLR:
     """mmengine PolyLR(by_epoch=False): lr_t = (base - eta_min) * (1 - t/T)^power + eta_min, t = steps taken."""
 
@@ -130,6 +133,7 @@ class FusedAdamW:
 
     def step(self, lr=None, grad_scale=1.0):
         self.step_count += 1
+        PARAM_EPOCH[0] += 1  # the fused kernel rewrites the parameters behind torch's version counters
         lr = self.lr if lr is None else lr
         self.param_groups[0]["lr"] = lr
         ops.adamw(self.flat, self.gflat, self.m, self.v, self.seg_start, self.seg_lr, self.seg_wd, lr, self.betas, self.eps,
