@@ -200,6 +200,30 @@ __global__ void k_softmax_rows(const float* __restrict__ s, long ld_s, void* __r
   const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* sr = s + row * ld_s;
+  if (n <= 1024) {  // the row lives in registers: one read, one exponential per element
+    float v[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = i * 64 + lane;
+      v[i] = c < n ? sr[c] : -INFINITY;
+      m = fmaxf(m, v[i]);
+    }
+    m = wave_max(m);
+    float z = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      v[i] = __expf(v[i] - m);  // exp(-inf) = 0 for the columns past n
+      z += v[i];
+    }
+    const float inv = 1.f / wave_sum(z);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = i * 64 + lane;
+      if (c < npad) st_any(out, row * ld_o + c, out_dt, v[i] * inv);
+    }
+    return;
+  }
   float m = -INFINITY;
   for (int c = lane; c < n; c += 64) m = fmaxf(m, sr[c]);
   m = wave_max(m);
@@ -374,6 +398,30 @@ __global__ void k_softmax_rows_b(const float* __restrict__ s, long ld_s, void* _
   if (row >= rows) return;
   const bool live = (int)(row % rpb) < valid;
   const float* sr = s + row * ld_s;
+  if (!ds && n <= 1024) {  // forward, row in registers (see k_softmax_rows)
+    float v[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = i * 64 + lane;
+      v[i] = (live && c < n) ? sr[c] : -INFINITY;
+      m = fmaxf(m, v[i]);
+    }
+    m = live ? wave_max(m) : 0.f;
+    float z = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      v[i] = __expf(v[i] - m);
+      z += v[i];
+    }
+    const float inv = live ? 1.f / wave_sum(z) : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = i * 64 + lane;
+      if (c < npad) st_any(out, row * ld_o + c, out_dt, live ? v[i] * inv : 0.f);
+    }
+    return;
+  }
   if (!ds) {
     float m = -INFINITY, z = 1.f;
     if (live) {
