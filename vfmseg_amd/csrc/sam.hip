@@ -433,6 +433,23 @@ __global__ void k_softmax_rows_b(const float* __restrict__ s, long ld_s, void* _
     }
     const float inv = 1.f / z;
     for (int c = lane; c < npad; c += 64) st_any(out, row * ld_o + c, out_dt, (live && c < n) ? __expf(sr[c] - m) * inv : 0.f);
+  } else if (n <= 1024) {  // softmax backward with the row of p and of dp in registers
+    float pv[16], dv[16];
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = i * 64 + lane;
+      const bool ok = live && c < n;
+      pv[i] = ok ? ld_any(pin, row * ld_o + c, out_dt) : 0.f;
+      dv[i] = ok ? sr[c] : 0.f;
+      dot = fmaf(pv[i], dv[i], dot);
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = i * 64 + lane;
+      if (c < npad) st_any(ds, row * ld_o + c, out_dt, pv[i] * (dv[i] - dot));
+    }
   } else {
     float dot = 0.f;
     if (live) {
