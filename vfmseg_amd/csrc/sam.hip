@@ -172,6 +172,88 @@ __global__ void __launch_bounds__(256) k_sam_prep_rows(SamPrepP p) {
   }
 }
 
+// bf16 form of k_sam_prep_rows with two channels per lane: 4-byte loads and stores instead of 2-byte ones (the kernel is bound
+// by the number of memory instructions, not by bytes).  d, S, Dq, ld even; all bases 4-byte aligned.
+__global__ void __launch_bounds__(256) k_sam_prep_rows_bf16x2(SamPrepP p) {
+  __shared__ float qs[SAM_PREP_MAXS][SAM_PREP_MAXD + 1];
+  __shared__ float rs[SAM_PREP_MAXS][SAM_PREP_MAXD + 1];
+  const int S = p.S, d = p.d, d2 = d >> 1, S2h = S * (S >> 1);
+  const int nwin = p.nwin_side * p.nwin_side;
+  const int pass = blockIdx.y;
+  const long blk = blockIdx.x;
+  const int line = (int)(blk % S);
+  const long bz = blk / S;
+  const int h = (int)(bz % p.H);
+  const long iw = bz / p.H;
+  const int win = (int)(iw % nwin), img = (int)(iw / nwin);
+  const int tid = threadIdx.x;
+  const int wy = (win / p.nwin_side) * S, wx = (win % p.nwin_side) * S;
+  const bf16_t* qkv = (const bf16_t*)p.qkv;
+  bf16_t* qa = (bf16_t*)p.qa;
+  bf16_t* ka = (bf16_t*)p.ka;
+  bf16_t* vw = (bf16_t*)p.vw;
+  auto ld2 = [&](long idx) -> float2 {
+    const ushort2 u = *reinterpret_cast<const ushort2*>(qkv + idx);
+    return make_float2(bf16_to_f32(u.x), bf16_to_f32(u.y));
+  };
+  auto st2 = [&](bf16_t* base, long idx, float a, float b) {
+    const ushort2 u = {f32_to_bf16(a), f32_to_bf16(b)};
+    *reinterpret_cast<ushort2*>(base + idx) = u;
+  };
+  for (int e = tid; e < S * d2; e += 256) {
+    const int i = e / d2, c = (e - i * d2) * 2;
+    const int iy = pass == 0 ? line : i, ix = pass == 0 ? i : line;
+    const int tok = iy * S + ix;
+    const int gy = wy + iy, gx = wx + ix;
+    const bool inside = gy < p.G && gx < p.G;
+    const long base = (((long)img * p.G + gy) * p.G + gx) * p.ld + h * d + c;
+    const float2 qv = inside ? ld2(base) : (p.bias ? make_float2(p.bias[h * d + c], p.bias[h * d + c + 1]) : make_float2(0.f, 0.f));
+    qs[i][c] = qv.x;
+    qs[i][c + 1] = qv.y;
+    if (pass == 0) {
+      const float2 kv = inside ? ld2(base + p.C) : (p.bias ? make_float2(p.bias[p.C + h * d + c], p.bias[p.C + h * d + c + 1]) : make_float2(0.f, 0.f));
+      const float2 vv = inside ? ld2(base + 2 * p.C)
+                               : (p.bias ? make_float2(p.bias[2 * p.C + h * d + c], p.bias[2 * p.C + h * d + c + 1]) : make_float2(0.f, 0.f));
+      const long o = (bz * p.rpb + tok) * p.Dq + c;
+      st2(qa, o, qv.x * p.scale, qv.y * p.scale);
+      st2(ka, o, kv.x, kv.y);
+      st2(vw, (bz * p.NP + tok) * d + c, vv.x, vv.y);
+    }
+  }
+  const float* tab = (pass == 0 ? p.rh : p.rw) + (long)line * S * d;
+  for (int e = tid; e < S * d2; e += 256) {
+    const int k = e / d2, c = (e - k * d2) * 2;
+    const float2 t = *reinterpret_cast<const float2*>(tab + k * d + c);
+    rs[k][c] = t.x;
+    rs[k][c + 1] = t.y;
+  }
+  if (pass == 0) {
+    const int extra2 = (p.Dq - d) >> 1;
+    for (int e = tid; e < S * extra2; e += 256) {
+      const int i = e / extra2, j = d + (e - i * extra2) * 2;
+      const long o = (bz * p.rpb + line * S + i) * p.Dq + j;
+      float k0 = 0.f, k1 = 0.f;
+      if (j < d + S) k0 = (j - d == line) ? 1.f : 0.f, k1 = (j + 1 - d == line) ? 1.f : 0.f;
+      else if (j < d + 2 * S) k0 = (j - d - S == i) ? 1.f : 0.f, k1 = (j + 1 - d - S == i) ? 1.f : 0.f;
+      st2(ka, o, k0, k1);
+      if (j >= d + 2 * S) st2(qa, o, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < S2h; e += 256) {
+    const int i = e / (S >> 1), kk = (e - i * (S >> 1)) * 2;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < d; ++c) {
+      const float qv = qs[i][c];
+      a0 = fmaf(qv, rs[kk][c], a0);
+      a1 = fmaf(qv, rs[kk + 1][c], a1);
+    }
+    const int tok = pass == 0 ? line * S + i : i * S + line;
+    st2(qa, (bz * p.rpb + tok) * p.Dq + d + pass * S + kk, a0, a1);
+  }
+}
+
 extern "C" int vfm_sam_attn_prep(const void* qkv, int dt, long ld, const float* bias, const float* rh, const float* rw, void* q_aug,
                                  void* k_aug, void* v_win, int nimg, int G, int S, int H, int d, int Dq, int NP, int rows_per_batch,
                                  float scale, void* stream) {
@@ -183,7 +265,10 @@ extern "C" int vfm_sam_attn_prep(const void* qkv, int dt, long ld, const float* 
   if (total == 0) return VFM_OK;
   if (S <= SAM_PREP_MAXS && d <= SAM_PREP_MAXD) {
     const long nb = (long)nimg * p.nwin_side * p.nwin_side * H;
-    hipLaunchKernelGGL(k_sam_prep_rows, dim3((unsigned)(nb * S), 2), dim3(256), 0, (hipStream_t)stream, p);
+    const bool x2 = dt == VFM_BF16 && d % 2 == 0 && S % 2 == 0 && Dq % 2 == 0 && ld % 2 == 0 && (H * d) % 2 == 0 && (uintptr_t)qkv % 4 == 0 &&
+                    (uintptr_t)q_aug % 4 == 0 && (uintptr_t)k_aug % 4 == 0 && (uintptr_t)v_win % 4 == 0 && (uintptr_t)rh % 8 == 0 && (uintptr_t)rw % 8 == 0;
+    if (x2) hipLaunchKernelGGL(k_sam_prep_rows_bf16x2, dim3((unsigned)(nb * S), 2), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(k_sam_prep_rows, dim3((unsigned)(nb * S), 2), dim3(256), 0, (hipStream_t)stream, p);
     VFM_LAUNCH_CHECK();
     return VFM_OK;
   }
