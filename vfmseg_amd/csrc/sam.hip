@@ -346,10 +346,37 @@ __global__ void k_sam_merge(const void* __restrict__ ow, int dt, void* __restric
     st_any(out, row * ld + h * d + c, dt, ld_any(ow, (bz * NP + tok) * d + c, dt));
   }
 }
+__global__ void k_sam_merge_bf16x2(const bf16_t* __restrict__ ow, bf16_t* __restrict__ out, long ld, int nimg, int G, int S, int nws,
+                                   int H, int d, int NP) {
+  const int d2 = d >> 1;
+  const long total = (long)nimg * G * G * H * d2;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % d2) * 2;
+    long t = idx / d2;
+    const int h = (int)(t % H);
+    t /= H;
+    const int gx = (int)(t % G);
+    t /= G;
+    const int gy = (int)(t % G);
+    const int img = (int)(t / G);
+    const int win = (gy / S) * nws + gx / S, tok = (gy % S) * S + gx % S;
+    const long bz = ((long)img * nws * nws + win) * H + h;
+    const long row = ((long)img * G + gy) * G + gx;
+    *reinterpret_cast<ushort2*>(out + row * ld + h * d + c) = *reinterpret_cast<const ushort2*>(ow + (bz * NP + tok) * d + c);
+  }
+}
 extern "C" int vfm_sam_attn_merge(const void* o_win, int dt, void* out, long ld, int nimg, int G, int S, int H, int d, int NP,
                                   void* stream) {
   const long total = (long)nimg * G * G * H * d;
   if (total == 0) return VFM_OK;
+  if (dt == VFM_BF16 && d % 2 == 0 && ld % 2 == 0 && (uintptr_t)o_win % 4 == 0 && (uintptr_t)out % 4 == 0) {
+    const long t2 = total / 2;
+    const int grid2 = (int)((t2 + 255) / 256 > 16384 ? 16384 : (t2 + 255) / 256);
+    hipLaunchKernelGGL(k_sam_merge_bf16x2, dim3(grid2), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)o_win, (bf16_t*)out, ld, nimg, G, S,
+                       (G + S - 1) / S, H, d, NP);
+    VFM_LAUNCH_CHECK();
+    return VFM_OK;
+  }
   const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipLaunchKernelGGL(k_sam_merge, dim3(grid), dim3(256), 0, (hipStream_t)stream, o_win, dt, out, ld, nimg, G, S, (G + S - 1) / S, H, d, NP);
   VFM_LAUNCH_CHECK();
