@@ -114,6 +114,46 @@ def test_layernorm(C):
     assert relerr(dw, wr.grad) < 2e-5 and relerr(db, br.grad) < 2e-5
 
 
+def test_elementwise_bf16_vector_paths():
+    """The 8-elements-per-lane bf16 forms of dropout mask / mask multiply / activation-gradient multiply / SwiGLU (aligned rows
+    inside wider buffers) against the scalar forms on a one-element-shifted (misaligned) copy of the same data and against torch."""
+    rows, C, ld = 37, 256, 264
+    def wide(t, shift=0):  # bf16 [rows, C] view inside a [rows, ld] buffer; shift=1 misaligns it -> scalar kernels
+        buf = torch.zeros(rows * ld + 8, dtype=torch.bfloat16, device=DEV)
+        v = buf[shift:shift + rows * ld].view(rows, ld)[:, :C]
+        v.copy_(t)
+        return v
+    x, y = rnd(rows, C, seed=90).bfloat16().to(DEV), rnd(rows, C, seed=91).bfloat16().to(DEV)
+    # dropout mask: identical counter-based values from both forms
+    m8, m1 = torch.empty(rows * C, dtype=torch.bfloat16, device=DEV), torch.empty(rows * C + 1, dtype=torch.bfloat16, device=DEV)
+    ops.dropout_mask(m8, 0.3, 1234, offset=77)
+    ops.dropout_mask(m1[1:], 0.3, 1234, offset=77)
+    assert torch.equal(m8, m1[1:]) and 0.6 < (m8 > 0).float().mean() < 0.8
+    mask = m8.view(rows, C)
+    for shift in (0, 1):
+        out = wide(torch.zeros(rows, C), shift)
+        ops.mul_mask(wide(x, shift), wide(mask, shift), out)
+        assert relerr(out.float(), x.float() * mask.float()) < 1e-2
+        for act, fn in ((ops.ACT_GELU, lambda t: 0.5 * (1 + torch.erf(t / 2 ** 0.5)) + t * torch.exp(-0.5 * t * t) / (2 * 3.141592653589793) ** 0.5),
+                        (ops.ACT_RELU, lambda t: (t > 0).double()), (ops.ACT_QGELU, lambda t: torch.sigmoid(1.702 * t) * (1 + 1.702 * t * (1 - torch.sigmoid(1.702 * t))))):
+            ops.act_grad_mul(wide(x, shift), wide(y, shift), out, act)
+            assert relerr(out.float(), x.double().cpu() * fn(y.double().cpu())) < 1.2e-2, (shift, act)
+    # SwiGLU: h = [a | g] bf16, fp32 product (EVA02) and bf16 product; backward with fp32 dout
+    h = rnd(rows, 2 * C, seed=92).bfloat16().to(DEV)
+    a, g = h[:, :C].double().cpu(), h[:, C:].double().cpu()
+    ref = a * torch.sigmoid(a) * g
+    of, ob = torch.empty(rows, C, device=DEV), torch.empty(rows, C, dtype=torch.bfloat16, device=DEV)
+    ops.swiglu_fwd(h, of, C)
+    ops.swiglu_fwd(h, ob, C)
+    assert relerr(of, ref) < 1e-5 and relerr(ob.float(), ref) < 1e-2
+    dout = rnd(rows, C, seed=93).to(DEV)
+    dh = torch.empty(rows, 2 * C, dtype=torch.bfloat16, device=DEV)
+    ops.swiglu_bwd(h, dout, dh, C)
+    sg = torch.sigmoid(a)
+    d = dout.double().cpu()
+    assert relerr(dh[:, :C].float(), d * g * sg * (1 + a * (1 - sg))) < 1e-2 and relerr(dh[:, C:].float(), d * a * sg) < 1e-2
+
+
 @pytest.mark.parametrize("C,ld", [(2730, 2752), (1366, 1366), (2731, 2752)])
 def test_layernorm_wide_ragged(C, ld):
     """EVA02's SwiGLU sub-LN: C = 2730 columns inside 2752-wide buffers (pair-vectorised kernels); odd C takes the scalar path."""
