@@ -154,6 +154,32 @@ def test_elementwise_bf16_vector_paths():
     assert relerr(dh[:, :C].float(), d * g * sg * (1 + a * (1 - sg))) < 1e-2 and relerr(dh[:, C:].float(), d * a * sg) < 1e-2
 
 
+def test_rope_vector_path():
+    """EVA02 RoPE (eva_02.py:119-160): the 8-columns-per-lane bf16 form against the scalar form (same data, misaligned by one
+    element) and against the rotation written out in torch; inverse = transpose."""
+    rows, np_, H, d = 3 * 16, 16, 4, 64
+    ncols = H * d
+    x = rnd(rows, ncols, seed=95).bfloat16()
+    ang = rnd(np_, d // 2, seed=96)
+    cos_t = torch.cos(ang).repeat_interleave(2, dim=1).contiguous().to(DEV)
+    sin_t = torch.sin(ang).repeat_interleave(2, dim=1).contiguous().to(DEV)
+    xv = x.float().view(rows, H, d // 2, 2)
+    t = torch.arange(rows) % np_
+    c, s_ = torch.cos(ang)[t][:, None, :], torch.sin(ang)[t][:, None, :]
+    ref = torch.stack([xv[..., 0] * c - xv[..., 1] * s_, xv[..., 1] * c + xv[..., 0] * s_], dim=-1).view(rows, ncols)
+    buf = torch.zeros(rows * ncols + 8, dtype=torch.bfloat16, device=DEV)
+    outs = []
+    for shift in (0, 1):
+        v = buf[shift:shift + rows * ncols].view(rows, ncols)
+        v.copy_(x)
+        ops.rope(v, rows, np_, ncols, d, cos_t, sin_t)
+        outs.append(v.clone())
+        assert relerr(v.float(), ref) < 1e-2
+        ops.rope(v, rows, np_, ncols, d, cos_t, sin_t, inverse=True)
+        assert relerr(v.float(), x.float()) < 2e-2
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("C,ld", [(2730, 2752), (1366, 1366), (2731, 2752)])
 def test_layernorm_wide_ragged(C, ld):
     """EVA02's SwiGLU sub-LN: C = 2730 columns inside 2752-wide buffers (pair-vectorised kernels); odd C takes the scalar path."""

@@ -549,11 +549,40 @@ __global__ void k_rope(void* __restrict__ x, int dt, long ld, long rows, int np,
     st_any(x, r * ld + c0 + 1, dt, y1);
   }
 }
+__global__ void k_rope_bf16x8(bf16_t* __restrict__ x, long ld, long rows, int np, int c8n, int d, const float* __restrict__ cs,
+                              const float* __restrict__ sn, int inverse) {
+  const long total = rows * c8n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / c8n;
+    const int c0 = (int)(i - r * c8n) * 8;
+    const int t = (int)(r % np), dc = c0 % d;
+    F8 v = ld8_bf16(x + r * ld + c0);
+    const F8 c = ld8_f32(cs + (long)t * d + dc), sv = ld8_f32(sn + (long)t * d + dc);
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const float x0 = v.v[e], x1 = v.v[e + 1];
+      if (!inverse) {
+        v.v[e] = x0 * c.v[e] - x1 * sv.v[e];
+        v.v[e + 1] = x1 * c.v[e + 1] + x0 * sv.v[e + 1];
+      } else {
+        v.v[e] = x0 * c.v[e] + x1 * sv.v[e + 1];
+        v.v[e + 1] = x1 * c.v[e + 1] - x0 * sv.v[e];
+      }
+    }
+    st8_bf16(x + r * ld + c0, v);
+  }
+}
 extern "C" int vfm_rope(void* x, int dt, long ld, long rows, int np, int ncols, int d, const float* cos_t, const float* sin_t,
                         int inverse, void* stream) {
   VFM_CHECK(d % 2 == 0 && ncols % d == 0 && np > 0, VFM_E_SHAPE, "vfm_rope: shape");
   const long total = rows * (ncols / 2);
   if (total == 0) return VFM_OK;
+  if (dt == VFM_BF16 && d % 8 == 0 && ld % 8 == 0 && al16(x) && al16(cos_t) && al16(sin_t)) {
+    hipLaunchKernelGGL(k_rope_bf16x8, dim3(grid8(rows * (ncols / 8))), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ld, rows, np, ncols / 8, d, cos_t,
+                       sin_t, inverse);
+    VFM_LAUNCH_CHECK();
+    return VFM_OK;
+  }
   const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipLaunchKernelGGL(k_rope, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, dt, ld, rows, np, ncols, d, cos_t, sin_t, inverse);
   VFM_LAUNCH_CHECK();
