@@ -99,7 +99,7 @@ class GemmTimer:
         return dict(flops=fl, ms=ms, launches=len(self.recs), sampled_every=self.every)
 
 
-def cpu_baseline(seconds_cap=40.0):
+def cpu_baseline(seconds_cap=40.0, model_kw=None):
     """The oracle (CPU fp32 restatement of the reference path) timed on this box's host cores: one train step
     (forward_train + backward + AdamW on the trainable tensors), B=1, 1024^2 input -> 2 x 512^2 passes."""
     from oracle import torch_ref as R
@@ -114,7 +114,9 @@ def cpu_baseline(seconds_cap=40.0):
     cores = max(1, min(cores, int(os.environ.get("VFMSEG_CPU_THREADS", "16"))))  # a GPU box grants a 16-core share
     torch.set_num_threads(cores)
     print(f"[bench] cpu_baseline: oracle train step on {cores} threads ...", file=sys.stderr, flush=True)
-    model = MODELS.build(presets.dinov2_ms_masked() if workload == "ms1024" else presets.dinov2_linear())
+    cfg = presets.dinov2_ms_masked(**(model_kw or {}))  # model_kw: tests shrink the model, not the workload
+    bb = cfg["backbone"]["backbone"]
+    model = MODELS.build(cfg)
     sd = synth_like(model.state_dict())
     del model
     tk = R.trainable_keys(sd)
@@ -123,7 +125,8 @@ def cpu_baseline(seconds_cap=40.0):
     img, lab = synth_image(1, 1024, seed=7), synth_label(1, 1024, seed=7)
     keep = torch.rand(1, 1, 32, 32, generator=torch.Generator().manual_seed(1)) > 0.2
     t0 = time.time()
-    losses = R.forward_train(sd, img, lab, (256, 768, 256, 768), keep)
+    losses = R.forward_train(sd, img, lab, (256, 768, 256, 768), keep, depth=bb["depth"], heads=bb["num_heads"],
+                             out_indices=tuple(bb.get("out_indices", (7, 11, 15, 23))))
     grads = torch.autograd.grad(R.total_loss(losses), [sd[k] for k in tk])
     with torch.no_grad():
         for k, g in zip(tk, grads):

@@ -49,3 +49,17 @@ def test_repo_config_builds_reference_key_scheme():
     from tests.helpers import model_shapes
     want = set(model_shapes(depth=2))
     assert keys == want, (sorted(keys - want)[:5], sorted(want - keys)[:5])
+
+
+def test_bench_cpu_baseline_runs():
+    """bench.py's cpu_baseline leg (the oracle timed on host cores) must keep working: it is only exercised at the end of a
+    GPU bench run, so a stale name there goes unnoticed.  One oracle train step of the real configuration (~20 s on 8 cores)."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    sys.path.insert(0, root)
+    spec.loader.exec_module(bench)
+    out = bench.cpu_baseline()
+    assert out["kind"] == "port" and out["unit"] == "images/s" and out["value"] > 0 and out["cores"] >= 1
