@@ -161,7 +161,10 @@ typedef struct vfm_gemm_desc {
   long kb_rows; /* bf16, B given as [K,N] (sb_n == 1): number of valid rows of B (<= K; A must be zero beyond); 0 = K */
 } vfm_gemm_desc;
 int vfm_gemm(const vfm_gemm_desc* d, void* stream);
-/* tuning / experiment knobs (e.g. key "gemm_cfg": force a bf16 GEMM tile configuration, -1 = heuristic) */
+/* tuning / experiment knobs (bench.py --tune KEY=INT).  bf16 GEMM dispatch: "gemm_cfg" forces a tile configuration (-1 = heuristic;
+ * 10/18 small tiles, 17 128x128 two-stage, 30/31 ping-pong, 32/33 256x256 ring, 34 128x128 five-chunk ring, 35/36 deeper rings),
+ * "gemm_use_pp" bit mask of the kernels the heuristic may pick (default 40), "gemm_split_tail", "gemm_fold_tail", "gemm_bt64",
+ * "gemm_batch_tiles".  Unknown keys return VFM_E_INVAL. */
 int vfm_tune(const char* key, int value);
 
 /* ---- attention -------------------------------------------------------------------------------- */
