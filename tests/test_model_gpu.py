@@ -156,6 +156,43 @@ def test_ms_inference_matches_reference_golden(golden_dir):
         set_compute_dtype("bf16")
 
 
+def test_merged_lora_inference_tracks_the_parameters():
+    """bf16 inference folds the LoRA pair into the QKV weight (W + s B A, cached).  The merged path must agree with the
+    unmerged one, and the cache must be rebuilt after an optimiser step (the fused AdamW kernel rewrites the parameters behind
+    torch's version counters: optim.PARAM_EPOCH) and after load_state_dict."""
+    from vfmseg_amd import presets as P_
+    from vfmseg_amd.optim import PEFTOptimWrapperConstructor
+    from vfmseg_amd.segmentors import SegDataSample
+    from vfmseg_amd.synth import synth_label
+    sd = cached_full_state_dict()
+    model = MODELS.build(P_.dinov2_ms_masked()).cuda()
+    model.load_state_dict(sd, strict=False)
+    img = synth_image(1, 1024, seed=11).cuda()
+
+    def logits(merge):
+        os.environ["VFMSEG_MERGE_LORA_EVAL"] = "1" if merge else "0"
+        model.eval()
+        with torch.no_grad():
+            return model.predict(img)[0].seg_logits.data.float().clone()
+    try:
+        a1, a0 = logits(True), logits(False)
+        assert rel_err(a1, a0) < 3e-2
+        oc = P_.optim_cfg()
+        oc["optim_wrapper"]["optimizer"]["lr"] = 5e-2   # a visible parameter change in one step
+        ow = PEFTOptimWrapperConstructor(oc["optim_wrapper"])(model, None)
+        lab = synth_label(1, 1024, seed=11).cuda()
+        model.train()
+        model.train_step(dict(inputs=img, data_samples=[SegDataSample(gt_sem_seg=lab[0])]), ow)
+        b1, b0 = logits(True), logits(False)
+        assert rel_err(b1, b0) < 3e-2, "stale merged weights after an optimiser step"
+        assert rel_err(b0, a0) > 5 * rel_err(b1, b0), "the step should have changed the logits visibly"
+        model.load_state_dict(sd, strict=False)
+        c1 = logits(True)
+        assert rel_err(c1, a0) < 3e-2, "stale merged weights after load_state_dict"
+    finally:
+        os.environ.pop("VFMSEG_MERGE_LORA_EVAL", None)
+
+
 def test_eva02_train_step_matches_oracle():
     """BASELINE config 4 (EVA02-L + LoRA + LinearHead + VFMHead), depth 4, full forward_train + backward vs the oracle."""
     from tests.helpers import eva02_state_dict, full_state_dict
