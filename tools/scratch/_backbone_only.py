@@ -1,6 +1,6 @@
 """Time of the backbone alone (fwd + bwd, 4 images = LR+HR passes of bs 2) vs the full train step."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import vfmseg_amd  # noqa
 from vfmseg_amd import presets

@@ -1,6 +1,6 @@
 """Cityscapes-sized (1024 x 2048) inference smoke + latency for both eval paths (18 crops at 1024 x 2048)."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import vfmseg_amd  # noqa: F401
 from vfmseg_amd import presets

@@ -1,7 +1,7 @@
 """Launches the backbone's four big GEMM shapes (default dispatch) a few times each: target of the rocprofv3 --pmc passes that
 give HBM-side bytes per launch of the dominant kernel (tools/pmc_traffic.py parses the result)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from vfmseg_amd import ops
 cfg = int(os.environ.get("CFG", "-1"))

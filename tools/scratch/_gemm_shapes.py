@@ -1,6 +1,6 @@
 """Per-signature timing of every bf16 GEMM of one train step under candidate tile configs (diagnostic)."""
 import os, sys, collections
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from vfmseg_amd import ops, functional as Fh

@@ -1,6 +1,6 @@
 """Lists the GEMM calls of one train step whose epilogue cannot take the vector path (diagnostic)."""
 import os, sys, collections
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from vfmseg_amd import ops, functional as Fh

@@ -1,6 +1,6 @@
 """Correctness screen of the ping-pong GEMM (cfg 30) over odd shapes, several repetitions (race screen)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from vfmseg_amd import ops
 
