@@ -534,6 +534,50 @@ def adamw_step(p, g, m, v, step, lr, wd, b1=0.9, b2=0.999, eps=1e-8):
     return p - (lr / bc1) * m / denom, m, v
 
 
+# parameters owned by normalisation MODULES of the reference's heads (isinstance check at peft_optimizer_constructor.py:93-96):
+# ConvModule GN (linear_head.py:36-40), nn.SyncBatchNorm (:44), nn.GroupNorm (VFMHead.py:31, :39-49), and the decoder's
+# LayerNorms (Transformer.py:167-169, :258) - the latter are hit by the custom key "norm" first anyway.
+NORM_MODULE_PREFIXES = (
+    "decode_head.fusion_conv.gn.", "decode_head.output_upscaling.1.", "aux_decoder.fuse_conv.1.",
+    "aux_decoder.seg_logits_embed.1.", "aux_decoder.seg_logits_embed.4.", "aux_decoder.seg_logits_embed.7.",
+)
+DG_CUSTOM_KEYS = {"norm": dict(decay_mult=0.0), "query_embed": dict(lr_mult=1.0, decay_mult=0.0),
+                  "level_embed": dict(lr_mult=1.0, decay_mult=0.0), "learnable_tokens": dict(lr_mult=1.0, decay_mult=0.0),
+                  "reins.scale": dict(lr_mult=1.0, decay_mult=0.0)}   # dg_lora_dinov2_ms_masked.py:10-25
+
+
+def train_step(sd, opt_state, img, label, hr_box, mask_keep, t, base_lr=1e-4, base_wd=0.05, end=40000, **kw):
+    """One iteration of the reference's training loop on the oracle: forward_train -> parse_losses -> backward ->
+    AdamW with the PEFTOptimWrapperConstructor groups at lr = PolyLR(t) -> SyncBN running stats
+    (tools/train.py:64-121 via mmengine Runner; dg_lora_dinov2_ms_masked.py:10-29).  sd is updated IN PLACE (plain
+    tensors); opt_state: {key: (m, v)} carried between calls; t = number of optimiser steps already taken.  Returns the
+    loss dict of this iteration (floats)."""
+    tk = trainable_keys(sd)
+    work = dict(sd)
+    for k in tk:
+        work[k] = sd[k].detach().clone().requires_grad_(True)
+    bn = {}
+    losses = forward_train(work, img, label, hr_box, mask_keep, bn_out=bn, **kw)
+    grads = torch.autograd.grad(total_loss(losses), [work[k] for k in tk], allow_unused=True)
+    lr_t = poly_lr(base_lr, t, end=end)
+    with torch.no_grad():
+        for k, g in zip(tk, grads):
+            if g is None:   # never entered the graph (inert adapters): torch's AdamW skips grad-less parameters
+                continue
+            lr_k, wd_k = param_group_options(k, key_is_norm(k), base_lr=lr_t, base_wd=base_wd, custom_keys=DG_CUSTOM_KEYS)
+            m, v = opt_state.get(k, (torch.zeros_like(g), torch.zeros_like(g)))
+            sd[k], m, v = adamw_step(sd[k].detach(), g, m, v, t + 1, lr_k, wd_k)
+            opt_state[k] = (m, v)
+        if bn:
+            sd["decode_head.output_upscaling.1.running_mean"] = bn["running_mean"].detach()
+            sd["decode_head.output_upscaling.1.running_var"] = bn["running_var"].detach()
+    return {k: float(v) for k, v in losses.items()}
+
+
+def key_is_norm(key):
+    return key.startswith(NORM_MODULE_PREFIXES)
+
+
 # =============================================================================== evaluation
 def confusion_iou(pred, label, num_classes=19, ignore=IGNORE):
     """mmseg IoUMetric.intersect_and_union + per-class IoU / mIoU (rein/dg_metrics.py:74-102 groups these by dataset)."""

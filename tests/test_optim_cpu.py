@@ -1,0 +1,70 @@
+"""Host logic of the optimiser / runner side (CPU): the product's parameter groups against the oracle's restatement of
+PEFTOptimWrapperConstructor.add_params (rein/optimizers/peft_optimizer_constructor.py:25-147), PolyLR, gradient-production
+order of the flat buffer, checkpoint discovery for --resume."""
+import os
+
+import torch
+
+import vfmseg_amd  # noqa: F401
+from oracle import torch_ref as R
+from vfmseg_amd import presets
+from vfmseg_amd.optim import PolyLR, param_options, production_order
+from vfmseg_amd.registry import MODELS
+from vfmseg_amd.runner import find_latest_checkpoint
+
+
+def _model(depth=2):
+    cfg = presets.dinov2_ms_masked(depth=depth)
+    cfg["backbone"]["backbone"]["out_indices"] = [0, 1]
+    return MODELS.build(cfg).train()
+
+
+def test_param_options_match_the_oracle_groups():
+    m = _model()
+    oc = presets.optim_cfg()["optim_wrapper"]
+    opts = param_options(m, oc["optimizer"]["lr"], oc["optimizer"]["weight_decay"], oc["paramwise_cfg"])
+    named = {n: p for n, p in m.named_parameters() if p.requires_grad}
+    assert set(opts) == set(named) and len(opts) > 80
+    assert all(("lora_" in n) for n in named if n.startswith("backbone.")), "only LoRA factors train in the backbone"
+    n_wd0 = 0
+    for n, (lr_mult, wd) in opts.items():
+        want_lr, want_wd = R.param_group_options(n, R.key_is_norm(n), base_lr=1.0, base_wd=0.05, custom_keys=R.DG_CUSTOM_KEYS)
+        assert (lr_mult, wd) == (want_lr, want_wd), (n, lr_mult, wd, want_lr, want_wd)
+        n_wd0 += wd == 0.0
+    # spot checks spelled out: norms decay-free, everything else (biases, LoRA, mask_token) decays
+    assert opts["decode_head.fusion_conv.gn.weight"][1] == 0.0 and opts["decode_head.output_upscaling.1.bias"][1] == 0.0
+    assert opts["aux_decoder.transformer_decoder.transformer_blocks.0.norm2.weight"][1] == 0.0
+    assert opts["aux_decoder.seg_logits_embed.4.weight"][1] == 0.0
+    assert opts["decode_head.conv_seg.bias"][1] == 0.05 and opts["aux_decoder.transformer_decoder.mask_token"][1] == 0.05
+    assert opts["backbone.model.base_model.model.blocks.0.attn.qkv.lora_A.default.weight"] == (1.0, 0.05)
+    assert 20 < n_wd0 < len(opts) // 2
+
+
+def test_polylr_matches_closed_form():
+    s = PolyLR(1e-4, power=0.9, eta_min=0.0, begin=0, end=40000)
+    for t in (0, 1, 50, 20000, 39999, 40000, 50000):
+        assert abs(s.lr(t) - R.poly_lr(1e-4, t)) < 1e-18
+    assert s.lr(0) == 1e-4 and s.lr(40000) == 0.0
+
+
+def test_production_order_follows_backward():
+    m = _model(depth=3)
+    names = production_order([n for n, p in m.named_parameters() if p.requires_grad])
+    groups = ["aux" if n.startswith("aux_decoder") else "lin" if n.startswith("decode_head") else "lora" for n in names]
+    first = {g: groups.index(g) for g in ("aux", "lin", "lora")}
+    last = {g: len(groups) - 1 - groups[::-1].index(g) for g in ("aux", "lin", "lora")}
+    assert last["aux"] < first["lin"] and last["lin"] < first["lora"]          # VFMHead -> LinearHead -> LoRA
+    blocks = [int(n.split("blocks.")[1].split(".")[0]) for n in names if "lora_" in n]
+    assert blocks == sorted(blocks, reverse=True)                                # LoRA layers L-1 .. 0
+
+
+def test_find_latest_checkpoint_orders_numerically(tmp_path):
+    assert find_latest_checkpoint(str(tmp_path / "missing")) is None
+    for it in (4000, 8000, 12000, 40000):
+        torch.save({}, tmp_path / f"iter_{it}.pth")
+    (tmp_path / "iter_notanumber.pth").write_text("x")
+    assert os.path.basename(find_latest_checkpoint(str(tmp_path))) == "iter_40000.pth"   # a string sort would pick iter_8000
+    (tmp_path / "last_checkpoint").write_text(str(tmp_path / "iter_12000.pth"))
+    assert os.path.basename(find_latest_checkpoint(str(tmp_path))) == "iter_12000.pth"   # the pointer file wins (mmengine)
+    (tmp_path / "last_checkpoint").write_text(str(tmp_path / "gone.pth"))
+    assert os.path.basename(find_latest_checkpoint(str(tmp_path))) == "iter_40000.pth"

@@ -28,6 +28,12 @@ def main():
     from vfmseg_amd.precision import set_compute_dtype
     from vfmseg_amd.runner import Runner
     set_compute_dtype(a.dtype)
+    if a.amp:
+        import warnings
+        warnings.warn("--amp (tools/train.py:87-102: AmpOptimWrapper, fp16 autocast + dynamic loss scale) has no fp16 path here: "
+                      "GEMM / attention operands are bf16 with fp32 accumulation, the residual stream, statistics, losses and "
+                      "the optimiser are fp32 (--dtype bf16, the default); bf16's exponent range needs no loss scaling, so the "
+                      "flag changes nothing")
     cfg = Config.fromfile(a.config)
     cfg.merge_from_dict(parse_cfg_options(a.cfg_options))
     cfg["work_dir"] = a.work_dir or cfg.get("work_dir") or os.path.join("./work_dirs", os.path.splitext(os.path.basename(a.config))[0])
@@ -37,9 +43,10 @@ def main():
     cfg["model"]["train_cfg"]["log_config"] = cfg.get("log_config", dict(interval=50, img_interval=500))
     runner = Runner.from_cfg(cfg)
     if a.resume:
-        cks = sorted(f for f in os.listdir(cfg["work_dir"]) if f.startswith("iter_")) if os.path.isdir(cfg["work_dir"]) else []
-        if cks:
-            runner.resume(os.path.join(cfg["work_dir"], cks[-1]))
+        from vfmseg_amd.runner import find_latest_checkpoint
+        ck = find_latest_checkpoint(cfg["work_dir"])
+        if ck:
+            runner.resume(ck)
     runner.train(a.max_iters, log_interval=cfg.get("default_hooks", {}).get("logger", {}).get("interval", 50),
                  ckpt_interval=cfg.get("default_hooks", {}).get("checkpoint", {}).get("interval", 4000))
 

@@ -125,7 +125,7 @@ class DinoVisionTransformer(nn.Module):
             self._engine = DinoEngine(self)
         return self._engine
 
-    def forward_tokens(self, jobs, training=False, seed=0):
+    def forward_tokens(self, jobs, training=False, seed=None):
         """jobs: list of (img [B,3,H,W] fp32 cuda, box or None) that share one token grid. Returns Xcat
         [sum(B)*Np, 4*D] (compute dtype) - the four taps side by side, token-major - and (hp, wp)."""
         return _BackboneFn.apply(self, jobs, training, seed, *self.engine().trainable())
@@ -204,7 +204,7 @@ class LoRABackbone(nn.Module):
                 p.requires_grad = False
         return self
 
-    def forward_tokens(self, jobs, seed=0):
+    def forward_tokens(self, jobs, seed=None):
         return self.vit.forward_tokens(jobs, training=self._lora_train, seed=seed)
 
     def forward(self, x):
@@ -410,6 +410,11 @@ class DinoEngine:
         nt = len(v.out_indices)
         xcat = torch.empty(Mp, nt * D, dtype=cd, device=dev)
         saved = []
+        if lora and training:
+            from .functional import draw_seed
+            seed, rng0 = draw_seed(seed, len(v.blocks) * M * D)
+        else:
+            seed, rng0 = 0, 0
         hd = D // H
         scale = hd ** -0.5
         for li, (blk, Lp) in enumerate(zip(v.blocks, P["layers"])):
@@ -422,7 +427,7 @@ class DinoEngine:
             if fused_drop:  # LN + dropout multiplier + dropped copy in one pass
                 mask = torch.empty(M, D, dtype=cd, device=dev)
                 xd = torch.empty(M, D, dtype=cd, device=dev)
-                ops.layernorm_dropout_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1, xd, mask, q.p, seed, offset=li * M * D)
+                ops.layernorm_dropout_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1, xd, mask, q.p, seed, offset=rng0 + li * M * D)
             else:
                 ops.layernorm_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1)
             if lora and merged is None:
@@ -430,7 +435,7 @@ class DinoEngine:
                     xd, mask = a1[:, :D], None
                     if training and q.p > 0:
                         mask = torch.empty(M, D, dtype=cd, device=dev)
-                        ops.dropout_mask(mask, q.p, seed, offset=li * M * D)
+                        ops.dropout_mask(mask, q.p, seed, offset=rng0 + li * M * D)
                         xd = torch.empty(M, D, dtype=cd, device=dev)
                         ops.mul_mask(a1[:, :D], mask, xd)
                 ops.gemm(xd, Lp["a"], a1[:, D:D + R_PAD], alpha=q.scaling)  # T = s * drop(xn) A^T

@@ -96,7 +96,7 @@ class CLIPVisionTransformer(nn.Module):
             self._engine = ClipEngine(self)
         return self._engine
 
-    def forward_tokens(self, jobs, training=False, seed=0):
+    def forward_tokens(self, jobs, training=False, seed=None):
         return _BackboneFn.apply(self, jobs, training, seed, *self.engine().trainable())
 
     def forward(self, x):
@@ -242,6 +242,8 @@ class ClipEngine:
         xcat = torch.empty(Mp, nt * D, dtype=cd, device=dev)
         saved = []
         scale = hd ** -0.5
+        from .functional import draw_seed
+        seed, rng0 = draw_seed(seed, 2 * len(v.blocks) * M * P["layers"][0]["hid"]) if (lora and training) else (0, 0)
         for li, (blk, Lp) in enumerate(zip(v.blocks, P["layers"])):
             hid = Lp["hid"]
             S = {"x_in": x}
@@ -264,12 +266,12 @@ class ClipEngine:
             if lora and training and q1.p > 0 and cd == torch.bfloat16 and D % 256 == 0:
                 mask1 = torch.empty(M, D, dtype=cd, device=dev)
                 xd1 = torch.empty(M, D, dtype=cd, device=dev)
-                ops.layernorm_dropout_fwd(xm, Lp["n2w"], Lp["n2b"], 1e-5, a2[:, :D], st2, xd1, mask1, q1.p, seed, offset=2 * li * M * hid)
+                ops.layernorm_dropout_fwd(xm, Lp["n2w"], Lp["n2b"], 1e-5, a2[:, :D], st2, xd1, mask1, q1.p, seed, offset=rng0 + 2 * li * M * hid)
             else:
                 ops.layernorm_fwd(xm, Lp["n2w"], Lp["n2b"], 1e-5, a2[:, :D], st2)
                 if lora and training and q1.p > 0:
                     mask1 = torch.empty(M, D, dtype=cd, device=dev)
-                    ops.dropout_mask(mask1, q1.p, seed, offset=2 * li * M * hid)
+                    ops.dropout_mask(mask1, q1.p, seed, offset=rng0 + 2 * li * M * hid)
                     xd1 = torch.empty(M, D, dtype=cd, device=dev)
                     ops.mul_mask(a2[:, :D], mask1, xd1)
             if lora:
@@ -282,7 +284,7 @@ class ClipEngine:
                 src = g[:, :hid]
                 if training and q2.p > 0:
                     mask2 = torch.empty(M, hid, dtype=cd, device=dev)
-                    ops.dropout_mask(mask2, q2.p, seed, offset=(2 * li + 1) * M * hid)
+                    ops.dropout_mask(mask2, q2.p, seed, offset=rng0 + (2 * li + 1) * M * hid)
                     xd2 = torch.empty(M, hid, dtype=cd, device=dev)
                     ops.mul_mask(src, mask2, xd2)
                     src = xd2

@@ -96,7 +96,7 @@ class EVA2(nn.Module):
             self._engine = EvaEngine(self)
         return self._engine
 
-    def forward_tokens(self, jobs, training=False, seed=0):
+    def forward_tokens(self, jobs, training=False, seed=None):
         return _BackboneFn.apply(self, jobs, training, seed, *self.engine().trainable())
 
     def forward(self, x):
@@ -233,6 +233,8 @@ class EvaEngine:
         xcat = torch.empty(Mp, nt * D, dtype=cd, device=dev)
         saved = []
         scale = hd ** -0.5
+        from .functional import draw_seed
+        seed, rng0 = draw_seed(seed, len(v.blocks) * M * D) if (lora and training) else (0, 0)
         for li, (blk, Lp) in enumerate(zip(v.blocks, P["layers"])):
             hid_p = Lp["hp"]
             S = {"x_in": x}
@@ -251,7 +253,7 @@ class EvaEngine:
                 xd, mask = ao[:, :D], None
                 if training and q.p > 0:
                     mask = torch.empty(M, D, dtype=cd, device=dev)
-                    ops.dropout_mask(mask, q.p, seed, offset=li * M * D)
+                    ops.dropout_mask(mask, q.p, seed, offset=rng0 + li * M * D)
                     xd = torch.empty(M, D, dtype=cd, device=dev)
                     ops.mul_mask(ao[:, :D], mask, xd)
                 ops.gemm(xd, Lp["a"], ao[:, D:D + R_PAD], alpha=q.scaling)

@@ -22,6 +22,15 @@ def _next_rng(n):
     return _seed_state["seed"], off
 
 
+def draw_seed(seed, n):
+    """(seed, base offset) for a backbone call's LoRA-dropout masks.  seed=None (the training path) reserves n counters of
+    the advancing generator the heads use, so every call - every train step, every DP rank after manual_seed(rank-specific)
+    - samples fresh masks like peft's nn.Dropout (lora_backbone.py:16-23); an explicit int pins the masks (tests)."""
+    if seed is None:
+        return _next_rng(n)
+    return int(seed), 0
+
+
 def _pad64(n):
     return (n + 63) // 64 * 64
 

@@ -149,6 +149,9 @@ class FusedAdamW:
         return dict(step=self.step_count, m=self.m, v=self.v, names=self.names)
 
     def load_state_dict(self, sd):
+        if list(sd.get("names", self.names)) != list(self.names) or sd["m"].numel() != self.m.numel():
+            raise ValueError("optimizer state does not match this model: the flat m/v buffers are laid out by parameter name "
+                             f"({len(sd.get('names', []))} saved names / {sd['m'].numel()} elements vs {len(self.names)} / {self.m.numel()})")
         self.step_count = sd["step"]
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])

@@ -200,6 +200,7 @@ def clip_ms_masked(layers=24, checkpoint=None, work_dir="work_dirs/tmp"):
     """configs/_base_/models/lora_clip_ms_masked.py: CLIP ViT-L/16 + LoRA, LinearHead + VFMHead."""
     cfg = dinov2_ms_masked(work_dir=work_dir)
     cfg["backbone"] = dict(type="LoRABackbone", backbone=clip_backbone(layers), checkpoint=checkpoint, Lora_config=clip_lora_cfg())
+    cfg["test_cfg"].pop("lr_img_size", None)   # lora_clip_ms_masked.py:78-84 has no lr_img_size (the key is read nowhere, SURVEY Q3)
     return cfg
 
 

@@ -33,6 +33,26 @@ class SyntheticLoader:
         return dict(inputs=imgs, data_samples=[SegDataSample(gt_sem_seg=labs[k]) for k in range(self.bs)])
 
 
+def find_latest_checkpoint(work_dir):
+    """mmengine's resume rule: the `last_checkpoint` pointer file if it names an existing file, else the iter_N.pth with the
+    largest N (numeric, not lexicographic: iter_8000 < iter_12000)."""
+    import re
+    if not os.path.isdir(work_dir):
+        return None
+    ptr = os.path.join(work_dir, "last_checkpoint")
+    if os.path.exists(ptr):
+        with open(ptr) as f:
+            path = f.read().strip()
+        if os.path.exists(path):
+            return path
+    best = None
+    for fn in os.listdir(work_dir):
+        m = re.fullmatch(r"iter_(\d+)\.pth", fn)
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), os.path.join(work_dir, fn))
+    return best[1] if best else None
+
+
 class Runner:
     def __init__(self, cfg, model, optim_wrapper, loader, work_dir, rank=0, world=1):
         self.cfg, self.model, self.ow, self.loader, self.work_dir = cfg, model, optim_wrapper, loader, work_dir
@@ -57,6 +77,16 @@ class Runner:
         ctor = OPTIM_WRAPPER_CONSTRUCTORS.get(ow_cfg.get("constructor", "PEFTOptimWrapperConstructor")) or PEFTOptimWrapperConstructor
         ow = ctor(ow_cfg, ow_cfg.get("paramwise_cfg"))(model, cfg.get("param_scheduler"))
         parallel.attach(model, ow)
+        ds = (cfg.get("train_dataloader", {}) or {}).get("dataset")
+        if ds is not None and not synthetic:
+            raise NotImplementedError(
+                "train_dataloader.dataset is configured, but the dataset / augmentation chain (mmseg-side, SURVEY 8 row f4) is not "
+                "part of this build: run with synthetic=True (tools/train.py default) or feed Runner(loader=...) an iterator of "
+                "dict(inputs=uint8|float32 CHW images, data_samples=[SegDataSample]) - SegDataPreProcessor takes both")
+        if ds is not None and rank == 0:
+            import warnings
+            warnings.warn(f"train_dataloader.dataset ({ds.get('type', '?') if isinstance(ds, dict) else type(ds).__name__}) is NOT read: "
+                          "this build trains on the synthetic 19-class stream (no datasets offline; SURVEY 8 row f4)")
         bs = cfg.get("train_dataloader", {}).get("batch_size", 2)
         size = tuple(cfg.get("crop_size", cfg["model"].get("data_preprocessor", {}).get("size", (1024, 1024))))
         loader = SyntheticLoader(bs, size, rank, world, seed)
@@ -64,14 +94,32 @@ class Runner:
         return cfg_cls(cfg, model, ow, loader, work_dir, rank, world)
 
     def save_checkpoint(self, path):
+        """mmengine CheckpointHook: weights, optimiser state, iteration - plus the RNG consumers of the hot path (the crop-box
+        np.random stream, the dropout / query-mask counter, the loader position) so that a resumed run continues the same
+        sample and mask sequence - and a `last_checkpoint` pointer file next to it."""
+        from . import functional as Fh
         sd = {k: v.detach().cpu() for k, v in self.model.state_dict().items()}
-        torch.save(dict(state_dict=sd, meta=dict(iter=self.iter), optimizer=self.ow.optimizer.state_dict()), path)
+        meta = dict(iter=self.iter, loader_pos=getattr(self.loader, "i", None), np_random=np.random.get_state(),
+                    mask_rng=dict(Fh._seed_state), torch_rng=torch.get_rng_state())
+        torch.save(dict(state_dict=sd, meta=meta, optimizer=self.ow.optimizer.state_dict()), path)
+        with open(os.path.join(os.path.dirname(path) or ".", "last_checkpoint"), "w") as f:
+            f.write(os.path.abspath(path))
 
     def resume(self, path):
-        ck = torch.load(path, map_location="cpu")
+        from . import functional as Fh
+        ck = torch.load(path, map_location="cpu", weights_only=False)
         self.model.load_state_dict(ck["state_dict"], strict=False)
         self.ow.optimizer.load_state_dict({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in ck["optimizer"].items()})
-        self.iter = self.ow.iter = ck["meta"]["iter"]
+        meta = ck["meta"]
+        self.iter = self.ow.iter = meta["iter"]
+        if meta.get("loader_pos") is not None and hasattr(self.loader, "i"):
+            self.loader.i = meta["loader_pos"]
+        if meta.get("np_random") is not None:
+            np.random.set_state(meta["np_random"])
+        if meta.get("mask_rng") is not None:
+            Fh._seed_state.update(meta["mask_rng"])
+        if meta.get("torch_rng") is not None:
+            torch.set_rng_state(meta["torch_rng"])
 
     def train(self, max_iters=None, log_interval=50, ckpt_interval=4000):
         tc = self.cfg.get("train_cfg", {})
@@ -92,6 +140,6 @@ class Runner:
                     log.write(json.dumps(rec) + "\n")
                     log.flush()
                     print(rec, flush=True)
-            if self.rank == 0 and ckpt_interval and self.iter % ckpt_interval == 0:
-                self.save_checkpoint(os.path.join(self.work_dir, f"iter_{self.iter}.pth"))
+            if self.rank == 0 and ckpt_interval and (self.iter % ckpt_interval == 0 or self.iter == max_iters):
+                self.save_checkpoint(os.path.join(self.work_dir, f"iter_{self.iter}.pth"))  # always one at the last iteration
         return self.model

@@ -73,7 +73,7 @@ class SAMViT(nn.Module):
             self._engine = SamEngine(self)
         return self._engine
 
-    def forward_tokens(self, jobs, training=False, seed=0):
+    def forward_tokens(self, jobs, training=False, seed=None):
         return _BackboneFn.apply(self, jobs, training, seed, *self.engine().trainable())
 
     def forward(self, x):
@@ -242,6 +242,8 @@ class SamEngine:
         xcat = torch.empty(M, nt * D, dtype=cd, device=dev)
         keep = bool(training) and lora            # activations for the hand-written backward
         saved = []
+        from .functional import draw_seed
+        seed, rng0 = draw_seed(seed, len(v.blocks) * M * D) if keep else (0, 0)
         for li, (blk, Lp) in enumerate(zip(v.blocks, P["layers"])):
             kq = Lp["qkv"].k
             S_ = {"x_in": x}
@@ -252,12 +254,12 @@ class SamEngine:
             if keep and q.p > 0 and cd == torch.bfloat16 and D % 256 == 0:
                 mask = torch.empty(M, D, dtype=cd, device=dev)
                 xd = torch.empty(M, D, dtype=cd, device=dev)
-                ops.layernorm_dropout_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1, xd, mask, q.p, seed, offset=li * M * D)
+                ops.layernorm_dropout_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1, xd, mask, q.p, seed, offset=rng0 + li * M * D)
             else:
                 ops.layernorm_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1)
                 if keep and q.p > 0:
                     mask = torch.empty(M, D, dtype=cd, device=dev)
-                    ops.dropout_mask(mask, q.p, seed, offset=li * M * D)
+                    ops.dropout_mask(mask, q.p, seed, offset=rng0 + li * M * D)
                     xd = torch.empty(M, D, dtype=cd, device=dev)
                     ops.mul_mask(a1[:, :D], mask, xd)
             if kq > D:
