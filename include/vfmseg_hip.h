@@ -270,6 +270,16 @@ int vfm_slide_accumulate(const float* crop, int crop_nchw, int B, int h, int w, 
 /* seg = preds / count ; pred = argmax_c  (NCHW) */
 int vfm_slide_finalize(float* preds, const float* count, uint8_t* argmax, int B, int C, int H, int W, void* stream);
 
+/* ---- evaluation ------------------------------------------------------------------------------------ */
+/* Confusion histogram behind mmseg IoUMetric.intersect_and_union, which rein/dg_metrics.py:46-52 (DGIoUMetric.process) calls per
+ * sample: for every pixel with label != ignore_index, hist[row * num_classes + pred] += 1 where row = label if 0 <= label <
+ * num_classes else num_classes (labels outside the class range still count into the prediction areas, as torch.histc on
+ * pred[mask] does).  hist: int64 [(num_classes+1) * num_classes], ACCUMULATED into (zero it once per evaluation);
+ * area_intersect = diag, area_pred_label = column sums, area_label = row sums of the first num_classes rows.
+ * pred uint8 [n], label int64 or uint8 [n], both 16-byte aligned; num_classes <= 64. */
+int vfm_confusion_hist(const uint8_t* pred, const void* label, int label_dt, long n, int num_classes, int ignore_index,
+                       int64_t* hist, void* stream);
+
 /* ---- optimiser ------------------------------------------------------------------------------------- */
 /* fused multi-tensor AdamW over one flat fp32 buffer (torch.optim.AdamW semantics; groups from
  * peft_optimizer_constructor.py:25-147): segment s covers [seg_start[s], seg_start[s+1]) with lr*seg_lr_mult[s],

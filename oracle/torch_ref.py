@@ -504,6 +504,45 @@ def ms_inference(sd, img, thr=0.968, conf=0.8, crop=(512, 512), stride=(320, 320
     return preds / cnt
 
 
+def lr_slide_inference(sd, img, crop=(512, 512), stride=(320, 320), **kw):
+    """Ms_VFM_encoder_decoder.py:280-283."""
+    lr = F.interpolate(img, scale_factor=0.5, mode="bilinear", align_corners=False)
+    return F.interpolate(slide_inference(sd, lr, crop, stride, **kw), scale_factor=2, mode="bilinear", align_corners=False)
+
+
+def msfull_slide_inference(sd, img, mask_keeps=None, crop=(512, 512), stride=(320, 320), **kw):
+    """Ms_VFM_encoder_decoder.py:286-328: coarse sliding pass at (512, 1024), then every window through the VFMHead with the
+    query mask ENABLED (enc_dec -> aux_decoder.forward; only ms_inference disables it).  mask_keeps: one bool [B,1,32,32] per
+    window in grid order (the torch.rand consumer made explicit), or None for no masking."""
+    b, _, h, w = img.shape
+    small = F.interpolate(img, size=(512, 1024), mode="bilinear", align_corners=False)
+    seg = F.interpolate(slide_inference(sd, small, crop, stride, **kw), size=(h, w), mode="bilinear", align_corners=False)
+    preds = img.new_zeros((b, 19, h, w))
+    cnt = img.new_zeros((b, 1, h, w))
+    for j, (y1, y2, x1, x2) in enumerate(grid_boxes(h, w, crop, stride)):
+        feats = dinov2_forward(sd, img[:, :, y1:y2, x1:x2], **kw)
+        lg = vfm_head_forward(sd, feats, seg[:, :, y1:y2, x1:x2], None if mask_keeps is None else mask_keeps[j])
+        preds[:, :, y1:y2, x1:x2] += F.interpolate(lg, size=(y2 - y1, x2 - x1), mode="bilinear", align_corners=False)
+        cnt[:, :, y1:y2, x1:x2] += 1
+    return preds / cnt
+
+
+def postprocess_result(seg_logits, metas):
+    """mmseg postprocess_result (1.2.2; tools/test.py:96-145 reaches it through predict): per image crop the padding
+    (left, right, top, bottom), undo the flip, bilinear to ori_shape, argmax.  Returns [(logits [C,h,w], pred [1,h,w])]."""
+    out = []
+    B, C, H, W = seg_logits.shape
+    for i in range(B):
+        m = metas[i]
+        pl, pr, pt, pb = m.get("img_padding_size", m.get("padding_size", [0] * 4))
+        x = seg_logits[i:i + 1, :, pt:H - pb, pl:W - pr]
+        if m.get("flip"):
+            x = x.flip(dims=(3,)) if m.get("flip_direction") == "horizontal" else x.flip(dims=(2,))
+        x = F.interpolate(x, size=tuple(m["ori_shape"]), mode="bilinear", align_corners=False).squeeze(0)
+        out.append((x, x.argmax(dim=0, keepdim=True)))
+    return out
+
+
 # =============================================================================== optimiser
 def param_group_options(name, module_is_norm, base_lr=1e-4, base_wd=0.05, custom_keys=None, norm_decay_mult=0.0):
     """peft_optimizer_constructor.py:25-147 for one parameter: custom key (longest first, substring of the full
@@ -571,7 +610,7 @@ def train_step(sd, opt_state, img, label, hr_box, mask_keep, t, base_lr=1e-4, ba
         if bn:
             sd["decode_head.output_upscaling.1.running_mean"] = bn["running_mean"].detach()
             sd["decode_head.output_upscaling.1.running_var"] = bn["running_var"].detach()
-    return {k: float(v) for k, v in losses.items()}
+    return {k: float(v.detach()) for k, v in losses.items()}
 
 
 def key_is_norm(key):
@@ -589,3 +628,46 @@ def confusion_iou(pred, label, num_classes=19, ignore=IGNORE):
     union = ap + al - inter
     iou = inter / union
     return iou, float(np.nanmean(iou.numpy()) * 100.0)
+
+
+def intersect_and_union(pred_label, label, num_classes=19, ignore_index=IGNORE):
+    """mmseg IoUMetric.intersect_and_union (called per sample at rein/dg_metrics.py:46-52): torch.histc over [0, nc-1] of
+    pred[mask], label[mask] and pred[mask][pred == label]; out-of-range values fall outside the histogram."""
+    mask = label != ignore_index
+    pred_label, label = pred_label[mask].float(), label[mask].float()
+    intersect = pred_label[pred_label == label]
+    h = lambda t: torch.histc(t, bins=num_classes, min=0, max=num_classes - 1).double()   # noqa: E731
+    ai, ap, al = h(intersect), h(pred_label), h(label)
+    return ai, ap + al - ai, ap, al
+
+
+def iou_metric_summary(results):
+    """mmseg IoUMetric.compute_metrics for metrics=['mIoU']: totals over the samples -> aAcc, IoU, Acc per class ->
+    np.round(nanmean * 100, 2) as aAcc / mIoU / mAcc."""
+    ai, au, ap, al = (sum(r[i] for r in results) for i in range(4))
+    ret = {"aAcc": (ai.sum() / al.sum()).numpy(), "IoU": (ai / au).numpy(), "Acc": (ai / al).numpy()}
+    return {(k if k == "aAcc" else "m" + k): float(np.round(np.nanmean(v) * 100, 2)) for k, v in ret.items()}
+
+
+def dg_iou_metrics(batches, dataset_keys, mean_used_keys=None, num_classes=19):
+    """rein/dg_metrics.py:24-102.  batches: list of batches, each a list of (pred [H,W], label [H,W], seg_map_path); every
+    sample of a batch is filed under the key found in the FIRST sample's path (:53-58)."""
+    mean_used_keys = mean_used_keys or dataset_keys
+    per = {}
+    for batch in batches:
+        key = "unknown"
+        for k in dataset_keys:
+            if k in batch[0][2]:
+                key = k
+                break
+        for pred, label, _ in batch:
+            per.setdefault(key, []).append(intersect_and_union(pred.long(), label.long(), num_classes))
+    metrics, to_mean = {}, {}
+    for key, res in per.items():
+        for k, v in iou_metric_summary(res).items():
+            metrics[f"{key}_{k}"] = v
+            if key in mean_used_keys:
+                to_mean.setdefault(k, []).append(v)
+    for k, v in to_mean.items():
+        metrics[f"mean_{k}"] = sum(v) / len(v)
+    return metrics

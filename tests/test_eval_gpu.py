@@ -1,0 +1,171 @@
+"""SURVEY 8 row f1 on the HIP path: confusion-histogram kernel, IoUMetric / DGIoUMetric (per-dataset grouping, mean_* keys),
+postprocess_result (un-pad, flip undo, resize to ori_shape), the lr / msfull sliding modes, and the north_star target
+"mIoU within +-0.1 of reference on a fixed synthetic batch" stated from HIP predictions vs oracle predictions."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import vfmseg_amd  # noqa: E402,F401
+from oracle import torch_ref as R  # noqa: E402
+from tests.helpers import full_state_dict, rel_err  # noqa: E402
+from vfmseg_amd import metrics as M, ops, presets  # noqa: E402
+from vfmseg_amd.precision import set_compute_dtype  # noqa: E402
+from vfmseg_amd.registry import METRICS, MODELS  # noqa: E402
+from vfmseg_amd.segmentors import PixelData, SegDataSample  # noqa: E402
+from vfmseg_amd.synth import synth_image, synth_label  # noqa: E402
+
+
+def _noisy_pred(lab, seed, flip=0.3):
+    g = torch.Generator().manual_seed(seed)
+    pred = lab.clone()
+    pred[pred == 255] = 3
+    noise = torch.randint(0, 19, lab.shape, generator=g)
+    take = torch.rand(lab.shape, generator=g) < flip
+    return torch.where(take, noise, pred).to(torch.uint8)
+
+
+@pytest.mark.parametrize("n,ldt", [(0, torch.int64), (7, torch.int64), (16, torch.uint8), (1000, torch.int64), (512 * 512 + 5, torch.uint8),
+                                   (1024 * 2048, torch.int64)])
+def test_confusion_hist_kernel_exact(n, ldt):
+    """bit-exact against a torch.bincount of label * nc + pred over the valid pixels, incl. empty / ragged sizes, labels
+    outside the class range (row nc) and the ignore value."""
+    nc = 19
+    g = torch.Generator().manual_seed(n + 1)
+    pred = torch.randint(0, nc, (n,), generator=g, dtype=torch.uint8)
+    lab = torch.randint(0, nc, (n,), generator=g)
+    r = torch.rand(n, generator=g)
+    lab[r < 0.07] = 255
+    lab[(r > 0.07) & (r < 0.09)] = 200          # not ignore, not a class: counts into the prediction areas only
+    want = torch.zeros((nc + 1) * nc, dtype=torch.int64)
+    v = lab != 255
+    rows = torch.where(lab[v] < nc, lab[v], torch.full_like(lab[v], nc))
+    if v.any():
+        want += torch.bincount(rows * nc + pred[v].long(), minlength=(nc + 1) * nc)
+    hist = torch.zeros((nc + 1) * nc, dtype=torch.int64, device="cuda")
+    ops.confusion_hist(pred.cuda(), lab.to(ldt).cuda(), hist, nc, 255)
+    ops.confusion_hist(pred.cuda(), lab.to(ldt).cuda(), hist, nc, 255)   # accumulates
+    assert torch.equal(hist.cpu(), 2 * want)
+    # the areas mmseg derives from it
+    if n:
+        ai, au, ap, al = R.intersect_and_union(pred.long(), lab, nc)
+        gi, gu, gp, gl = M.areas_from_confusion(want.numpy(), nc)
+        np.testing.assert_array_equal(gi, ai.numpy()), np.testing.assert_array_equal(gu, au.numpy())
+        np.testing.assert_array_equal(gp, ap.numpy()), np.testing.assert_array_equal(gl, al.numpy())
+
+
+def test_dg_iou_metric_groups_like_the_reference():
+    """rein/dg_metrics.py:24-102 semantics vs the oracle restatement: three datasets + an unknown path, batches of 1 and 2
+    (a batch is filed under its FIRST sample's key), mean over mean_used_keys only."""
+    keys, used = ["citys", "bdd", "map"], ["citys", "bdd"]
+    metric = METRICS.build(dict(type="DGIoUMetric", dataset_keys=keys, mean_used_keys=used))
+    paths = [["data/citys/a.png"], ["data/bdd/b.png", "data/citys/zz.png"], ["data/map/c.png"], ["elsewhere/d.png"], ["x/citys/e.png"]]
+    batches = []
+    k = 0
+    for ps in paths:
+        batch, samples = [], []
+        for pth in ps:
+            lab = synth_label(1, 256, seed=80 + k)[0, 0]
+            pred = _noisy_pred(lab, 90 + k, flip=0.2 + 0.1 * (k % 3))
+            batch.append((pred, lab, pth))
+            ds = SegDataSample(gt_sem_seg=lab.unsqueeze(0).cuda(), metainfo=dict(seg_map_path=pth))
+            ds.pred_sem_seg = PixelData(pred.unsqueeze(0).cuda())
+            samples.append(ds)
+            k += 1
+        metric.process(None, samples)
+        batches.append(batch)
+    got = metric.evaluate(k)
+    want = R.dg_iou_metrics(batches, keys, used)
+    assert set(got) == set(want), (sorted(got), sorted(want))
+    for kk in want:
+        assert abs(got[kk] - want[kk]) < 1e-9, (kk, got[kk], want[kk])
+    assert "unknown_mIoU" in got and "mean_mIoU" in got and "map_mIoU" in got
+    assert abs(got["mean_mIoU"] - (got["citys_mIoU"] + got["bdd_mIoU"]) / 2) < 1e-9
+    # dict-form samples (what mmengine's evaluator passes) through the plain IoUMetric
+    m2 = METRICS.build(dict(type="IoUMetric"))
+    lab = synth_label(1, 256, seed=99)[0, 0]
+    pred = _noisy_pred(lab, 98)
+    m2.process(None, [dict(pred_sem_seg=dict(data=pred.cuda()), gt_sem_seg=dict(data=lab.cuda()))])
+    res = m2.evaluate(1)
+    assert res == R.iou_metric_summary([R.intersect_and_union(pred.long(), lab)])
+
+
+def _small_model(mode):
+    set_compute_dtype(mode)
+    depth = 4
+    cfg = presets.dinov2_ms_masked(depth=depth)
+    cfg["backbone"]["backbone"]["out_indices"] = [0, 1, 2, 3]
+    sd = full_state_dict(depth=depth)
+    model = MODELS.build(cfg)
+    model.load_state_dict(sd)
+    return model.cuda().eval(), sd, dict(depth=depth, out_indices=(0, 1, 2, 3))
+
+
+def test_postprocess_result_unpads_flips_and_resizes():
+    model, _, _ = _small_model("f32")
+    try:
+        g = torch.Generator().manual_seed(5)
+        logits = torch.randn(2, 19, 96, 128, generator=g)
+        metas = [dict(padding_size=(0, 28, 0, 16), ori_shape=(160, 200), flip=True, flip_direction="horizontal"),
+                 dict(img_padding_size=(4, 0, 8, 0), ori_shape=(88, 124), flip=True, flip_direction="vertical")]
+        out = model.postprocess_result(logits.cuda().clone(), [SegDataSample(), SegDataSample()], metas)
+        ref = R.postprocess_result(logits, metas)
+        for o, (rl, rp) in zip(out, ref):
+            assert tuple(o.seg_logits.data.shape) == tuple(rl.shape)
+            assert rel_err(o.seg_logits.data.cpu(), rl) < 1e-5
+            mism = (o.pred_sem_seg.data.cpu().long() != rp)
+            top2 = rl.topk(2, dim=0)[0]
+            assert mism.float().mean() < 1e-3 and (mism.sum() == 0 or (top2[0] - top2[1])[mism[0]].max() < 1e-4)
+        # no padding / flip / resize: the batch path returns the logits themselves
+        out = model.postprocess_result(logits.cuda(), None, [dict(ori_shape=(96, 128), padding_size=[0] * 4)] * 2)
+        assert torch.equal(out[1].pred_sem_seg.data[0].cpu().long(), logits[1].argmax(0))
+    finally:
+        set_compute_dtype("bf16")
+
+
+def test_lr_and_msfull_slide_modes_match_oracle():
+    """Ms_VFM_encoder_decoder.py:276-332: `lr_slide_inference` (the config default) and `msfull_slide_inference` on a 1024^2
+    image, depth 4, fp32 parity mode, with the msfull query masks injected on both sides."""
+    model, sd, kw = _small_model("f32")
+    try:
+        img = synth_image(1, 1024, seed=71)
+        model.test_cfg["mode"] = "lr_slide_inference"
+        with torch.no_grad():
+            got = model.inference(img.cuda(), [{}]).cpu()
+            ref = R.lr_slide_inference(sd, img, **kw)
+        assert got.shape == ref.shape and rel_err(got, ref) < 1e-3, rel_err(got, ref)
+        model.test_cfg["mode"] = "msfull_slide_inference"
+        keeps = torch.rand(9, 1, 1, 32, 32, generator=torch.Generator().manual_seed(6)) > 0.2
+        model.aux_decoder.transformer_decoder.fixed_keep = keeps.reshape(9, 1, 32, 32)
+        with torch.no_grad():
+            got = model.inference(img.cuda(), [{}]).cpu()
+            ref = R.msfull_slide_inference(sd, img, mask_keeps=[keeps[j] for j in range(9)], **kw)
+        assert rel_err(got, ref) < 1e-3, rel_err(got, ref)
+    finally:
+        set_compute_dtype("bf16")
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_miou_within_0p1_of_oracle_on_fixed_synthetic_batch(mode):
+    """north_star: "mIoU within +-0.1 of reference on a fixed synthetic batch".  Predictions of the HIP path (ms_slide_inference,
+    depth 4, 3 fixed 1024^2 images) vs predictions of the oracle on the same images, both scored against the same synthetic
+    labels with the reference's metric (DGIoUMetric semantics)."""
+    model, sd, kw = _small_model(mode)
+    try:
+        model.test_cfg["mode"] = "ms_slide_inference"
+        metric = METRICS.build(dict(type="DGIoUMetric", dataset_keys=["citys"]))
+        ref_batches = []
+        for i in range(3):
+            img, lab = synth_image(1, 1024, seed=300 + i), synth_label(1, 1024, seed=300 + i)
+            with torch.no_grad():
+                out = model.predict(img.cuda(), [SegDataSample(gt_sem_seg=lab[0].cuda(), metainfo=dict(seg_map_path=f"citys/{i}.png", ori_shape=(1024, 1024)))])
+                ref = R.ms_inference(sd, img, thr=model.test_cfg["threadshod"], conf=model.test_cfg["conf"], **kw)
+            metric.process(None, out)
+            ref_batches.append([(ref.argmax(1)[0], lab[0, 0], f"citys/{i}.png")])
+        got, want = metric.evaluate(3), R.dg_iou_metrics(ref_batches, ["citys"])
+        print(f"[mIoU {mode}] HIP {got} | oracle {want}")
+        for k in ("citys_mIoU", "citys_mAcc", "citys_aAcc", "mean_mIoU"):
+            assert abs(got[k] - want[k]) <= 0.1, (k, got[k], want[k])
+    finally:
+        set_compute_dtype("bf16")

@@ -74,8 +74,9 @@ def _fulldepth(golden_dir, name, cfg, sd, img_seed, gen_seed, D, live, tol, stol
     print(f"[fulldepth {name}]", {k: f"{v_:.2e}" for k, v_ in report.items()})
 
 
-# tolerances: f32 = the 1e-3 logits bar of north_star (measured 1e-5..3e-4); bf16 = bf16 MFMA operands over 24-32 blocks
-MODES = [("f32", 1e-3, 1e-3, 5e-3, 2e-3), ("bf16", 5e-2, 2e-2, 2e-1, 5e-2)]
+# tolerances (tap slice, tensor stats, grad slice, grad norm).  Measured on MI355X (profiles/r02_parity_fulldepth_and_bf16.log): f32 taps
+# 2e-6..4e-6, grads 2e-6..1.1e-5 (north_star bar: 1e-3); bf16 taps 4e-3..1.7e-2, grads 5e-3..4.3e-2 over 24-32 blocks
+MODES = [("f32", 1e-4, 1e-3, 2e-4, 1e-3), ("bf16", 4e-2, 2e-2, 1.2e-1, 5e-2)]
 
 
 @pytest.mark.parametrize("mode,tol,stol,gtol,ntol", MODES)

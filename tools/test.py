@@ -24,7 +24,8 @@ def main():
     import torch
     import vfmseg_amd  # noqa: F401
     from vfmseg_amd.config import Config, parse_cfg_options
-    from vfmseg_amd.metrics import IoUMetric
+    from vfmseg_amd.registry import METRICS
+    from vfmseg_amd.segmentors import SegDataSample
     from vfmseg_amd.precision import set_compute_dtype
     from vfmseg_amd.registry import MODELS
     from vfmseg_amd.synth import synth_image, synth_label, synth_like
@@ -40,17 +41,22 @@ def main():
         sd.update({"backbone." + k: v for k, v in torch.load(a.backbone, map_location="cpu").items()})
     model.load_state_dict(sd, strict=False)
     model = model.cuda().eval()
-    metric = IoUMetric(num_classes=model.num_classes)
+    ev = cfg.get("test_evaluator") or cfg.get("val_evaluator") or dict(type="IoUMetric")
+    ev = dict(ev[0] if isinstance(ev, (list, tuple)) else ev)
+    metric = METRICS.build(ev)      # DGIoUMetric (rein/dg_metrics.py) with the config's dataset_keys, or mmseg's IoUMetric
+    keys = list(getattr(metric, "dataset_keys", [])) or ["synthetic"]
     t = 0.0
     for i in range(a.images):
         img, lab = synth_image(1, tuple(a.size), seed=500 + i).cuda(), synth_label(1, tuple(a.size), seed=500 + i).cuda()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = model.predict(img)
+        sample = SegDataSample(gt_sem_seg=lab[0], metainfo=dict(seg_map_path=f"{keys[i % len(keys)]}/synthetic_{i}.png",
+                                                                 ori_shape=tuple(a.size), img_shape=tuple(a.size), padding_size=[0, 0, 0, 0]))
+        out = model.predict(img, [sample])
         torch.cuda.synchronize()
         t += time.perf_counter() - t0
-        metric.process(out[0].pred_sem_seg.data[0], lab[0, 0])
-    res = metric.compute()
+        metric.process(None, out)
+    res = dict(metric.evaluate(a.images))
     res["ms_per_img"] = 1e3 * t / a.images
     print(res)
 

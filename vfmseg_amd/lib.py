@@ -101,6 +101,7 @@ SIGNATURES = {
     "vfm_conf_gate": [vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, vp],
     "vfm_slide_accumulate": [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "vfm_slide_finalize": [vp, vp, vp, ci, ci, ci, ci, vp],
+    "vfm_confusion_hist": [vp, vp, ci, cl, ci, ci, vp, vp],
     "vfm_adamw": [vp, vp, vp, vp, cl, vp, vp, vp, ci, cf, cf, cf, cf, ci, cf, vp],
 }
 

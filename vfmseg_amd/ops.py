@@ -622,6 +622,16 @@ def slide_finalize(preds, count, argmax=None):
     return preds
 
 
+def confusion_hist(pred_u8, label, hist, num_classes, ignore_index=255):
+    """hist int64 [(nc+1)*nc] += confusion counts of (label, pred) over the pixels with label != ignore_index."""
+    lib = L.load()
+    assert pred_u8.dtype == torch.uint8 and pred_u8.is_contiguous() and label.is_contiguous() and pred_u8.numel() == label.numel()
+    assert hist.dtype == torch.int64 and hist.numel() == (num_classes + 1) * num_classes
+    L.check(lib.vfm_confusion_hist(L.ptr(pred_u8), L.ptr(label), L.dt_of(label), pred_u8.numel(), int(num_classes), int(ignore_index),
+                                   L.ptr(hist), L.stream()), "vfm_confusion_hist")
+    return hist
+
+
 def adamw(p, g, m, v, seg_start, seg_lr_mult, seg_wd, lr, betas, eps, step, grad_scale=1.0):
     lib = L.load()
     L.check(lib.vfm_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(seg_start), L.ptr(seg_lr_mult),

@@ -232,15 +232,52 @@ class EncoderDecoder(nn.Module):
         return self.postprocess_result(seg_logits, data_samples, metas)
 
     def postprocess_result(self, seg_logits, data_samples, metas):
-        """argmax masks (uint8) per image; ori_shape == img_shape on the synthetic path (no un-padding / flip)."""
+        """mmseg EncoderDecoder/BaseSegmentor.postprocess_result (1.2.2, restated; reached from tools/test.py:96-145): per
+        image remove the padding recorded by the data preprocessor (`img_padding_size` / `padding_size` = left, right, top,
+        bottom), undo a test-time flip, resize the logits bilinearly to `ori_shape`, argmax -> `seg_logits` / `pred_sem_seg`."""
         B, C, H, W = seg_logits.shape
-        am = torch.empty(B, H, W, dtype=torch.uint8, device=seg_logits.device)
-        ops.slide_finalize(seg_logits, None, am)
         out = []
+        plain = True
+        for i in range(B):
+            m = metas[i] if metas else {}
+            pad = m.get("img_padding_size", m.get("padding_size", [0, 0, 0, 0]))
+            ori = tuple(m.get("ori_shape", (H, W)))[:2]
+            if any(int(v) for v in pad) or m.get("flip") or ori != (H, W):
+                plain = False
+        if plain:  # synthetic / already-sized inputs: one argmax launch over the batch, no copies
+            am = torch.empty(B, H, W, dtype=torch.uint8, device=seg_logits.device)
+            ops.slide_finalize(seg_logits, None, am)
+            per_img = [(seg_logits[i], am[i:i + 1]) for i in range(B)]
+        else:
+            per_img = []
+            for i in range(B):
+                m = metas[i] if metas else {}
+                pl, pr, pt, pb = [int(v) for v in m.get("img_padding_size", m.get("padding_size", [0, 0, 0, 0]))]
+                h, w = H - pt - pb, W - pl - pr
+                win = seg_logits[i, :, pt:H - pb, pl:W - pr]
+                cur = torch.empty(1, C, h, w, dtype=torch.float32, device=seg_logits.device)
+                sstr = [win.stride(0), win.stride(1), win.stride(2)]
+                src = win
+                if m.get("flip"):
+                    fd = m.get("flip_direction", "horizontal")
+                    assert fd in ("horizontal", "vertical")
+                    if fd == "horizontal":   # read each row backwards: start at its last element, stride -1
+                        src, sstr = win[:, :, w - 1:], [win.stride(0), win.stride(1), -win.stride(2)]
+                    else:
+                        src, sstr = win[:, h - 1:, :], [win.stride(0), -win.stride(1), win.stride(2)]
+                ops.strided_copy(src, cur, (C, h, w), sstr, (h * w, w, 1))
+                oh, ow = tuple(m.get("ori_shape", (h, w)))[:2]
+                if (oh, ow) != (h, w):
+                    res = torch.empty(1, C, oh, ow, dtype=torch.float32, device=seg_logits.device)
+                    ops.resize_bilinear(cur, True, 1, h, w, C, res, 1, (oh, ow))
+                    cur = res
+                am = torch.empty(1, oh, ow, dtype=torch.uint8, device=seg_logits.device)
+                ops.slide_finalize(cur, None, am)
+                per_img.append((cur[0], am))
         for i in range(B):
             ds = data_samples[i] if data_samples else SegDataSample()
-            ds.seg_logits = PixelData(seg_logits[i])
-            ds.pred_sem_seg = PixelData(am[i:i + 1])
+            ds.seg_logits = PixelData(per_img[i][0])
+            ds.pred_sem_seg = PixelData(per_img[i][1])
             out.append(ds)
         return out
 
@@ -323,12 +360,56 @@ class MsVFMEncoderDecoder(EncoderDecoder):
         return self.aux_decoder.forward_tokens(fp, context)
 
     def inference(self, inputs, batch_img_metas):
+        """Ms_VFM_encoder_decoder.py:276-332: the four test modes."""
         mode = self.test_cfg.get("mode", "lr_slide_inference")
+        assert mode in ("lr_slide_inference", "hr_slide_inference", "msfull_slide_inference", "ms_slide_inference")
         if mode == "ms_slide_inference":
             return self.ms_inference(inputs, batch_img_metas)
         if mode == "hr_slide_inference":
             return self.slide_inference(inputs, batch_img_metas)
-        raise NotImplementedError(f"test mode {mode} is not on the HIP path (ms_slide_inference / hr_slide_inference are)")
+        if mode == "lr_slide_inference":
+            return self.lr_slide_inference(inputs, batch_img_metas)
+        return self.msfull_slide_inference(inputs, batch_img_metas)
+
+    def _resize_nchw(self, x, size):
+        B, C, H, W = x.shape
+        out = torch.empty(B, C, size[0], size[1], dtype=torch.float32, device=x.device)
+        ops.resize_bilinear(x, True, B, H, W, C, out, 1, tuple(size))
+        return out
+
+    def lr_slide_inference(self, inputs, batch_img_metas):
+        """:280-283: 0.5x bilinear input, the base class' sliding LinearHead pass, 2x bilinear logits."""
+        B, _, H, W = inputs.shape
+        lh, lw = int(H * 0.5), int(W * 0.5)    # F.interpolate(scale_factor=0.5): floor(size * scale)
+        lr = self.slide_inference(self._resize_nchw(inputs, (lh, lw)), batch_img_metas)
+        return self._resize_nchw(lr, (int(lh * 2), int(lw * 2)))
+
+    def msfull_slide_inference(self, inputs, batch_img_metas):
+        """:286-328: coarse sliding LinearHead pass on the input squeezed to (512, 1024), logits resized to the input size,
+        then EVERY window refined by the VFMHead with its coarse logits as context (no confidence gate; the decoder's query mask
+        stays enabled here - only ms_inference turns it off, :422-423).  All windows go through one batched pass."""
+        B, _, H, W = inputs.shape
+        C = self.out_channels
+        dev = inputs.device
+        coarse = self.slide_inference(self._resize_nchw(inputs, (512, 1024)), batch_img_metas)
+        seg = self._resize_nchw(coarse, (H, W))
+        boxes = grid_boxes(H, W, self.test_cfg.crop_size, self.test_cfg.stride)
+        hc, wc = boxes[0][1] - boxes[0][0], boxes[0][3] - boxes[0][2]
+        assert all((b[1] - b[0], b[3] - b[2]) == (hc, wc) for b in boxes)
+        ctx = torch.empty(len(boxes) * B, C, hc, wc, dtype=torch.float32, device=dev)
+        for j, (y1, y2, x1, x2) in enumerate(boxes):
+            win = seg[:, :, y1:y2, x1:x2]
+            ops.strided_copy(win, ctx[j * B:(j + 1) * B], (B, C, hc, wc), (win.stride(0), win.stride(1), win.stride(2), 1),
+                             (C * hc * wc, hc * wc, wc, 1))
+        xcat, hp, wp = self._tokens([(inputs, b) for b in boxes])
+        lg = self.aux_decoder.forward_tokens(FeatPack(xcat, B * len(boxes), hp, wp), ctx)
+        preds = torch.zeros(B, C, H, W, dtype=torch.float32, device=dev)
+        count = torch.zeros(B, 1, H, W, dtype=torch.float32, device=dev)
+        for j, (y1, y2, x1, x2) in enumerate(boxes):
+            ops.slide_accumulate(lg[j * B:(j + 1) * B], False, B, lg.shape[1], lg.shape[2], C, preds, count, (y1, x1, hc, wc))
+            self.hr_crop_box = (y1, y2, x1, x2)
+        ops.slide_finalize(preds, count)
+        return preds
 
     def ms_inference(self, inputs, batch_img_metas):
         """Ms_VFM_encoder_decoder.py:400-466.  Stage 0: whole-image pass at a hard-coded (512, 1024) through the
