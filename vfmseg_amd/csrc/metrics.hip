@@ -59,11 +59,12 @@ __global__ __launch_bounds__(256) void k_confusion_hist(const uint8_t* __restric
 
 extern "C" int vfm_confusion_hist(const uint8_t* pred, const void* label, int label_dt, long n, int num_classes, int ignore_index,
                                   int64_t* hist, void* stream) {
-  VFM_CHECK(pred && label && hist && n >= 0, VFM_E_INVAL, "vfm_confusion_hist: null pointer");
+  VFM_CHECK(hist && n >= 0, VFM_E_INVAL, "vfm_confusion_hist: null histogram / negative size");
+  if (n == 0) return VFM_OK;  // an empty map (its pointers may be null) adds nothing
+  VFM_CHECK(pred && label, VFM_E_INVAL, "vfm_confusion_hist: null pointer");
   VFM_CHECK(num_classes > 0 && num_classes <= NC_MAX, VFM_E_SHAPE, "vfm_confusion_hist: num_classes %d not in [1, %d]", num_classes, NC_MAX);
   VFM_CHECK(label_dt == VFM_I64 || label_dt == VFM_U8, VFM_E_UNSUPPORTED, "vfm_confusion_hist: labels must be int64 or uint8");
   VFM_CHECK(((uintptr_t)pred & 15) == 0 && ((uintptr_t)label & 15) == 0, VFM_E_ALIGN, "vfm_confusion_hist: 16-byte aligned maps required");
-  if (n == 0) return VFM_OK;
   const int bins = (num_classes + 1) * num_classes;
   const size_t lds = 4u * bins * sizeof(unsigned int);
   long blocks = (n / 16 + 255) / 256;
