@@ -629,7 +629,8 @@ class _BackboneFn(torch.autograd.Function):
     def forward(ctx, vit, jobs, training, seed, *lora_params):
         eng = vit.engine()
         need_grad = training and any(p.requires_grad for p in lora_params)
-        xcat, grid, c = eng.forward(jobs, training, seed)
+        with ops.region("backbone"):
+            xcat, grid, c = eng.forward(jobs, training, seed)
         if need_grad:
             ctx.eng, ctx.c = eng, c
         else:
@@ -646,7 +647,8 @@ class _BackboneFn(torch.autograd.Function):
             return (None, None, None, None) + (None,) * ctx.nparams
         if BACKWARD_EVENTS["heads_done"] is not None:
             BACKWARD_EVENTS["heads_done"]()
-        grads = ctx.eng.backward(ctx.c, dxcat.contiguous())
+        with ops.region("backbone"):
+            grads = ctx.eng.backward(ctx.c, dxcat.contiguous())
         return (None, None, None, None) + tuple(grads)
 
 

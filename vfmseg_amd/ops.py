@@ -12,6 +12,23 @@ from .lib import (ACT_GELU, ACT_NONE, ACT_QGELU, ACT_RELU, BF16, EP_GELU, EP_MUL
 
 _ws_cache = {}
 
+# Measurement hook (bench.py installs it; None in production): PROFILE(kind, flops, region) -> finish() | None is called around the
+# launches of the two MFMA kernel families so that HIP events bracket exactly one kernel on the stream it is launched on.
+# REGION names who is launching ("backbone" inside the ViT engines, "heads" elsewhere).
+PROFILE = None
+REGION = ["heads"]
+
+
+class region:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        REGION.append(self.name)
+
+    def __exit__(self, *a):
+        REGION.pop()
+
 
 def workspace(nfloats, device, tag="default"):
     """Grow-only fp32 scratch per (device, tag); kernels never allocate."""
@@ -329,7 +346,10 @@ def gemm(a, b, c, *, alpha=1.0, bias=None, bias_mod=0, colscale=None, residual=N
         d.batch, d.stride_a, d.stride_b, d.stride_c = a.shape[0], a.stride(0), b.stride(0), c.stride(0)
     else:
         d.batch = 1
+    fin = PROFILE("gemm", 2.0 * M * N * K * d.batch, REGION[-1]) if (PROFILE is not None and a.dtype == torch.bfloat16) else None
     L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
+    if fin is not None:
+        fin()
     return c
 
 
@@ -393,7 +413,10 @@ def gemm_splitk_bt(at, y, slabs, kch):
     d.alpha = 1.0
     d.batch, d.stride_a, d.stride_b, d.stride_c = kch, ck, ck * y.stride(0), slabs.stride(0)
     d.kb_rows = int(M)
+    fin = PROFILE("gemm", 2.0 * P * Q * mp, REGION[-1]) if PROFILE is not None else None
     L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
+    if fin is not None:
+        fin()
     return slabs
 
 
@@ -418,7 +441,10 @@ def gemm_splitk_tn(xs, y, slabs, kch):
     d.alpha = 1.0
     d.batch, d.stride_a, d.stride_b, d.stride_c = kch, ck * xs.stride(0), ck * y.stride(0), slabs.stride(0)
     d.kb_rows = int(M)
+    fin = PROFILE("gemm", 2.0 * P * Q * mp, REGION[-1]) if PROFILE is not None else None
     L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
+    if fin is not None:
+        fin()
     return slabs
 
 
@@ -443,7 +469,12 @@ def attn_fwd(q, k, v, o, lse, B, H, d, nq_main, nq_extra, nk_main, nk_extra, sca
     """q,k,v,o: 2-D row-major views [rows, >=H*d] (column slices of a packed qkv buffer are fine)."""
     lib = L.load()
     a = _attn_desc(q, k, v, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, lse)
+    fin = None
+    if PROFILE is not None and q.dtype == torch.bfloat16:   # QK^T + PV: 4 B H Nq Nk d
+        fin = PROFILE("attn_fwd", 4.0 * B * H * (nq_main + nq_extra) * (nk_main + nk_extra) * d, REGION[-1])
     L.check(lib.vfm_attn_fwd(C.byref(a), L.stream()), "vfm_attn_fwd")
+    if fin is not None:
+        fin()
     return o
 
 
@@ -455,7 +486,12 @@ def attn_bwd(q, k, v, o, lse, dout, dq, dk, dv, B, H, d, nq_main, nq_extra, nk_m
     a.ld_dq, a.ld_dk, a.ld_dv = dq.stride(0), dk.stride(0), dv.stride(0)
     delta = workspace(B * H * (nq_main + nq_extra), q.device, "attn_delta")
     a.delta = L.ptr(delta)
+    fin = None
+    if PROFILE is not None and q.dtype == torch.bfloat16:   # algorithmic: S, dP, dV, dK, dQ = five products = 10 B H Nq Nk d
+        fin = PROFILE("attn_bwd", 10.0 * B * H * (nq_main + nq_extra) * (nk_main + nk_extra) * d, REGION[-1])
     L.check(lib.vfm_attn_bwd(C.byref(a), L.stream()), "vfm_attn_bwd")
+    if fin is not None:
+        fin()
 
 
 def sam_relpos_table(rel_pos, S, out):
