@@ -25,7 +25,8 @@ enum { VFM_F32 = 0, VFM_BF16 = 1, VFM_U8 = 2, VFM_I64 = 3 };
 enum { VFM_OK = 0, VFM_E_INVAL = -1, VFM_E_SHAPE = -2, VFM_E_ALIGN = -3, VFM_E_HIP = -4, VFM_E_UNSUPPORTED = -5 };
 /* GEMM epilogue modes */
 enum { VFM_EP_NONE = 0, VFM_EP_GELU = 1, VFM_EP_RELU = 2, VFM_EP_MUL_GELU_GRAD = 3, VFM_EP_MUL = 4,
-       VFM_EP_QGELU = 5 /* CLIP QuickGELU x*sigmoid(1.702x), clip.py:18-20 */, VFM_EP_MUL_QGELU_GRAD = 6 };
+       VFM_EP_QGELU = 5 /* CLIP QuickGELU x*sigmoid(1.702x), clip.py:18-20 */, VFM_EP_MUL_QGELU_GRAD = 6,
+       VFM_EP_GELU_DGELU = 7 /* C = gelu(v) and C2 = gelu'(v) (NOT the pre-activation): the backward GEMM then uses VFM_EP_MUL */ };
 /* activation fused into norm kernels */
 enum { VFM_ACT_NONE = 0, VFM_ACT_GELU = 1, VFM_ACT_RELU = 2, VFM_ACT_QGELU = 3 };
 
@@ -44,6 +45,14 @@ int vfm_transpose(const void* src, int src_dt, long ld_src, void* dst, int dst_d
  * dst[i0*d0+i1*d1+i2*d2+i3*d3] = src[i0*s0+i1*s1+i2*s2+i3*s3]; accumulate=1 adds into an fp32 dst */
 int vfm_strided_copy(const void* src, int src_dt, void* dst, int dst_dt, long n0, long n1, long n2, long n3, long s0,
                      long s1, long s2, long s3, long d0, long d1, long d2, long d3, int accumulate, void* stream);
+/* A table of such copies in ONE launch (fp32 sources; entries in DEVICE memory; max_elems = the largest entry's element count):
+ * the per-step re-pack of all trainable decoder weights (Conv2d / ConvTranspose2d / Linear parameters of linear_head.py:36-48,
+ * VFMHead.py:28-49, Transformer.py:95-177) into their GEMM operand layouts. */
+typedef struct vfm_copy_job {
+  const float* src; void* dst; long dst_dt;
+  long n[4], s[4], d[4];
+} vfm_copy_job;
+int vfm_strided_copy_batch(const vfm_copy_job* table_dev, int njobs, long max_elems, void* stream);
 /* y = a*x + b*y elementwise over n fp32 values (gradient accumulation, residual adds) */
 int vfm_axpby(const float* x, float a, float* y, float b, long n, void* stream);
 /* y[i] *= *scalar (device scalar; keeps the loss-scale multiply on the GPU) */
@@ -142,7 +151,9 @@ int vfm_bn_bwd_apply(const void* dy, int dy_dt, const float* x, const float* mea
  *                   (sb_k == 1) or [K,N] (sb_n == 1, N % 8 == 0: weight-gradient GEMMs consume activations in place)
  *   in_dt VFM_F32 : exact-fp32 MFMA path, arbitrary element strides (sa_m,sa_k),(sb_n,sb_k), any K
  * epilogue order:  v = alpha*acc + bias[n % bias_mod];  if C2: C2 = v (pre-activation, saved for backward)
- *                  ep_mode: GELU/RELU -> v = act(v);  MUL_GELU_GRAD -> v *= gelu'(aux[m,n]);  MUL -> v *= aux[m,n]
+ *                  ep_mode: GELU/RELU -> v = act(v);  MUL_GELU_GRAD -> v *= gelu'(aux[m,n]);  MUL -> v *= aux[m,n];
+ *                           GELU_DGELU -> C2 = gelu'(v) instead of v, then v = gelu(v)   (mlp.py:34-40 forward saving what its
+ *                           backward multiplies by)
  *                  v *= colscale[n];  v += residual[m,n];  C = v   (residual may alias C: in-place accumulate)
  * batch: z in [0,batch): operand offsets z*stride (elements).  (attention.py:51-53,58,80; mlp.py:34-40; linear_head.py:36-48)
  */
@@ -251,6 +262,9 @@ int vfm_unblock(const float* x, float* y, int B, int H, int W, int C, int levels
  *   touch HBM. */
 int vfm_upsample_ce(const float* logits_low, const int64_t* label, int B, int h, int w, int C, int H, int W,
                     int ignore_index, float* loss_parts, int32_t* counts, float* dlogits, void* stream);
+/* After vfm_upsample_ce: loss[0] = scale * sum(loss_parts[0..n)), acc[0] = 100 * counts[0] / (counts[1] + eps) (mmseg `accuracy`
+ * over the valid pixels, linear_head.py:95-108), then counts is reset to (0, 0) for the next call. */
+int vfm_ce_finish(const float* loss_parts, long n, float scale, int32_t* counts, float eps, float* loss, float* acc, void* stream);
 /* deterministic sum of n floats -> out[0] (out[0] *= scale) */
 int vfm_reduce_sum(const float* x, long n, float scale, float* out, void* stream);
 
@@ -283,10 +297,12 @@ int vfm_confusion_hist(const uint8_t* pred, const void* label, int label_dt, lon
 /* ---- optimiser ------------------------------------------------------------------------------------- */
 /* fused multi-tensor AdamW over one flat fp32 buffer (torch.optim.AdamW semantics; groups from
  * peft_optimizer_constructor.py:25-147): segment s covers [seg_start[s], seg_start[s+1]) with lr*seg_lr_mult[s],
- * seg_wd[s]. lr and step are passed by value each iteration (PolyLR on the host). */
-int vfm_adamw(float* p, const float* g, float* m, float* v, long n, const long* seg_start, const float* seg_lr_mult,
+ * seg_wd[s]. lr and step are passed by value each iteration (PolyLR on the host).  zero_grad != 0 also clears g in the same
+ * pass (OptimWrapper.update_params: step then zero_grad); vec4 != 0 promises that every seg_start is a multiple of 4 (and the
+ * buffers 16-byte aligned): one float4 per lane. */
+int vfm_adamw(float* p, float* g, float* m, float* v, long n, const long* seg_start, const float* seg_lr_mult,
               const float* seg_wd, int n_seg, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
-              void* stream);
+              int zero_grad, int vec4, void* stream);
 
 #ifdef __cplusplus
 }

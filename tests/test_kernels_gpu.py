@@ -329,6 +329,13 @@ def test_gemm_f32(M, N, K):
         ref, pre = _gemm_ref(a, b, bias, cs, res, ep, aux, 0.5)
         assert relerr(c, ref) < 1e-5, ep
         assert relerr(c2, pre) < 1e-5
+    # GELU forward that saves gelu'(pre-activation) in the second output
+    c, c2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    ops.gemm(a.to(DEV), b.to(DEV), c, bias=bias.to(DEV), ep_mode=ops.EP_GELU_DGELU, c2=c2)
+    pre = (a.double() @ b.double().t() + bias.double()).requires_grad_(True)
+    gl = F.gelu(pre)
+    gl.sum().backward()
+    assert relerr(c, gl.detach()) < 1e-5 and relerr(c2, pre.grad) < 1e-5
     # transposed operands via strides + in-place accumulate
     c = res.clone().to(DEV)
     ops.gemm(a.t().contiguous().to(DEV), b.t().contiguous().to(DEV), c, residual=c, trans_a=True, trans_b=True)
@@ -397,6 +404,17 @@ def test_gemm_bf16_configs_fast_epilogues(cfg, M, N, K):
             c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
             ops.gemm(a, b, c, ep_mode=ops.EP_MUL_GELU_GRAD, aux=aux)
             assert relerr(c.float(), acc * gelu_grad(ad)) < 1e-2
+            # forward that saves the activation's derivative + the backward that only multiplies (what the backbones use)
+            c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            c2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ops.gemm(a, b, c, bias=bias, ep_mode=ops.EP_GELU_DGELU, c2=c2)
+            assert relerr(c.float(), gelu(acc + bd)) < 1e-2 and relerr(c2.float(), gelu_grad(acc + bd)) < 1e-2
+            c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ops.gemm(a, b, c, ep_mode=ops.EP_MUL, aux=aux)
+            assert relerr(c.float(), acc * ad) < 1e-2
+            c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            ops.gemm(a, b, c, bias=bias, ep_mode=ops.EP_GELU)
+            assert relerr(c.float(), gelu(acc + bd)) < 1e-2
     finally:
         ops.tune("gemm_cfg", -1)
 
@@ -597,21 +615,26 @@ def test_inference_helpers():
     assert torch.equal(am.cpu().long(), (pr / cr).argmax(1))
 
 
-def test_adamw():
-    n = 10000
+@pytest.mark.parametrize("vec4,zero", [(False, False), (True, True)])
+def test_adamw(vec4, zero):
+    """vs torch.optim.AdamW with two parameter groups (different lr multipliers and decays), scalar and float4 forms; the
+    fused zero_grad clears the gradient buffer in the same pass."""
+    n = 10000 + (0 if vec4 else 3)
+    cut = 6000
     p, g = rnd(n, seed=58), rnd(n, seed=59)
-    q = p.clone().requires_grad_(True)
-    q2 = p[6000:].clone().requires_grad_(True)
-    opt = torch.optim.AdamW([dict(params=[q], weight_decay=0.05)], lr=1e-3)
+    q1, q2 = p[:cut].clone().requires_grad_(True), p[cut:].clone().requires_grad_(True)
+    opt = torch.optim.AdamW([dict(params=[q1], weight_decay=0.05, lr=1e-3), dict(params=[q2], weight_decay=0.0, lr=2e-3)])
     pd, m, v = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
-    seg = torch.tensor([0, 6000], dtype=torch.int64, device=DEV)
-    lrm = torch.tensor([1.0, 1.0], device=DEV)
-    wd = torch.tensor([0.05, 0.05], device=DEV)
+    seg = torch.tensor([0, cut], dtype=torch.int64, device=DEV)
+    lrm = torch.tensor([1.0, 2.0], device=DEV)
+    wd = torch.tensor([0.05, 0.0], device=DEV)
     for step in (1, 2, 3):
-        q.grad = g.clone() * step
+        q1.grad, q2.grad = g[:cut].clone() * step, g[cut:].clone() * step
         opt.step()
-        ops.adamw(pd, (g * step).to(DEV), m, v, seg, lrm, wd, 1e-3, (0.9, 0.999), 1e-8, step)
-    assert relerr(pd, q.detach()) < 1e-5
+        gd = (g * step * 4.0).to(DEV)
+        ops.adamw(pd, gd, m, v, seg, lrm, wd, 1e-3, (0.9, 0.999), 1e-8, step, grad_scale=0.25, zero_grad=zero, vec4=vec4)
+        assert (gd.abs().sum().item() == 0) == zero
+    assert relerr(pd, torch.cat([q1, q2]).detach()) < 1e-5
 
 
 def test_checkpoint_converters():

@@ -454,9 +454,13 @@ class DinoEngine:
             st2 = torch.empty(M, 2, dtype=torch.float32, device=dev)
             ops.layernorm_fwd(xm, Lp["n2w"], Lp["n2b"], 1e-6, a2, st2)
             hid = Lp["fc1"].n
-            hpre = torch.empty(M, hid, dtype=cd, device=dev)
             g = ops.empty_ld(M, hid, cd, dev)
-            Lp["fc1"].fwd(a2, g, bias=Lp["fc1_b"], ep_mode=ops.EP_GELU, c2=hpre)
+            if training and lora:   # the forward also saves gelu'(pre-activation): what fc2's dgrad multiplies by (mlp.py:34-40)
+                hpre = torch.empty(M, hid, dtype=cd, device=dev)
+                Lp["fc1"].fwd(a2, g, bias=Lp["fc1_b"], ep_mode=ops.EP_GELU_DGELU, c2=hpre)
+            else:
+                hpre = None
+                Lp["fc1"].fwd(a2, g, bias=Lp["fc1_b"], ep_mode=ops.EP_GELU)
             xo = torch.empty(M, D, dtype=torch.float32, device=dev)
             Lp["fc2"].fwd(g, xo, bias=Lp["fc2_b"], colscale=Lp["g2"], residual=xm)
             S.update(a1=a1, st1=st1, qkv=qkv, ao=ao, lse=lse, x_mid=xm, a2=a2, st2=st2, hpre=hpre, g=g)
@@ -495,7 +499,7 @@ class DinoEngine:
                 ops.cast(dx, t, Lp["g2"])
             hid = Lp["fc1"].n
             dh = ops.empty_ld(M, hid, cd, dev)
-            Lp["fc2"].dgrad(t, dh, ep_mode=ops.EP_MUL_GELU_GRAD, aux=S["hpre"])
+            Lp["fc2"].dgrad(t, dh, ep_mode=ops.EP_MUL, aux=S["hpre"])
             dn = torch.empty(M, D, dtype=cd, device=dev)
             Lp["fc1"].dgrad(dh, dn)
             if fuse_t:

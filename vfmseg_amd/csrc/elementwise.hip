@@ -169,12 +169,28 @@ __global__ void k_colsum1(const T* __restrict__ x, long ld, long rows, long cols
     ws[(long)blockIdx.y * cols + c] = a;
   }
 }
-__global__ void k_colsum2(const float* __restrict__ ws, long cols, int parts, float* __restrict__ out, int accumulate) {
-  const long c = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+// second stage: 64 columns x 4 part groups per block; every thread's loads are independent (unrolled), the four group sums meet in
+// LDS in a fixed order (deterministic).  The first form - one thread per column walking all parts - was a chain of up to 64
+// dependent loads: 16 us per call, ~30 calls per train step.
+__global__ void __launch_bounds__(256) k_colsum2(const float* __restrict__ ws, long cols, int parts, float* __restrict__ out, int accumulate) {
+  __shared__ float sh[4][64];
+  const int tx = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long c = blockIdx.x * 64L + tx;
   float a = 0.f;
-  for (int p = 0; p < parts; ++p) a += ws[(long)p * cols + c];
-  out[c] = accumulate ? out[c] + a : a;
+  if (c < cols) {
+    int p = g;
+    for (; p + 12 < parts; p += 16) {
+      const float v0 = ws[(long)p * cols + c], v1 = ws[(long)(p + 4) * cols + c], v2 = ws[(long)(p + 8) * cols + c], v3 = ws[(long)(p + 12) * cols + c];
+      a += (v0 + v1) + (v2 + v3);
+    }
+    for (; p < parts; p += 4) a += ws[(long)p * cols + c];
+  }
+  sh[g][tx] = a;
+  __syncthreads();
+  if (g == 0 && c < cols) {
+    const float t = (sh[0][tx] + sh[1][tx]) + (sh[2][tx] + sh[3][tx]);
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 extern "C" int vfm_colsum(const void* x, int dt, long ld, long rows, long cols, float* out, int accumulate, float* ws,
                           void* stream) {
@@ -191,7 +207,7 @@ extern "C" int vfm_colsum(const void* x, int dt, long ld, long rows, long cols, 
   if (dt == VFM_F32) hipLaunchKernelGGL(k_colsum1<float>, grid, dim3(256), 0, s, (const float*)x, ld, rows, cols, ws, CT);
   else if (dt == VFM_BF16) hipLaunchKernelGGL(k_colsum1<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, rows, cols, ws, CT);
   else VFM_FAIL(VFM_E_INVAL, "vfm_colsum: dtype");
-  hipLaunchKernelGGL(k_colsum2, dim3(cdiv(cols, 256)), dim3(256), 0, s, ws, cols, (int)parts, out, accumulate);
+  hipLaunchKernelGGL(k_colsum2, dim3(cdiv(cols, 64)), dim3(256), 0, s, ws, cols, (int)parts, out, accumulate);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }
@@ -220,6 +236,32 @@ extern "C" int vfm_slab_reduce(const float* slabs, int kch, long P, long Q, long
   const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(k_slab_reduce, dim3(grid), dim3(256), 0, (hipStream_t)stream, slabs, kch, P, Q, rows_used, alpha, dst, sp, sq,
                      accumulate);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ batched strided copy
+// One launch for a whole TABLE of 4-D strided fp32 -> (bf16 | fp32) copies (blockIdx.y = entry): the per-step re-pack of every
+// trainable decoder weight into its GEMM operand layout (39 single launches + zero fills per train step before).
+__global__ void k_strided_copy_batch(const vfm_copy_job* __restrict__ tab) {
+  const vfm_copy_job t = tab[blockIdx.y];
+  const long total = t.n[0] * t.n[1] * t.n[2] * t.n[3];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i;
+    const long i3 = r % t.n[3]; r /= t.n[3];
+    const long i2 = r % t.n[2]; r /= t.n[2];
+    const long i1 = r % t.n[1]; r /= t.n[1];
+    const float v = t.src[r * t.s[0] + i1 * t.s[1] + i2 * t.s[2] + i3 * t.s[3]];
+    st_any(t.dst, r * t.d[0] + i1 * t.d[1] + i2 * t.d[2] + i3 * t.d[3], t.dst_dt, v);
+  }
+}
+extern "C" int vfm_strided_copy_batch(const vfm_copy_job* table_dev, int njobs, long max_elems, void* stream) {
+  VFM_CHECK(table_dev && njobs >= 0, VFM_E_INVAL, "vfm_strided_copy_batch: bad args");
+  if (njobs == 0 || max_elems <= 0) return VFM_OK;
+  int gx = (int)((max_elems + 1023) / 1024);   // >= 4 elements per thread
+  if (gx > 64) gx = 64;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(k_strided_copy_batch, dim3(gx, njobs), dim3(256), 0, (hipStream_t)stream, table_dev);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }
@@ -668,7 +710,7 @@ extern "C" int vfm_mask_token_bwd(const float* dout, const uint8_t* keep, float*
   const long rpc = (rows + nchunk - 1) / nchunk;
   hipLaunchKernelGGL(k_mask_token_bwd, dim3(cdiv(C, 64), (unsigned)nchunk), dim3(256), 0, (hipStream_t)stream, dout, keep, dx, ws, rows,
                      C, rpc);
-  hipLaunchKernelGGL(k_colsum2, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, ws, C, (int)nchunk, dtoken, 0);
+  hipLaunchKernelGGL(k_colsum2, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, ws, C, (int)nchunk, dtoken, 0);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }
@@ -680,6 +722,27 @@ __global__ void k_reduce_sum(const float* __restrict__ x, long n, float scale, f
   for (long i = threadIdx.x; i < n; i += blockDim.x) a += x[i];
   a = block_sum(a, sh);
   if (threadIdx.x == 0) out[0] = a * scale;
+}
+// loss = scale * sum(parts) and acc = 100 * hits / (valid + eps) in one launch; counts = (hits, valid) is then reset to zero
+// for the next call (the head keeps one persistent counter pair: no fill launch, no five-kernel ATen chain per head and step)
+__global__ void k_ce_finish(const float* __restrict__ x, long n, float scale, int32_t* __restrict__ counts, float eps,
+                            float* __restrict__ loss, float* __restrict__ acc) {
+  __shared__ float sh[16];
+  float a = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) a += x[i];
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0) {
+    loss[0] = a * scale;
+    acc[0] = (float)counts[0] * (100.0f / ((float)counts[1] + eps));
+    counts[0] = 0, counts[1] = 0;
+  }
+}
+extern "C" int vfm_ce_finish(const float* parts, long n, float scale, int32_t* counts, float eps, float* loss, float* acc,
+                             void* stream) {
+  VFM_CHECK(parts && counts && loss && acc, VFM_E_INVAL, "vfm_ce_finish: null pointer");
+  hipLaunchKernelGGL(k_ce_finish, dim3(1), dim3(1024), 0, (hipStream_t)stream, parts, n, scale, counts, eps, loss, acc);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
 }
 extern "C" int vfm_reduce_sum(const float* x, long n, float scale, float* out, void* stream) {
   hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, scale, out);

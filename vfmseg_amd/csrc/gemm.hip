@@ -68,6 +68,7 @@ extern "C" int vfm_gemm(const vfm_gemm_desc* d, void* stream) {
   VFM_CHECK(d->M >= 0 && d->N >= 0 && d->K >= 0, VFM_E_SHAPE, "vfm_gemm: negative dim");
   VFM_CHECK(d->ldc >= d->N, VFM_E_SHAPE, "vfm_gemm: ldc < N");
   VFM_CHECK(!(d->ep_mode == VFM_EP_MUL_GELU_GRAD || d->ep_mode == VFM_EP_MUL || d->ep_mode == VFM_EP_MUL_QGELU_GRAD) || d->aux, VFM_E_INVAL, "vfm_gemm: aux missing");
+  VFM_CHECK(d->ep_mode != VFM_EP_GELU_DGELU || d->C2, VFM_E_INVAL, "vfm_gemm: VFM_EP_GELU_DGELU needs the second output C2");
   if (d->M == 0 || d->N == 0) return VFM_OK;
   hipStream_t s = (hipStream_t)stream;
   const long batch = d->batch > 0 ? d->batch : 1;

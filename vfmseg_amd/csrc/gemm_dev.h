@@ -28,14 +28,19 @@ __device__ __forceinline__ void epi_store4(const EpiParams& e, long zoff, long m
   }
   if (e.C2) {
     const long o = zoff + m * e.ldc2 + n;
+    float y[4] = {x[0], x[1], x[2], x[3]};
+    if (e.ep_mode == VFM_EP_GELU_DGELU) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[i] = gelu_grad_f(x[i]);
+    }
     if (e.c2_dt == VFM_BF16) {
-      ushort4 p = {f32_to_bf16(x[0]), f32_to_bf16(x[1]), f32_to_bf16(x[2]), f32_to_bf16(x[3])};
+      ushort4 p = {f32_to_bf16(y[0]), f32_to_bf16(y[1]), f32_to_bf16(y[2]), f32_to_bf16(y[3])};
       *reinterpret_cast<ushort4*>((bf16_t*)e.C2 + o) = p;
     } else {
-      *reinterpret_cast<float4*>((float*)e.C2 + o) = make_float4(x[0], x[1], x[2], x[3]);
+      *reinterpret_cast<float4*>((float*)e.C2 + o) = make_float4(y[0], y[1], y[2], y[3]);
     }
   }
-  if (e.ep_mode == VFM_EP_GELU) {
+  if (e.ep_mode == VFM_EP_GELU || e.ep_mode == VFM_EP_GELU_DGELU) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) x[i] = gelu_f(x[i]);
   } else if (e.ep_mode == VFM_EP_RELU) {
@@ -231,6 +236,182 @@ __device__ __forceinline__ void epi_fast(const EpiParams& e, long zoff, f32x16 (
   if constexpr (NG > 3) group(IC<3>{});
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// epi_fast8: the same straight-line scheme at EIGHT columns per lane (one 16-byte store per bf16 output row piece: the store tail
+// of a tile is issue-bound, not bandwidth-bound) with the arithmetic on pairs (v_pk_fma_f32 / v_pk_mul_f32: two columns per
+// VALU issue).  C2MODE: 0 no second output, 1 = bf16 pre-activation, 2 = bf16 derivative of the activation at the pre-activation
+// (GELU: Phi(v) + v phi(v); its exponential is the one inside erf, so both outputs cost one rcp + one exp per element) - the
+// backward GEMM then only multiplies (VFM_EP_MUL) instead of re-evaluating the derivative from a bf16-rounded copy.
+// Measured inside the train step: the epilogue of the fc1 / fc2-dgrad GEMMs (GELU on 16.8 M values, 64 MB of
+// stores) cost 27-34 us of a 54-59 us launch.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+
+// g = gelu(v), dg = gelu'(v) for a pair (Abramowitz-Stegun 7.1.26 erf, |err| <= 1.5e-7, as erf_fast / gelu_grad_fast)
+template <bool WANT_DG>
+__device__ __forceinline__ void gelu_pair(f32x2 v, f32x2& g, f32x2& dg) {
+  const f32x2 av = f32x2{fabsf(v.x), fabsf(v.y)};
+  const f32x2 den = pk_fma(splat2(0.3275911f * 0.70710678118654752440f), av, splat2(1.0f));
+  const f32x2 t = f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+  f32x2 p = pk_fma(t, splat2(1.061405429f), splat2(-1.453152027f));
+  p = pk_fma(t, p, splat2(1.421413741f));
+  p = pk_fma(t, p, splat2(-0.284496736f));
+  p = pk_fma(t, p, splat2(0.254829592f));
+  const f32x2 e2 = v * v * splat2(-0.5f * 1.44269504088896340736f);        // exp(-v^2/2) = exp2(-v^2/2 * log2 e)
+  const f32x2 ex = f32x2{__builtin_amdgcn_exp2f(e2.x), __builtin_amdgcn_exp2f(e2.y)};
+  const f32x2 q = p * t * ex;                                               // 1 - erf(|v| / sqrt 2)
+  const f32x2 erfa = splat2(1.0f) - q;
+  const f32x2 erfv = f32x2{copysignf(erfa.x, v.x), copysignf(erfa.y, v.y)};
+  const f32x2 cdf = pk_fma(splat2(0.5f), erfv, splat2(0.5f));
+  g = v * cdf;
+  if constexpr (WANT_DG) dg = pk_fma(v * splat2(0.39894228040143267794f), ex, cdf);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(f32x2 v) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);   // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+  return *reinterpret_cast<const uint32_t*>(&b);
+}
+__device__ __forceinline__ f32x2 unpack_bf16x2(uint32_t w) { return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+
+template <int MODE, int CDT, int RES, int C2MODE, int MI, int NI, int GROUP>
+__device__ __forceinline__ void epi_fast8(const EpiParams& e, long zoff, f32x16 (&acc)[MI][NI], float* img, int lane, long m_base,
+                                          long n_base, long M, long N) {
+  constexpr int WN = NI * 32, LD = WN + 4, LPR = WN / 8, RPP = 64 / LPR, PPS = 32 / RPP, NP = MI * PPS, NG = MI / GROUP;
+  static_assert(MI % GROUP == 0 && NG <= 4, "slab grouping");
+  constexpr bool AUX = (MODE == VFM_EP_MUL_GELU_GRAD || MODE == VFM_EP_MUL || MODE == VFM_EP_MUL_QGELU_GRAD);
+  const int fr = lane & 31, fh = lane >> 5;
+  const int rr = lane / LPR, cc = (lane % LPR) * 8;
+  const long n = n_base + cc;
+  const bool n_ok = n < N;  // N % 8 == 0 on this path
+  f32x2 b2[4], s2[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b2[i] = splat2(0.f), s2[i] = splat2(1.f);
+  if (e.bias && n_ok) {
+    const long bn = n % e.bias_mod;
+    const float4 lo = *reinterpret_cast<const float4*>(e.bias + bn), hi = *reinterpret_cast<const float4*>(e.bias + bn + 4);
+    b2[0] = f32x2{lo.x, lo.y}, b2[1] = f32x2{lo.z, lo.w}, b2[2] = f32x2{hi.x, hi.y}, b2[3] = f32x2{hi.z, hi.w};
+  }
+  if (e.colscale && n_ok) {
+    const float4 lo = *reinterpret_cast<const float4*>(e.colscale + n), hi = *reinterpret_cast<const float4*>(e.colscale + n + 4);
+    s2[0] = f32x2{lo.x, lo.y}, s2[1] = f32x2{lo.z, lo.w}, s2[2] = f32x2{hi.x, hi.y}, s2[3] = f32x2{hi.z, hi.w};
+  }
+  const f32x2 alpha2 = splat2(e.alpha);
+
+  auto dump = [&](auto Gc) {
+    constexpr int gi = decltype(Gc)::value;
+#pragma unroll
+    for (int s = 0; s < GROUP; ++s)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          img[(s * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LD + j * 32 + fr] = acc[gi * GROUP + s][j][r];
+  };
+  dump(IC<0>{});
+
+  // ---- every load of the wave tile, before any store (loads and stores share one in-order vmcnt)
+  float4 res[RES == 1 ? 2 * NP : 1];
+  uint4 resh[RES == 2 ? NP : 1];
+  uint4 aux[AUX ? NP : 1];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const long m = m_base + (p / PPS) * 32 + (p % PPS) * RPP + rr;
+    const bool ok = n_ok && m < M;
+    if constexpr (RES == 1) {
+      res[2 * p] = res[2 * p + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        const float* rp = (const float*)e.residual + zoff + m * e.ldr + n;
+        res[2 * p] = *reinterpret_cast<const float4*>(rp), res[2 * p + 1] = *reinterpret_cast<const float4*>(rp + 4);
+      }
+    }
+    if constexpr (RES == 2) {
+      resh[p] = make_uint4(0, 0, 0, 0);
+      if (ok) resh[p] = *reinterpret_cast<const uint4*>((const bf16_t*)e.residual + zoff + m * e.ldr + n);
+    }
+    if constexpr (AUX) {
+      aux[p] = make_uint4(0, 0, 0, 0);
+      if (ok) aux[p] = *reinterpret_cast<const uint4*>((const bf16_t*)e.aux + m * e.ld_aux + n);
+    }
+  }
+
+  auto group = [&](auto Gc) {
+    constexpr int gi = decltype(Gc)::value;
+    if constexpr (gi > 0) dump(Gc);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < GROUP * PPS; ++q) {
+      const int p = gi * GROUP * PPS + q;
+      const int irow = (q / PPS) * 32 + (q % PPS) * RPP + rr;
+      const long m = m_base + (p / PPS) * 32 + (p % PPS) * RPP + rr;
+      const float4 v0 = *reinterpret_cast<const float4*>(img + irow * LD + cc), v1 = *reinterpret_cast<const float4*>(img + irow * LD + cc + 4);
+      f32x2 x[4] = {pk_fma(f32x2{v0.x, v0.y}, alpha2, b2[0]), pk_fma(f32x2{v0.z, v0.w}, alpha2, b2[1]),
+                    pk_fma(f32x2{v1.x, v1.y}, alpha2, b2[2]), pk_fma(f32x2{v1.z, v1.w}, alpha2, b2[3])};
+      const bool ok = n_ok && m < M;
+      f32x2 d[4];
+      if constexpr (C2MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = x[i];
+      }
+      if constexpr (MODE == VFM_EP_GELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x2 g, dg;
+          gelu_pair<C2MODE == 2>(x[i], g, dg);
+          x[i] = g;
+          if constexpr (C2MODE == 2) d[i] = dg;
+        }
+      } else if constexpr (MODE == VFM_EP_RELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = f32x2{fmaxf(x[i].x, 0.f), fmaxf(x[i].y, 0.f)};
+      } else if constexpr (MODE == VFM_EP_QGELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = f32x2{qgelu_f(x[i].x), qgelu_f(x[i].y)};
+      } else if constexpr (AUX) {
+        const uint32_t aw[4] = {aux[p].x, aux[p].y, aux[p].z, aux[p].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x2 a = unpack_bf16x2(aw[i]);
+          if constexpr (MODE == VFM_EP_MUL_GELU_GRAD) a = f32x2{gelu_grad_fast(a.x), gelu_grad_fast(a.y)};
+          if constexpr (MODE == VFM_EP_MUL_QGELU_GRAD) a = f32x2{qgelu_grad_f(a.x), qgelu_grad_f(a.y)};
+          x[i] = x[i] * a;
+        }
+      }
+      if constexpr (C2MODE != 0) {
+        if (ok) *reinterpret_cast<uint4*>((bf16_t*)e.C2 + zoff + m * e.ldc2 + n) = make_uint4(pack_bf16x2(d[0]), pack_bf16x2(d[1]), pack_bf16x2(d[2]), pack_bf16x2(d[3]));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[i] = x[i] * s2[i];
+      if constexpr (RES == 1) {
+        x[0] += f32x2{res[2 * p].x, res[2 * p].y}, x[1] += f32x2{res[2 * p].z, res[2 * p].w};
+        x[2] += f32x2{res[2 * p + 1].x, res[2 * p + 1].y}, x[3] += f32x2{res[2 * p + 1].z, res[2 * p + 1].w};
+      }
+      if constexpr (RES == 2) {
+        x[0] += unpack_bf16x2(resh[p].x), x[1] += unpack_bf16x2(resh[p].y), x[2] += unpack_bf16x2(resh[p].z), x[3] += unpack_bf16x2(resh[p].w);
+      }
+      if (ok) {
+        const long o = zoff + m * e.ldc + n;
+        if constexpr (CDT == VFM_BF16) {
+          *reinterpret_cast<uint4*>((bf16_t*)e.C + o) = make_uint4(pack_bf16x2(x[0]), pack_bf16x2(x[1]), pack_bf16x2(x[2]), pack_bf16x2(x[3]));
+        } else {
+          float* cp = (float*)e.C + o;
+          *reinterpret_cast<float4*>(cp) = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
+          *reinterpret_cast<float4*>(cp + 4) = make_float4(x[2].x, x[2].y, x[3].x, x[3].y);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  };
+  group(IC<0>{});
+  if constexpr (NG > 1) group(IC<1>{});
+  if constexpr (NG > 2) group(IC<2>{});
+  if constexpr (NG > 3) group(IC<3>{});
+}
+
 // any other combination: compact (rolled) pass loop around the generic epi_store4
 template <int MI, int NI, int GROUP>
 __device__ __forceinline__ void epi_generic(const EpiParams& e, long zoff, f32x16 (&acc)[MI][NI], float* img, int lane, long m_base,
@@ -267,27 +448,46 @@ __device__ __forceinline__ void epi_generic(const EpiParams& e, long zoff, f32x1
 }
 
 // wave-uniform selection of the epilogue instance
+__device__ __forceinline__ bool epi_vec8_ok(const EpiParams& e, long zoff, long N) {
+  auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  bool ok = (N % 8 == 0) && (e.ldc % 8 == 0) && (zoff % 8 == 0) && a16(e.C) && (!e.bias || e.bias_mod % 8 == 0);
+  if (e.C2) ok = ok && e.c2_dt == VFM_BF16 && a16(e.C2) && (e.ldc2 % 8 == 0);
+  if (e.aux) ok = ok && e.aux_dt == VFM_BF16 && a16(e.aux) && (e.ld_aux % 8 == 0);
+  if (e.residual) ok = ok && a16(e.residual) && (e.ldr % 8 == 0);
+  return ok;
+}
+
 template <int MI, int NI, int GROUP>
 __device__ __forceinline__ void epi_wave_tile(const EpiParams& e, long zoff, f32x16 (&acc)[MI][NI], float* img, int lane, long m_base,
                                               long n_base, long M, long N) {
   const int mode = e.ep_mode;
   const bool plain = !e.C2 && !e.residual;
+  if (epi_vec8_ok(e, zoff, N)) {   // eight columns per lane, packed arithmetic: every shape of the four backbones
+    if (mode == VFM_EP_NONE && plain && e.c_dt == VFM_BF16)
+      return epi_fast8<VFM_EP_NONE, VFM_BF16, 0, 0, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+    if (mode == VFM_EP_NONE && !e.C2 && e.residual && e.r_dt == VFM_F32 && e.c_dt == VFM_F32)
+      return epi_fast8<VFM_EP_NONE, VFM_F32, 1, 0, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+    if (mode == VFM_EP_GELU_DGELU && e.C2 && !e.residual && e.c_dt == VFM_BF16)
+      return epi_fast8<VFM_EP_GELU, VFM_BF16, 0, 2, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+    if (mode == VFM_EP_GELU && e.C2 && !e.residual && e.c_dt == VFM_BF16)
+      return epi_fast8<VFM_EP_GELU, VFM_BF16, 0, 1, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+    if (mode == VFM_EP_GELU && plain && e.c_dt == VFM_BF16)
+      return epi_fast8<VFM_EP_GELU, VFM_BF16, 0, 0, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+    if (mode == VFM_EP_MUL && plain && e.c_dt == VFM_BF16)
+      return epi_fast8<VFM_EP_MUL, VFM_BF16, 0, 0, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+    if (mode == VFM_EP_MUL_GELU_GRAD && plain && e.c_dt == VFM_BF16)
+      return epi_fast8<VFM_EP_MUL_GELU_GRAD, VFM_BF16, 0, 0, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+    if (mode == VFM_EP_MUL && !e.C2 && e.residual && e.r_dt == VFM_BF16 && e.c_dt == VFM_BF16)
+      return epi_fast8<VFM_EP_MUL, VFM_BF16, 2, 0, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);  // LoRA: dx += mask * (dT A)
+    if (mode == VFM_EP_NONE && !e.C2 && e.residual && e.r_dt == VFM_BF16 && e.c_dt == VFM_BF16)
+      return epi_fast8<VFM_EP_NONE, VFM_BF16, 2, 0, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+  }
   if (mode == VFM_EP_NONE && plain && e.c_dt == VFM_BF16)
     epi_fast<VFM_EP_NONE, VFM_BF16, 0, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
   else if (mode == VFM_EP_NONE && plain && e.c_dt == VFM_F32)
     epi_fast<VFM_EP_NONE, VFM_F32, 0, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
   else if (mode == VFM_EP_NONE && !e.C2 && e.residual && e.r_dt == VFM_F32 && e.c_dt == VFM_F32)
     epi_fast<VFM_EP_NONE, VFM_F32, 1, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
-  else if (mode == VFM_EP_GELU && e.C2 && e.c2_dt == VFM_BF16 && !e.residual && e.c_dt == VFM_BF16)
-    epi_fast<VFM_EP_GELU, VFM_BF16, 0, true, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
-  else if (mode == VFM_EP_GELU && plain && e.c_dt == VFM_BF16)  // inference: no pre-activation copy
-    epi_fast<VFM_EP_GELU, VFM_BF16, 0, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
-  else if (mode == VFM_EP_MUL_GELU_GRAD && e.aux_dt == VFM_BF16 && plain && e.c_dt == VFM_BF16)
-    epi_fast<VFM_EP_MUL_GELU_GRAD, VFM_BF16, 0, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
-  else if (mode == VFM_EP_MUL && e.aux_dt == VFM_BF16 && !e.C2 && e.residual && e.r_dt == VFM_BF16 && e.c_dt == VFM_BF16)
-    epi_fast<VFM_EP_MUL, VFM_BF16, 2, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);  // LoRA: dx += mask * (dT A)
-  else if (mode == VFM_EP_NONE && !e.C2 && e.residual && e.r_dt == VFM_BF16 && e.c_dt == VFM_BF16)
-    epi_fast<VFM_EP_NONE, VFM_BF16, 2, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
   else if (mode == VFM_EP_QGELU && e.C2 && e.c2_dt == VFM_BF16 && !e.residual && e.c_dt == VFM_BF16)
     epi_fast<VFM_EP_QGELU, VFM_BF16, 0, true, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
   else if (mode == VFM_EP_MUL_QGELU_GRAD && e.aux_dt == VFM_BF16 && plain && e.c_dt == VFM_BF16)

@@ -28,9 +28,10 @@ static inline EpiParams make_epi(const vfm_gemm_desc* d) {
 __device__ __forceinline__ void epi_store(const EpiParams& e, long zoff, long m, long n, float acc) {
   float v = e.alpha * acc;
   if (e.bias) v += e.bias[n % e.bias_mod];
-  if (e.C2) st_any(e.C2, zoff + m * e.ldc2 + n, e.c2_dt, v);
+  if (e.C2) st_any(e.C2, zoff + m * e.ldc2 + n, e.c2_dt, e.ep_mode == VFM_EP_GELU_DGELU ? gelu_grad_f(v) : v);
   switch (e.ep_mode) {
-    case VFM_EP_GELU: v = gelu_f(v); break;
+    case VFM_EP_GELU:
+    case VFM_EP_GELU_DGELU: v = gelu_f(v); break;
     case VFM_EP_RELU: v = fmaxf(v, 0.f); break;
     case VFM_EP_MUL_GELU_GRAD: v *= gelu_grad_f(ld_any(e.aux, m * e.ld_aux + n, e.aux_dt)); break;
     case VFM_EP_MUL: v *= ld_any(e.aux, m * e.ld_aux + n, e.aux_dt); break;

@@ -208,6 +208,19 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   // ---- epilogue (accumulators -> per-wave fp32 LDS image -> 16-byte rows), one 64-row half of the wave tile at a time
   const long zoff = z * stride_c;
   if constexpr (DBG & 1) return;
+  if constexpr (DBG & 4) {   // diagnostic: no epilogue, but the accumulators stay live (the MFMAs are not dead code)
+#pragma unroll
+    for (int h = 0; h < MI / 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (a "v" constraint does not exist for the host pass: the instantiation would silently vanish)
+          asm volatile("" ::"v"(acc[h][i][j]));
+#endif
+        }
+    return;
+  }
   __syncthreads();
   float* img = reinterpret_cast<float*>(smem) + wave * 64 * (NI * 32 + 4);
   const long mw = m0 + wm * MI * 32, nw = n0 + wn * NI * 32;
@@ -249,10 +262,14 @@ bool vfm_gemm_launch_w4(const vfm_gemm_desc* d, hipStream_t s, bool vec, const v
   }
   if (form == 8) {
     if (!vec) return launch_w4_t<false, 4, 2, 2, 4, 2, 0>(d, s, tail);
+    if (g_pp_dbg == 4) return launch_w4_t<true, 4, 2, 2, 4, 2, 4>(d, s, tail);
     return g_pp_dbg == 1 ? launch_w4_t<true, 4, 2, 2, 4, 2, 1>(d, s, tail) : launch_w4_t<true, 4, 2, 2, 4, 2, 0>(d, s, tail);
   }
   if (form == 5) return vec ? launch_w4_t<true, 2, 1, 2, 4, 4, 0>(d, s, tail) : launch_w4_t<false, 2, 1, 2, 4, 4, 0>(d, s, tail);
   if (form == 3) return vec ? launch_w4_t<true, 2, 1, 2, 4, 3, 0>(d, s, tail) : launch_w4_t<false, 2, 1, 2, 4, 3, 0>(d, s, tail);
   if (!vec) return launch_w4_t<false, 2, 1, 2, 4, 2, 0>(d, s, tail);
+  if (g_pp_dbg == 1) return launch_w4_t<true, 2, 1, 2, 4, 2, 1>(d, s, tail);   // diagnostic: no epilogue => the MFMAs are dead code too:
+                                                                               // what is left is the operand stream (DMA + barriers)
+  if (g_pp_dbg == 4) return launch_w4_t<true, 2, 1, 2, 4, 2, 4>(d, s, tail);   // diagnostic: main loop only (MFMAs live), no epilogue
   return launch_w4_t<true, 2, 1, 2, 4, 2, 0>(d, s, tail);
 }

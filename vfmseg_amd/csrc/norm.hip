@@ -334,11 +334,13 @@ __global__ void k_ln_bwd_fin(const float* __restrict__ ws, int parts, int C, flo
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
   float a = 0.f, b = 0.f;
-  if (c < C)
+  if (c < C) {
+#pragma unroll 8   // independent loads in flight: a rolled loop is a chain of round trips (10 us per call)
     for (int p = ty; p < parts; p += 4) {
       a += ws[((long)p * 2 + 0) * C + c];
       b += ws[((long)p * 2 + 1) * C + c];
     }
+  }
   sh[0][ty][tx] = a, sh[1][ty][tx] = b;
   __syncthreads();
   if (ty == 0 && c < C) {
@@ -614,11 +616,13 @@ __global__ void k_chan_fin_wb(const float* __restrict__ ws, int slots, int C, fl
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
   float a = 0.f, b = 0.f;
-  if (c < C)
+  if (c < C) {
+#pragma unroll 8
     for (int k = ty; k < slots; k += 4) {
       b += ws[((long)k * 2 + 0) * C + c];
       a += ws[((long)k * 2 + 1) * C + c];
     }
+  }
   sh[0][ty][tx] = a, sh[1][ty][tx] = b;
   __syncthreads();
   if (ty == 0 && c < C) {
@@ -671,16 +675,26 @@ extern "C" int vfm_groupnorm_bwd(const void* dy, int dy_dt, const float* x, cons
 }
 
 // =============================================================================================== BatchNorm
-__global__ void k_bn_fin_sums(const float* __restrict__ ws, int slots, int C, float* __restrict__ sums) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ void __launch_bounds__(256) k_bn_fin_sums(const float* __restrict__ ws, int slots, int C, float* __restrict__ sums) {
+  // 64 channels x 4 slot groups per block, fixed combination order (the one-thread-per-channel walk over all slots was a chain of
+  // dependent loads: 17 us per call)
+  __shared__ double sh[2][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
   double a = 0.0, b = 0.0;
-  for (int k = 0; k < slots; ++k) {
-    a += ws[((long)k * 2 + 0) * C + c];
-    b += ws[((long)k * 2 + 1) * C + c];
+  if (c < C) {
+#pragma unroll 8
+    for (int k = ty; k < slots; k += 4) {
+      a += ws[((long)k * 2 + 0) * C + c];
+      b += ws[((long)k * 2 + 1) * C + c];
+    }
   }
-  sums[c] = (float)a;
-  sums[C + c] = (float)b;
+  sh[0][ty][tx] = a, sh[1][ty][tx] = b;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    sums[c] = (float)((sh[0][0][tx] + sh[0][1][tx]) + (sh[0][2][tx] + sh[0][3][tx]));
+    sums[C + c] = (float)((sh[1][0][tx] + sh[1][1][tx]) + (sh[1][2][tx] + sh[1][3][tx]));
+  }
 }
 extern "C" int vfm_bn_moments(const float* x, long rows, long C, float* sums, float* ws, void* stream) {
   VFM_CHECK(ws && sums, VFM_E_INVAL, "vfm_bn_moments: args");
@@ -689,7 +703,7 @@ extern "C" int vfm_bn_moments(const float* x, long rows, long C, float* sums, fl
   const int rpc = (int)((rows + nchunk - 1) / nchunk);
   hipLaunchKernelGGL((k_chan_moments<0, float>), dim3(cdiv(C, 64), nchunk, 1), dim3(256), 0, s, x, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0.f, 0, ws, rows, (int)C, rpc);
-  hipLaunchKernelGGL(k_bn_fin_sums, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, nchunk, (int)C, sums);
+  hipLaunchKernelGGL(k_bn_fin_sums, dim3(cdiv(C, 64)), dim3(256), 0, s, ws, nchunk, (int)C, sums);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }
@@ -747,7 +761,7 @@ extern "C" int vfm_bn_bwd_reduce(const void* dy, int dy_dt, const float* x, cons
   else if (dy_dt == VFM_F32)
     hipLaunchKernelGGL((k_chan_moments<1, float>), grid, dim3(256), 0, s, x, (const float*)dy, w, b, mean_var, 0, eps, act, ws, rows, (int)C, rpc);
   else VFM_FAIL(VFM_E_INVAL, "vfm_bn_bwd_reduce: dtype");
-  hipLaunchKernelGGL(k_bn_fin_sums, dim3(cdiv(C, 256)), dim3(256), 0, s, ws, nchunk, (int)C, sums_dy);
+  hipLaunchKernelGGL(k_bn_fin_sums, dim3(cdiv(C, 64)), dim3(256), 0, s, ws, nchunk, (int)C, sums_dy);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }

@@ -96,11 +96,9 @@ class BaseDecodeHead(nn.Module):
     # ---- shared loss path (linear_head.py:72-113 / VFMHead.py:91-133)
     def _loss_from_lowres(self, logits_nhwc, seg_label, return_logits):
         label = seg_label.squeeze(1).contiguous()
-        loss, counts = Fh.UpsampleCEFn.apply(logits_nhwc, label, self.ignore_index, self.loss_decode.loss_weight)
-        losses = {self.loss_decode.loss_name: loss}
-        eps = torch.finfo(torch.float32).eps
-        c = counts.float()
-        losses["acc_seg"] = (c[0] * (100.0 / (c[1] + eps))).reshape(1)
+        # loss and accuracy (mmseg `accuracy`: 100 * correct / (valid + eps)) come out of the fused kernel pair
+        loss, acc = Fh.UpsampleCEFn.apply(logits_nhwc, label, self.ignore_index, self.loss_decode.loss_weight)
+        losses = {self.loss_decode.loss_name: loss, "acc_seg": acc}
         if return_logits:
             B, h, w, C = logits_nhwc.shape
             H, W = label.shape[1:]

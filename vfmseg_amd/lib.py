@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvfmseg_hip.so")
 
 F32, BF16, U8, I64 = 0, 1, 2, 3
-EP_NONE, EP_GELU, EP_RELU, EP_MUL_GELU_GRAD, EP_MUL, EP_QGELU, EP_MUL_QGELU_GRAD = 0, 1, 2, 3, 4, 5, 6
+EP_NONE, EP_GELU, EP_RELU, EP_MUL_GELU_GRAD, EP_MUL, EP_QGELU, EP_MUL_QGELU_GRAD, EP_GELU_DGELU = 0, 1, 2, 3, 4, 5, 6, 7
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_QGELU = 0, 1, 2, 3
 
 vp, ci, cl, cf, u64 = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint64
@@ -51,6 +51,7 @@ SIGNATURES = {
     "vfm_cast": [vp, ci, cl, vp, ci, cl, cl, cl, vp, vp],
     "vfm_transpose": [vp, ci, cl, vp, ci, cl, cl, cl, cl, vp],
     "vfm_strided_copy": [vp, ci, vp, ci] + [cl] * 12 + [ci, vp],
+    "vfm_strided_copy_batch": [vp, ci, cl, vp],
     "vfm_axpby": [vp, cf, vp, cf, cl, vp],
     "vfm_scale_by_device_scalar": [vp, vp, cl, vp],
     "vfm_colsum": [vp, ci, cl, cl, cl, vp, ci, vp, vp],
@@ -98,11 +99,12 @@ SIGNATURES = {
     "vfm_unblock": [vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "vfm_upsample_ce": [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp],
     "vfm_reduce_sum": [vp, cl, cf, vp, vp],
+    "vfm_ce_finish": [vp, cl, cf, vp, cf, vp, vp, vp],
     "vfm_conf_gate": [vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, vp],
     "vfm_slide_accumulate": [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "vfm_slide_finalize": [vp, vp, vp, ci, ci, ci, ci, vp],
     "vfm_confusion_hist": [vp, vp, ci, cl, ci, ci, vp, vp],
-    "vfm_adamw": [vp, vp, vp, vp, cl, vp, vp, vp, ci, cf, cf, cf, cf, ci, cf, vp],
+    "vfm_adamw": [vp, vp, vp, vp, cl, vp, vp, vp, ci, cf, cf, cf, cf, ci, cf, ci, ci, vp],
 }
 
 _lib = None

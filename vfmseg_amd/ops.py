@@ -7,8 +7,8 @@ import ctypes as C
 import torch
 
 from . import lib as L
-from .lib import (ACT_GELU, ACT_NONE, ACT_QGELU, ACT_RELU, BF16, EP_GELU, EP_MUL, EP_MUL_GELU_GRAD, EP_MUL_QGELU_GRAD,  # noqa: F401
-                  EP_NONE, EP_QGELU, EP_RELU, F32)
+from .lib import (ACT_GELU, ACT_NONE, ACT_QGELU, ACT_RELU, BF16, EP_GELU, EP_GELU_DGELU, EP_MUL, EP_MUL_GELU_GRAD,  # noqa: F401
+                  EP_MUL_QGELU_GRAD, EP_NONE, EP_QGELU, EP_RELU, F32)
 
 _ws_cache = {}
 
@@ -93,6 +93,32 @@ def strided_copy(src, dst, shape, sstr, dstr, accumulate=False):
     L.check(lib.vfm_strided_copy(L.ptr(src), L.dt_of(src), L.ptr(dst), L.dt_of(dst), *n, *s, *d, int(accumulate), L.stream()),
             "vfm_strided_copy")
     return dst
+
+
+class CopyBatch:
+    """Device table for vfm_strided_copy_batch: jobs = [(src fp32 tensor, dst tensor, shape, src strides, dst strides)], each
+    up to 4-D; run() performs all of them in one launch.  The tensors are kept alive by the table."""
+
+    def __init__(self, jobs):
+        import struct
+        buf = bytearray()
+        self.keep, self.max_elems, self.n = [], 0, len(jobs)
+        for (src, dst, shape, sstr, dstr) in jobs:
+            assert src.dtype == torch.float32 and src.is_cuda and dst.is_cuda
+            k = 4 - len(shape)
+            n, s_, d_ = [1] * k + list(shape), [0] * k + list(sstr), [0] * k + list(dstr)
+            buf += struct.pack("2Q13q", src.data_ptr(), dst.data_ptr(), L.dt_of(dst), *n, *s_, *d_)
+            self.keep += [src, dst]
+            e = 1
+            for v in shape:
+                e *= v
+            self.max_elems = max(self.max_elems, e)
+        self.table = torch.frombuffer(buf, dtype=torch.uint8).clone().to(jobs[0][1].device) if jobs else None
+
+    def run(self):
+        if self.n:
+            lib = L.load()
+            L.check(lib.vfm_strided_copy_batch(L.ptr(self.table), self.n, self.max_elems, L.stream()), "vfm_strided_copy_batch")
 
 
 def permute_copy(src, perm, dst):
@@ -622,6 +648,31 @@ def upsample_ce(logits_low, label, ignore_index=255, need_grad=True):
     return loss, counts, dl
 
 
+_ce_counts = {}
+
+
+def upsample_ce_loss_acc(logits_low, label, ignore_index=255, need_grad=True):
+    """The training form of upsample_ce: returns (loss[1], acc[1], dlogits) with the loss / accuracy finished by ONE launch and
+    a persistent, self-resetting counter pair per device (zeroed once)."""
+    lib = L.load()
+    B, h, w, Cc = logits_low.shape
+    _, H, W = label.shape
+    dev = logits_low.device
+    counts = _ce_counts.get(dev)
+    if counts is None:
+        counts = _ce_counts[dev] = torch.zeros(2, dtype=torch.int32, device=dev)
+    parts = torch.empty(B * h * w, dtype=torch.float32, device=dev)
+    dl = torch.empty_like(logits_low) if need_grad else None
+    assert logits_low.is_contiguous() and label.is_contiguous() and label.dtype == torch.int64
+    L.check(lib.vfm_upsample_ce(L.ptr(logits_low), L.ptr(label), B, h, w, Cc, H, W, ignore_index, L.ptr(parts), L.ptr(counts),
+                                L.ptr(dl), L.stream()), "vfm_upsample_ce")
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    eps = float(torch.finfo(torch.float32).eps)
+    L.check(lib.vfm_ce_finish(L.ptr(parts), parts.numel(), 1.0 / (B * H * W), L.ptr(counts), eps, L.ptr(out), L.ptr(out[1:]), L.stream()),
+            "vfm_ce_finish")
+    return out[0:1], out[1:2], dl
+
+
 def preprocess_u8(img_u8, out, mean, std, bgr_to_rgb, pad_val=0.0):
     """img_u8 uint8 [3,H,W] (cuda) -> out fp32 [3,Hp,Wp]: channel swap, normalise, pad (mmseg SegDataPreProcessor)."""
     lib = L.load()
@@ -668,8 +719,8 @@ def confusion_hist(pred_u8, label, hist, num_classes, ignore_index=255):
     return hist
 
 
-def adamw(p, g, m, v, seg_start, seg_lr_mult, seg_wd, lr, betas, eps, step, grad_scale=1.0):
+def adamw(p, g, m, v, seg_start, seg_lr_mult, seg_wd, lr, betas, eps, step, grad_scale=1.0, zero_grad=False, vec4=False):
     lib = L.load()
     L.check(lib.vfm_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(seg_start), L.ptr(seg_lr_mult),
                           L.ptr(seg_wd), seg_start.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), int(step),
-                          float(grad_scale), L.stream()), "vfm_adamw")
+                          float(grad_scale), int(bool(zero_grad)), int(bool(vec4)), L.stream()), "vfm_adamw")

@@ -131,16 +131,20 @@ class FusedAdamW:
             cuts[-1][2] = a + dict(zip(self.names, [p.numel() for p in self.params]))[nm]
         return [tuple(c) for c in cuts]
 
-    def step(self, lr=None, grad_scale=1.0):
+    def step(self, lr=None, grad_scale=1.0, zero_grad=False):
+        """zero_grad=True clears the flat gradient buffer in the same pass (OptimWrapper.update_params: step, then zero_grad)."""
         self.step_count += 1
         PARAM_EPOCH[0] += 1  # the fused kernel rewrites the parameters behind torch's version counters
         lr = self.lr if lr is None else lr
         self.param_groups[0]["lr"] = lr
         ops.adamw(self.flat, self.gflat, self.m, self.v, self.seg_start, self.seg_lr, self.seg_wd, lr, self.betas, self.eps,
-                  self.step_count, grad_scale)
+                  self.step_count, grad_scale, zero_grad=zero_grad, vec4=True)   # offsets are multiples of 16 floats
+        self._grads_cleared = bool(zero_grad)
 
     def zero_grad(self):
-        self.gflat.zero_()
+        if not getattr(self, "_grads_cleared", False):
+            self.gflat.zero_()
+        self._grads_cleared = False
         for p, a, sz in zip(self.params, self.offsets[:-1], self.sizes):
             if p.grad is None or p.grad.data_ptr() != self.gflat.data_ptr() + a * 4:
                 p.grad = self.gflat[a:a + sz].view(p.shape)
@@ -169,7 +173,7 @@ class OptimWrapper:
         if self.grad_sync is not None:
             self.grad_sync()
         lr = self.scheduler.lr(self.iter) if self.scheduler is not None else None
-        self.optimizer.step(lr, grad_scale=getattr(self.grad_sync, "post_scale", 1.0))
+        self.optimizer.step(lr, grad_scale=getattr(self.grad_sync, "post_scale", 1.0), zero_grad=True)
         self.optimizer.zero_grad()
         self.iter += 1
 

@@ -278,7 +278,8 @@ class SamEngine:
             hid = Lp["fc1"].n
             g = ops.empty_ld(M, hid, cd, dev)
             hpre = torch.empty(M, hid, dtype=cd, device=dev) if keep else None
-            Lp["fc1"].fwd(a2, g, bias=Lp["fc1_b"], ep_mode=ops.EP_GELU, c2=hpre)
+            # training also saves gelu'(pre-activation): what fc2's dgrad multiplies by
+            Lp["fc1"].fwd(a2, g, bias=Lp["fc1_b"], ep_mode=ops.EP_GELU_DGELU if keep else ops.EP_GELU, c2=hpre)
             xo = torch.empty(M, D, dtype=torch.float32, device=dev)
             Lp["fc2"].fwd(g, xo, bias=Lp["fc2_b"], residual=xm)
             if keep:
@@ -312,7 +313,7 @@ class SamEngine:
             ops.cast(dx, t)
             hid = Lp["fc1"].n
             dh = ops.empty_ld(M, hid, cd, dev)
-            Lp["fc2"].dgrad(t, dh, ep_mode=ops.EP_MUL_GELU_GRAD, aux=S_["hpre"])
+            Lp["fc2"].dgrad(t, dh, ep_mode=ops.EP_MUL, aux=S_["hpre"])
             dn = torch.empty(M, D, dtype=cd, device=dev)
             Lp["fc1"].dgrad(dh, dn)
             ops.layernorm_bwd(dn, S_["x_mid"], Lp["n2w"], S_["st2"], dx, accumulate_dx=True)
