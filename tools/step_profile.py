@@ -12,7 +12,7 @@ import sys
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_adamw")]
+    idx = [i for i, r in enumerate(rows) if "k_adamw" in r["Kernel_Name"]]
     if len(idx) >= 2:
         step = rows[idx[-2] + 1:idx[-1] + 1]
     else:

@@ -243,23 +243,25 @@ extern "C" int vfm_slab_reduce(const float* slabs, int kch, long P, long Q, long
 // ------------------------------------------------------------------------------------------------ batched strided copy
 // One launch for a whole TABLE of 4-D strided fp32 -> (bf16 | fp32) copies (blockIdx.y = entry): the per-step re-pack of every
 // trainable decoder weight into its GEMM operand layout (39 single launches + zero fills per train step before).
-__global__ void k_strided_copy_batch(const vfm_copy_job* __restrict__ tab) {
+__global__ void __launch_bounds__(256) k_strided_copy_batch(const vfm_copy_job* __restrict__ tab) {
   const vfm_copy_job t = tab[blockIdx.y];
-  const long total = t.n[0] * t.n[1] * t.n[2] * t.n[3];
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    long r = i;
-    const long i3 = r % t.n[3]; r /= t.n[3];
-    const long i2 = r % t.n[2]; r /= t.n[2];
-    const long i1 = r % t.n[1]; r /= t.n[1];
-    const float v = t.src[r * t.s[0] + i1 * t.s[1] + i2 * t.s[2] + i3 * t.s[3]];
-    st_any(t.dst, r * t.d[0] + i1 * t.d[1] + i2 * t.d[2] + i3 * t.d[3], t.dst_dt, v);
+  const unsigned n1 = (unsigned)t.n[1], n2 = (unsigned)t.n[2], n3 = (unsigned)t.n[3];
+  const unsigned total = (unsigned)t.n[0] * n1 * n2 * n3;   // < 2^31 elements per job (checked on the host side of the table)
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    unsigned r = i;
+    const unsigned i3 = r % n3; r /= n3;
+    const unsigned i2 = r % n2; r /= n2;
+    const unsigned i1 = r % n1; r /= n1;
+    const float v = t.src[(long)r * t.s[0] + (long)i1 * t.s[1] + (long)i2 * t.s[2] + (long)i3 * t.s[3]];
+    st_any(t.dst, (long)r * t.d[0] + (long)i1 * t.d[1] + (long)i2 * t.d[2] + (long)i3 * t.d[3], (int)t.dst_dt, v);
   }
 }
 extern "C" int vfm_strided_copy_batch(const vfm_copy_job* table_dev, int njobs, long max_elems, void* stream) {
   VFM_CHECK(table_dev && njobs >= 0, VFM_E_INVAL, "vfm_strided_copy_batch: bad args");
   if (njobs == 0 || max_elems <= 0) return VFM_OK;
-  int gx = (int)((max_elems + 1023) / 1024);   // >= 4 elements per thread
-  if (gx > 64) gx = 64;
+  VFM_CHECK(max_elems < (1l << 31), VFM_E_SHAPE, "vfm_strided_copy_batch: jobs are limited to 2^31 elements");
+  int gx = (int)((max_elems + 2047) / 2048);   // ~8 elements per thread of the largest job; smaller jobs' surplus blocks exit at once
+  if (gx > 2048) gx = 2048;
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL(k_strided_copy_batch, dim3(gx, njobs), dim3(256), 0, (hipStream_t)stream, table_dev);
   VFM_LAUNCH_CHECK();
