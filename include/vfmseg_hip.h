@@ -225,6 +225,13 @@ int vfm_softmax_rows_bwd(const void* p, const float* dp, long ld_dp, void* ds, i
 int vfm_sam_attn_bwd_merge(const void* dqa, const void* dkT, const void* dvT, int dt, const float* rh, const float* rw, void* dqkv,
                            long ld, int nimg, int G, int S, int H, int d, int dp, int NP, int Dq, float scale, void* stream);
 
+/* Flash-style forward of the same attention (inference; head dim 80 = SAM ViT-H): token-major qkv [nimg*G*G, 3*H*d] -> token-major
+ * out [nimg*G*G, H*d] in ONE launch - windows of S = 14 on the zero-padded grid (padded tokens: k / v = projection bias) or global
+ * attention (S = G = 32).  tbl_h / tbl_w: bf16 [2*SP, d] (SP = 16 for S = 14, 32 for S = 32) relative-index tables,
+ * tbl[j] = rel_pos(re-interpolated)[j] = Rh[qh, kh] for qh - kh + S - 1 = j, rows >= 2S-1 zero.  No score matrix in memory. */
+int vfm_sam_attn_flash_fwd(const void* qkv, long ld, const float* bias, const void* tbl_h, const void* tbl_w, void* out, long ldo,
+                           int nimg, int G, int S, int H, int d, float scale, void* stream);
+
 /* ---- ViT input / output ------------------------------------------------------------------------ */
 /* im2col of non-overlapping PxP patches (patch_embed.py:65-77): img fp32 NCHW [B,3,H,W] (crop window y0,x0,
  * row/plane strides in elements) -> A [B*(h/P)*(w/P), 3*P*P] in out_dt, k = c*P*P + py*P + px (conv weight order) */

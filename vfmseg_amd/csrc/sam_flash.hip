@@ -1,0 +1,343 @@
+// Flash-style SAM attention forward for gfx950 (head dim 80): windowed (14 x 14 windows of the zero-padded grid) and global
+// attention with the decomposed relative-position bias, straight from the token-major qkv matrix to the token-major output.
+// Reference: rein/models/backbones/sam_vit.py:273-298 (Attention.forward), :301-356 (window partition / unpartition),
+// :359-430 (get_rel_pos, add_decomposed_rel_pos).  Replaces, for inference, the materialised form of sam.hip (prep -> batched
+// score GEMM -> fp32 score matrix -> row softmax -> P V GEMM -> merge: six launches and ~0.4 GB of traffic per layer).
+//
+//   score[q, k] = scale * q.k + q.Rh[qh, kh] + q.Rw[qw, kw],      Rh[qh, kh] = tbl_h[qh - kh + S - 1]  (relative-index table)
+//
+// * The bias needs only T_h = Q tbl_h^T and T_w = Q tbl_w^T  ([queries x (2S-1)], two small MFMA products per wave, K = 80):
+//   Bh[q, kh] = T_h[q, qh(q) - kh + S - 1].  Each lane gathers its query's S + S values once (through a wave-private LDS image).
+// * It then enters the scores through the MFMA itself: the query operand is extended to [q | Bh[q,:]/scale | Bw[q,:]/scale] and the
+//   key tile in LDS to [k | onehot(kh) | onehot(kw)] (the one-hot columns are written by the tile loader from the key index), so
+//   the biased score is one dot product of length 80 + 2 SP and the softmax loop carries no per-score gathers.
+// * One wave owns 32 queries on the MFMA lane index (S^T = K Q^T, O^T += V^T P^T; P never leaves registers), as in attention_bf16.hip;
+//   K / V tiles of 64 keys are staged global -> registers -> LDS (rows are 160 B: no whole-line LDS-DMA shape), double buffered,
+//   one barrier per tile.  Window tokens outside the image are real keys whose k / v equal the projection bias (window_partition
+//   pads the NORMALISED input with zeros); queries outside the image are computed and dropped (window_unpartition).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define SF_D 80
+#define SF_LOG2E 1.4426950408889634f
+#define SF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+struct SamFlashP {
+  const bf16_t* qkv; long ld;        // token-major [nimg*G*G, 3*H*80]
+  const float* bias;                 // [3*H*80] projection bias (qkv of the padded window tokens), may be null
+  const bf16_t* tbl_h; const bf16_t* tbl_w;  // [JP, 80] relative-index tables (rows >= 2S-1 zero)
+  bf16_t* out; long ldo;             // token-major [nimg*G*G, H*80]
+  int nimg, G, H, nws;               // nws windows per side (1 for global)
+  float scale;
+};
+
+template <int S>
+struct SamFlashCfg {
+  static constexpr int NW = S == 14 ? 7 : 4;          // waves per block: 224 (>= 196) or 128 queries
+  static constexpr int NT = NW * 64;
+  static constexpr int NWIN = S * S;                   // tokens per window
+  static constexpr int QBLK = (NWIN + NW * 32 - 1) / (NW * 32);
+  static constexpr int SP = S <= 16 ? 16 : 32;         // one-hot columns per axis
+  static constexpr int JP = 2 * SP;                    // padded rows of the relative-index tables (>= 2S-1)
+  static constexpr int KSTEPS = (SF_D + 2 * SP) / 16;  // 7 / 9 k-steps of the extended score product
+  static constexpr int KS = S == 14 ? 240 : 304;       // bytes per row of the K tile (160 + 4 SP, padded so that 16 rows hit 16 slots)
+  static constexpr int VS = 192;                       // bytes per row of the V tile (96 columns, 80..95 zero)
+  static constexpr int TS = 176;                       // bytes per row of the table image
+  static constexpr int TILE = 64 * (KS + VS);
+  static constexpr int NTILES = (NWIN + 63) / 64;
+  static constexpr int TH_BYTES = NW * 2 * JP * 32 * 4;  // per-wave T_h^T / T_w^T images [JP][32 queries] fp32
+  static constexpr int SMEM = 2 * TILE + TH_BYTES;
+};
+
+__device__ __forceinline__ int sf_acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ f32x16 sf_zero() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+__device__ __forceinline__ uint32_t sf_pack2(float a, float b) {
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const b2 v = __builtin_convertvector(f2{a, b}, b2);
+  return *reinterpret_cast<const uint32_t*>(&v);
+}
+
+template <int S>
+__global__ void __launch_bounds__(SamFlashCfg<S>::NT) k_sam_flash_fwd(SamFlashP p) {
+  using C = SamFlashCfg<S>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, h = lane >> 5;
+  // block -> (image, window, head, query block)
+  int bid = blockIdx.x;
+  const int qb = bid % C::QBLK; bid /= C::QBLK;
+  const int head = bid % p.H; bid /= p.H;
+  const int wx = bid % p.nws; bid /= p.nws;
+  const int wy = bid % p.nws;
+  const int img = bid / p.nws;
+  const int G = p.G, Cq = p.H * SF_D;
+  auto tok_row = [&](int t, bool& inside) -> long {   // window token index -> row of the token-major matrices
+    const int ty = t / S, tx = t - ty * S;
+    const int gy = wy * S + ty, gx = wx * S + tx;
+    inside = gy < G && gx < G;
+    return ((long)img * G + gy) * G + gx;
+  };
+  // one 16-byte piece (8 columns from column c8) of section sec (0 q, 1 k, 2 v) of window token t
+  auto load_piece = [&](int sec, int t, int c8) -> uint4 {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (t < C::NWIN) {
+      bool inside;
+      const long row = tok_row(t, inside);
+      const int col = sec * Cq + head * SF_D + c8;
+      if (inside) {
+        v = *reinterpret_cast<const uint4*>(p.qkv + row * p.ld + col);
+      } else if (p.bias) {
+        const float4 a = *reinterpret_cast<const float4*>(p.bias + col), b = *reinterpret_cast<const float4*>(p.bias + col + 4);
+        v = make_uint4(sf_pack2(a.x, a.y), sf_pack2(a.z, a.w), sf_pack2(b.x, b.y), sf_pack2(b.z, b.w));
+      }
+    }
+    return v;
+  };
+
+  // ---- prologue 1: the table images (aliased with K/V stage 1) and this wave's query fragments
+  char* timg = smem + C::TILE;                       // [2][JP rows][176 B]
+  for (int pc = tid; pc < 2 * C::JP * 10; pc += C::NT) {
+    const int which = pc / (C::JP * 10), rem = pc - which * (C::JP * 10), row = rem / 10, c = rem - row * 10;
+    const bf16_t* src = which ? p.tbl_w : p.tbl_h;
+    *reinterpret_cast<uint4*>(timg + (which * C::JP + row) * C::TS + c * 16) = *reinterpret_cast<const uint4*>(src + row * SF_D + c * 8);
+  }
+  const int q0 = qb * (C::NW * 32) + wave * 32;
+  const int qi = q0 + fr;                            // this lane's query (window token index)
+  const int qc = qi < C::NWIN ? qi : C::NWIN - 1;    // clamped: surplus queries of the last wave are computed and dropped
+  bf16x8 qa[C::KSTEPS];
+#pragma unroll
+  for (int kk = 0; kk < 5; ++kk) {
+    const uint4 v = load_piece(0, qc, 16 * kk + 8 * h);
+    qa[kk] = *reinterpret_cast<const bf16x8*>(&v);
+  }
+  __syncthreads();
+  // ---- prologue 2: T^T[j, q] = tbl[j, :] . q  (rows j = relative index), both axes, into the wave-private images
+  float* th = reinterpret_cast<float*>(smem + 2 * C::TILE) + wave * (2 * C::JP * 32);
+#pragma unroll
+  for (int which = 0; which < 2; ++which)
+#pragma unroll
+    for (int jb = 0; jb < C::JP / 32; ++jb) {
+      f32x16 acc = sf_zero();
+#pragma unroll
+      for (int kk = 0; kk < 5; ++kk) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(timg + (which * C::JP + jb * 32 + fr) * C::TS + (2 * kk + h) * 16);
+        acc = SF_MFMA(a, qa[kk], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) th[(which * C::JP + jb * 32 + sf_acc_row(r, h)) * 32 + fr] = acc[r];
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  {  // gather Bh[q, kh] / scale, Bw[q, kw] / scale into the extension k-steps of the query operand
+    const int qh = qc / S, qw = qc - qh * S;
+    const float inv = 1.0f / p.scale;
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+#pragma unroll
+      for (int ks = 0; ks < C::SP / 16; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int kx = 16 * ks + 8 * h + e;        // key coordinate along this axis
+          const int j = (which ? qw : qh) - kx + S - 1;
+          v[e] = kx < S ? th[(which * C::JP + j) * 32 + fr] * inv : 0.f;
+        }
+        const uint4 u = make_uint4(sf_pack2(v[0], v[1]), sf_pack2(v[2], v[3]), sf_pack2(v[4], v[5]), sf_pack2(v[6], v[7]));
+        qa[5 + which * (C::SP / 16) + ks] = *reinterpret_cast<const bf16x8*>(&u);
+      }
+  }
+  __syncthreads();  // everyone is done with the table image: stage 1 of the K/V ring may be overwritten
+
+  // ---- K/V tile staging: 64 keys x (10 K pieces + 10 V pieces + the one-hot columns), global -> registers -> LDS
+  constexpr int PK = 64 * 10, POH = 64 * (2 * C::SP / 8), PTOT = 2 * PK + POH, PPT = (PTOT + C::NT - 1) / C::NT;
+  uint4 stg[PPT];
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int pc = tid + i * C::NT;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (pc < 2 * PK) {
+        const int sec = pc / PK, rem = pc - sec * PK, row = rem / 10, c = rem - row * 10;
+        v = load_piece(1 + sec, t * 64 + row, c * 8);
+      } else if (pc < PTOT) {
+        const int rem = pc - 2 * PK, row = rem / (2 * C::SP / 8), c = rem - row * (2 * C::SP / 8);
+        const int key = t * 64 + row;
+        if (key < C::NWIN) {
+          const int kh = key / S, kw = key - kh * S;
+          const int want = (c < C::SP / 8 ? kh : kw + C::SP) - 8 * c;   // position of the 1 inside this piece, if 0..7
+          if (want >= 0 && want < 8) {   // bf16 1.0 at element `want` of the piece
+            const uint32_t val = (want & 1) ? 0x3F800000u : 0x00003F80u;
+            const int wi = want >> 1;
+            v = make_uint4(wi == 0 ? val : 0u, wi == 1 ? val : 0u, wi == 2 ? val : 0u, wi == 3 ? val : 0u);
+          }
+        }
+      }
+      stg[i] = v;
+    }
+  };
+  auto commit = [&](int buf) {
+    char* kt = smem + buf * C::TILE;
+    char* vt = kt + 64 * C::KS;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int pc = tid + i * C::NT;
+      if (pc < PK) {
+        const int row = pc / 10, c = pc - row * 10;
+        *reinterpret_cast<uint4*>(kt + row * C::KS + c * 16) = stg[i];
+      } else if (pc < 2 * PK) {
+        const int rem = pc - PK, row = rem / 10, c = rem - row * 10;
+        *reinterpret_cast<uint4*>(vt + row * C::VS + c * 16) = stg[i];
+      } else if (pc < PTOT) {
+        const int rem = pc - 2 * PK, row = rem / (2 * C::SP / 8), c = rem - row * (2 * C::SP / 8);
+        *reinterpret_cast<uint4*>(kt + row * C::KS + 160 + c * 16) = stg[i];
+      }
+    }
+  };
+  // columns 80..95 of both V stages are never written by the loader: zero them once (the third 32-row block of O^T reads them)
+  for (int i = tid; i < 2 * 64 * 2; i += C::NT) {
+    const int buf = i / 128, rem = i - buf * 128, row = rem >> 1, c = rem & 1;
+    *reinterpret_cast<uint4*>(smem + buf * C::TILE + 64 * C::KS + row * C::VS + 160 + c * 16) = make_uint4(0, 0, 0, 0);
+  }
+  fetch(0);
+  commit(0);
+  __syncthreads();
+
+  const float c = p.scale * SF_LOG2E;
+  f32x16 oacc[3] = {sf_zero(), sf_zero(), sf_zero()};
+  float m = -INFINITY, l = 0.f;
+#pragma unroll 1
+  for (int t = 0; t < C::NTILES; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < C::NTILES) fetch(t + 1);            // global loads of the next tile fly during this tile's products
+    const char* kt = smem + buf * C::TILE;
+    const char* vt = kt + 64 * C::KS;
+    f32x16 sacc[2] = {sf_zero(), sf_zero()};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int kk = 0; kk < C::KSTEPS; ++kk) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(kt + (kb * 32 + fr) * C::KS + (2 * kk + h) * 16);
+        sacc[kb] = SF_MFMA(a, qa[kk], sacc[kb]);
+      }
+    if ((C::NWIN % 64 != 0) && t == C::NTILES - 1) {  // ragged last tile: keys beyond the window do not exist
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t * 64 + kb * 32 + sf_acc_row(r, h) >= C::NWIN) sacc[kb][r] = -INFINITY;
+    }
+    // ---- online softmax over this lane's 32 keys of the tile (the other 32 live in lane ^ 32)
+    float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m4[r & 3] = fmaxf(m4[r & 3], sacc[kb][r]);
+    float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const bool need = (mx - m) * c > 8.0f;          // lazy rescale (as attention_bf16.hip): p <= 2^8 keeps bf16 / fp32 sums exact enough
+    const float mn = need ? mx : m;
+    const float alpha = need ? __builtin_amdgcn_exp2f((m - mn) * c) : 1.0f;
+    const float mnc = mn * c;
+    float rs4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -mnc));
+        sacc[kb][r] = pv;
+        rs4[r & 3] += pv;
+      }
+    l = l * alpha + ((rs4[0] + rs4[1]) + (rs4[2] + rs4[3]));
+    m = mn;
+    if (__ballot(alpha != 1.0f) != 0ull) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[j][r] *= alpha;
+    }
+    // ---- O^T[col, query] += V^T[col x key] P^T[key x query]
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 pb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pb[e] = (__bf16)sacc[kb][8 * s + e];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int g = lane >> 4, i = lane & 15, q4 = i >> 2, pp = i & 3, hh = g >> 1;
+          const int chunk = 4 * j + 2 * (g & 1) + (pp >> 1);
+          const int r0 = kb * 32 + 16 * s + 4 * hh + q4;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(vt + r0 * C::VS + chunk * 16 + ((pp & 1) << 3)));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(vt + (r0 + 8) * C::VS + chunk * 16 + ((pp & 1) << 3)));
+          union { struct { s16x4 a, b; } st; bf16x8 v; } u;
+          u.st.a = lo;
+          u.st.b = hi;
+          oacc[j] = SF_MFMA(u.v, pb, oacc[j]);
+        }
+      }
+    if (t + 1 < C::NTILES) commit(buf ^ 1);         // stage buf^1 was last read during tile t-1: every wave passed that barrier
+    __syncthreads();
+  }
+  // ---- epilogue: lane = query, registers = output columns sf_acc_row(r, h) + 32 j (columns >= 80 are padding)
+  l += __shfl_xor(l, 32, 64);
+  const float mult = 1.f / l;
+  bool inside = false;
+  const long row = tok_row(qc, inside);
+  if (qi < C::NWIN && inside) {
+    bf16_t* o = p.out + row * p.ldo + head * SF_D;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int col = 32 * j + 8 * rq + 4 * h;     // four consecutive columns: registers 4 rq .. 4 rq + 3
+        if (col < SF_D)
+          *reinterpret_cast<uint2*>(o + col) = make_uint2(sf_pack2(oacc[j][4 * rq] * mult, oacc[j][4 * rq + 1] * mult),
+                                                          sf_pack2(oacc[j][4 * rq + 2] * mult, oacc[j][4 * rq + 3] * mult));
+      }
+  }
+}
+
+template <int S>
+static int launch_sam_flash(const SamFlashP& p, hipStream_t s) {
+  using C = SamFlashCfg<S>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_sam_flash_fwd<S>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+    attr = true;
+  }
+  const long blocks = (long)p.nimg * p.nws * p.nws * p.H * C::QBLK;
+  hipLaunchKernelGGL(k_sam_flash_fwd<S>, dim3((unsigned)blocks), dim3(C::NT), C::SMEM, s, p);
+  return 0;
+}
+
+extern "C" int vfm_sam_attn_flash_fwd(const void* qkv, long ld, const float* bias, const void* tbl_h, const void* tbl_w, void* out,
+                                      long ldo, int nimg, int G, int S, int H, int d, float scale, void* stream) {
+  VFM_CHECK(qkv && tbl_h && tbl_w && out, VFM_E_INVAL, "vfm_sam_attn_flash_fwd: null pointer");
+  VFM_CHECK(d == SF_D, VFM_E_UNSUPPORTED, "vfm_sam_attn_flash_fwd: head dim %d (only 80 = SAM ViT-H)", d);
+  VFM_CHECK((S == 14 && G > 0) || (S == 32 && G == 32), VFM_E_UNSUPPORTED,
+            "vfm_sam_attn_flash_fwd: window %d on a %d-token grid (14 x 14 windows or 32 x 32 global)", S, G);
+  VFM_CHECK(ld % 8 == 0 && ldo % 4 == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 7) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
+                ((uintptr_t)tbl_h & 15) == 0 && ((uintptr_t)tbl_w & 15) == 0,
+            VFM_E_ALIGN, "vfm_sam_attn_flash_fwd: alignment");
+  if (nimg <= 0) return VFM_OK;
+  SamFlashP p;
+  p.qkv = (const bf16_t*)qkv, p.ld = ld, p.bias = bias, p.tbl_h = (const bf16_t*)tbl_h, p.tbl_w = (const bf16_t*)tbl_w;
+  p.out = (bf16_t*)out, p.ldo = ldo, p.nimg = nimg, p.G = G, p.H = H, p.nws = S == 32 ? 1 : (G + S - 1) / S, p.scale = scale;
+  if (S == 14) launch_sam_flash<14>(p, (hipStream_t)stream);
+  else launch_sam_flash<32>(p, (hipStream_t)stream);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}

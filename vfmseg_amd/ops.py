@@ -527,6 +527,15 @@ def sam_relpos_table(rel_pos, S, out):
     return out
 
 
+def sam_attn_flash_fwd(qkv, bias, tbl_h, tbl_w, out, nimg, G, S, H, d, scale):
+    """One-launch SAM attention forward (inference): qkv [M, 3*H*d] bf16 -> out [M, H*d] bf16."""
+    lib = L.load()
+    assert qkv.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and tbl_h.dtype == torch.bfloat16 and tbl_h.is_contiguous()
+    L.check(lib.vfm_sam_attn_flash_fwd(L.ptr(qkv), _ld(qkv), L.ptr(bias), L.ptr(tbl_h), L.ptr(tbl_w), L.ptr(out), _ld(out), nimg, G, S, H, d,
+                                       float(scale), L.stream()), "vfm_sam_attn_flash_fwd")
+    return out
+
+
 def sam_attn_prep(qkv, bias, rh, rw, q_aug, k_aug, v_win, nimg, G, S, H, d, scale):
     lib = L.load()
     L.check(lib.vfm_sam_attn_prep(L.ptr(qkv), L.dt_of(qkv), _ld(qkv), L.ptr(bias), L.ptr(rh), L.ptr(rw), L.ptr(q_aug),

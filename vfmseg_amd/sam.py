@@ -10,6 +10,8 @@ Training (lora_sam_ms_masked.py) differentiates the same form: dP = dO V^T, the 
 dK^T = (scale q)^T dS and dQaug = dS Kaug are batched GEMMs whose large operand (P, dS, Kaug) is consumed in place as the
 [K, N] operand; the rel-pos chain rule is folded into the final scatter back to token-major dqkv (csrc/sam.hip).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -128,8 +130,19 @@ class SamEngine:
                 rw = torch.empty(S, S, d, dtype=torch.float32, device=dev)
                 ops.sam_relpos_table(blk.attn.rel_pos_h.detach().float().contiguous(), S, rh)   # frozen -> once
                 ops.sam_relpos_table(blk.attn.rel_pos_w.detach().float().contiguous(), S, rw)
+                # relative-index tables of the flash forward: tbl[j] = Rh[qh, kh] for qh - kh + S - 1 = j (rows >= 2S-1 zero)
+                JP = 2 * (16 if S <= 16 else 32)
+                idx_q = torch.tensor([max(j - (S - 1), 0) for j in range(2 * S - 1)], device=dev)
+                idx_k = torch.tensor([max(S - 1 - j, 0) for j in range(2 * S - 1)], device=dev)
+                tbl = []
+                for r_ in (rh, rw):
+                    t_ = torch.zeros(max(JP, 2 * S - 1), d, dtype=torch.float32, device=dev)
+                    t_[:2 * S - 1] = r_[idx_q, idx_k]
+                    tb = torch.zeros(t_.shape, dtype=torch.bfloat16, device=dev)
+                    ops.cast(t_, tb)
+                    tbl.append(tb)
                 Lp = dict(
-                    S=S, rh=rh, rw=rw,
+                    S=S, rh=rh, rw=rw, tbl_h=tbl[0], tbl_w=tbl[1],
                     qkv=Packed(base.weight.detach(), cd, k_pad=kq), qkv_b=base.bias.detach().float().contiguous(),
                     proj=Packed(blk.attn.proj.weight.detach(), cd), proj_b=blk.attn.proj.bias.detach().float().contiguous(),
                     fc1=Packed(blk.mlp.lin1.weight.detach(), cd), fc1_b=blk.mlp.lin1.bias.detach().float().contiguous(),
@@ -158,6 +171,12 @@ class SamEngine:
         """-> token-major attention output [nimg*G*G, H*d] (+ the probabilities [nb, NP, NP] when keep=True: rows / columns
         beyond the S*S window tokens are zero, so P can later serve in place as a [K, N] GEMM operand)"""
         S = Lp["S"]
+        if (not keep and cd == torch.bfloat16 and d == 80 and (S == 14 or (S == 32 and G == 32))
+                and os.environ.get("VFMSEG_SAM_FLASH", "1") != "0"):
+            # inference: one flash-style launch, no score matrix (csrc/sam_flash.hip)
+            ao = torch.empty(nimg * G * G, H * d, dtype=cd, device=dev)
+            ops.sam_attn_flash_fwd(qkv, Lp["qkv_b"], Lp["tbl_h"], Lp["tbl_w"], ao, nimg, G, S, H, d, d ** -0.5)
+            return ao
         nws = (G + S - 1) // S
         nb, Nw = nimg * nws * nws * H, S * S
         Dq, NP = _pad64(d + 2 * S), _pad64(Nw)
