@@ -49,7 +49,7 @@ int vfm_strided_copy(const void* src, int src_dt, void* dst, int dst_dt, long n0
  * the per-step re-pack of all trainable decoder weights (Conv2d / ConvTranspose2d / Linear parameters of linear_head.py:36-48,
  * VFMHead.py:28-49, Transformer.py:95-177) into their GEMM operand layouts. */
 typedef struct vfm_copy_job {
-  const float* src; void* dst; long dst_dt;
+  const float* src; void* dst; long dst_dt; long accumulate;   /* accumulate != 0: dst (fp32) += src */
   long n[4], s[4], d[4];
 } vfm_copy_job;
 int vfm_strided_copy_batch(const vfm_copy_job* table_dev, int njobs, long max_elems, void* stream);
@@ -169,7 +169,9 @@ typedef struct vfm_gemm_desc {
   int ep_mode; const void* aux; int aux_dt; long ld_aux;
   void* C2; int c2_dt; long ldc2;
   long batch, stride_a, stride_b, stride_c;
-  long kb_rows; /* bf16, B given as [K,N] (sb_n == 1): number of valid rows of B (<= K; A must be zero beyond); 0 = K */
+  long kb_rows; /* bf16, B given as [K,N] (sb_n == 1): number of valid rows of B (<= K; A must be zero beyond); 0 = K.  With batch > 1 a
+                 * positive value counts the rows of ONE matrix that the batches slice along K (split-K); a negative value -r gives
+                 * every batch r valid rows of its own (independent problems, e.g. one weight gradient per layer) */
 } vfm_gemm_desc;
 int vfm_gemm(const vfm_gemm_desc* d, void* stream);
 /* tuning / experiment knobs (bench.py --tune KEY=INT).  bf16 GEMM dispatch: "gemm_cfg" forces a tile configuration (-1 = heuristic;

@@ -258,3 +258,40 @@ def test_lora_dropout_masks_differ_between_steps():
     c, _ = m.forward_tokens([(img, None)], seed=5)
     d, _ = m.forward_tokens([(img, None)], seed=5)
     assert torch.equal(c, d)
+
+
+def test_layer_batched_lora_wgrads_equal_per_layer_path():
+    """bf16 train mode with the optimiser's flat gradient buffer: the LoRA weight gradients computed by the two layer-batched
+    TN GEMMs + batched scatter (DinoEngine._lora_wgrads_batched) against the per-layer split-K path, same forward (dropout on,
+    fixed seed), depth 4."""
+    from vfmseg_amd.optim import PEFTOptimWrapperConstructor
+    set_compute_dtype("bf16")
+    depth = 4
+    cfg = presets.dinov2_ms_masked(depth=depth)
+    cfg["backbone"]["backbone"]["out_indices"] = [0, 1, 2, 3]
+    model = MODELS.build(cfg)
+    model.load_state_dict(full_state_dict(depth=depth))
+    model = model.cuda().train()
+    oc = presets.optim_cfg()
+    ow = PEFTOptimWrapperConstructor(oc["optim_wrapper"])(model, None)
+    opt = ow.optimizer
+    img = synth_image(2, 512, seed=81).cuda()
+    g = torch.Generator().manual_seed(2)
+    outs = {}
+    try:
+        for flag in ("1", "0"):
+            os.environ["VFMSEG_LORA_WGRAD_BATCHED"] = flag
+            opt.gflat.zero_()
+            xcat, _ = model.backbone.forward_tokens([(img, None)], seed=11)
+            dx = torch.randn(xcat.shape, generator=torch.Generator().manual_seed(3)).to(xcat.dtype).cuda()
+            xcat.backward(dx)
+            outs[flag] = opt.gflat.clone()
+    finally:
+        os.environ.pop("VFMSEG_LORA_WGRAD_BATCHED", None)
+    lora = [(n, a, a + sz) for n, a, sz in zip(opt.names, opt.offsets[:-1], opt.sizes) if "lora_" in n]
+    assert len(lora) == 2 * depth
+    for n, a, b in lora:
+        ga, gb = outs["1"][a:b], outs["0"][a:b]
+        assert gb.abs().max() > 0
+        e = rel_err(ga, gb)
+        assert e < 2e-3, (n, e)     # same bf16 operands; only the fp32 summation order (one pass vs 16 split-K slabs) differs

@@ -415,18 +415,27 @@ class DinoEngine:
             seed, rng0 = draw_seed(seed, len(v.blocks) * M * D)
         else:
             seed, rng0 = 0, 0
+        # training: the K-extended QKV operands [LN(x) | T] and the dropped LN copies of ALL layers live in two layer-batched
+        # buffers, so that the LoRA weight gradients of many layers can run as ONE batched GEMM each (see backward)
+        nL = len(v.blocks)
+        batched = lora and training and cd == torch.bfloat16 and merged is None
+        A1all = torch.empty(nL, M, P["layers"][0]["qkv"].k, dtype=cd, device=dev) if batched else None
+        XDall = None
         hd = D // H
         scale = hd ** -0.5
         for li, (blk, Lp) in enumerate(zip(v.blocks, P["layers"])):
             S = {"x_in": x}
             kq = D if merged is not None else Lp["qkv"].k
-            a1 = torch.empty(M, kq, dtype=cd, device=dev)  # [LN(x) | T]: the T GEMM writes all R_PAD columns (A is zero-padded)
+            # [LN(x) | T]: the T GEMM writes all R_PAD columns (A is zero-padded)
+            a1 = A1all[li] if batched else torch.empty(M, kq, dtype=cd, device=dev)
             st1 = torch.empty(M, 2, dtype=torch.float32, device=dev)
             q = blk.attn.qkv if lora else None
             fused_drop = lora and training and q.p > 0 and cd == torch.bfloat16 and D % 256 == 0
             if fused_drop:  # LN + dropout multiplier + dropped copy in one pass
                 mask = torch.empty(M, D, dtype=cd, device=dev)
-                xd = torch.empty(M, D, dtype=cd, device=dev)
+                if batched and XDall is None:
+                    XDall = torch.empty(nL, M, D, dtype=cd, device=dev)
+                xd = XDall[li] if batched else torch.empty(M, D, dtype=cd, device=dev)
                 ops.layernorm_dropout_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1, xd, mask, q.p, seed, offset=rng0 + li * M * D)
             else:
                 ops.layernorm_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1)
@@ -469,7 +478,7 @@ class DinoEngine:
             if li in v.out_indices:
                 i = v.out_indices.index(li)
                 ops.cast(x[:Mp], xcat[:, i * D:(i + 1) * D])
-        ctx = dict(saved=saved, nimg=nimg, Np=Np, M=M, Mp=Mp, P=P, training=training)
+        ctx = dict(saved=saved, nimg=nimg, Np=Np, M=M, Mp=Mp, P=P, training=training, A1all=A1all, XDall=XDall)
         return xcat, (hp, wp), ctx
 
     # ---- backward: d(xcat) -> LoRA grads [dA0, dB0, dA1, dB1, ...]
@@ -482,6 +491,22 @@ class DinoEngine:
         M, Mp, nimg, Np = ctx["M"], ctx["Mp"], ctx["nimg"], ctx["Np"]
         dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
         grads = [None] * (2 * len(v.blocks))
+        nL = len(v.blocks)
+        # LoRA weight gradients, layer-batched: dB_l^T = T_l^T dqkv_l and dA_l = s dT_l^T drop(LN x)_l are 2 x 24 skinny GEMMs
+        # (64 output rows, reduction over the 4100 tokens) that each needed split-K slabs + a combine launch (35 us per layer for
+        # 0.3 % of the step's FLOPs).  Keeping dqkv / d[LN x | T] of the layers (0.8 GB of 288) turns them into TWO batched GEMMs
+        # per half of the backbone - no split-K, no slabs - plus one batched scatter into the flat gradient buffer.  Two halves so
+        # that the first LoRA gradient bucket can still leave (DP) while the second half of the backward runs.
+        from .functional import direct_grad_target
+        wg_batched = (ctx.get("A1all") is not None and self.lora_on() and os.environ.get("VFMSEG_LORA_WGRAD_BATCHED", "1") != "0" and
+                      all(direct_grad_target(b.attn.qkv.lora_A["default"].weight) is not None and
+                          direct_grad_target(b.attn.qkv.lora_B["default"].weight) is not None for b in v.blocks) and
+                      (ctx.get("XDall") is not None or all(S_["mask"] is None for S_ in ctx["saved"])))
+        if wg_batched:
+            kq_all = ctx["A1all"].shape[2]
+            DA1all = torch.empty(nL, M, kq_all, dtype=cd, device=dev)
+            DQKVall = torch.empty(nL, M, 3 * D, dtype=cd, device=dev)
+        half = nL // 2
         fuse_t = cd == torch.bfloat16 and D % 256 == 0  # LN backward emits the next dgrad operand bf16(dx * gamma) itself
         def add_tap(li):
             if li in v.out_indices:
@@ -511,14 +536,18 @@ class DinoEngine:
             # ---- attention branch: x_mid = x_in + g1 * proj(attn(qkv(LN1(x_in))))
             dao = torch.empty(M, D, dtype=cd, device=dev)
             Lp["proj"].dgrad(t, dao)
-            dqkv = torch.empty(M, 3 * D, dtype=cd, device=dev)
+            dqkv = DQKVall[li] if wg_batched else torch.empty(M, 3 * D, dtype=cd, device=dev)
             qkv = S["qkv"]
             ops.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], S["ao"], S["lse"], dao, dqkv[:, :D], dqkv[:, D:2 * D],
                          dqkv[:, 2 * D:], nimg, H, hd, Np, 1, Np, 1, scale)
             kq = Lp["qkv"].k
-            da1 = torch.empty(M, kq, dtype=cd, device=dev)
+            da1 = DA1all[li] if wg_batched else torch.empty(M, kq, dtype=cd, device=dev)
             Lp["qkv"].dgrad(dqkv, da1)
-            if isinstance(q, LoraLinear):
+            if isinstance(q, LoraLinear) and wg_batched:
+                # d LN1(x) = da1[:, :D] + mask * (s * dT @ A); the weight gradients of this layer wait for their batch
+                ep = dict(ep_mode=ops.EP_MUL, aux=S["mask"]) if S["mask"] is not None else {}
+                ops.gemm(da1[:, D:D + R_PAD], Lp["at"], da1[:, :D], alpha=q.scaling, residual=da1[:, :D], **ep)
+            elif isinstance(q, LoraLinear):
                 r = q.r
                 A, Bm = q.lora_A["default"].weight, q.lora_B["default"].weight
                 a1 = S["a1"]
@@ -557,9 +586,46 @@ class DinoEngine:
                 ops.layernorm_bwd(da1[:, :D], S["x_in"], Lp["n1w"], S["st1"], dx, accumulate_dx=True)
                 t = None
             ctx["saved"][li] = None
-            if BACKWARD_EVENTS["block_done"] is not None:
+            if wg_batched:
+                if li == half or li == 0:
+                    lo, hi = (half, nL) if li == half and half > 0 else (0, half if half > 0 else nL)
+                    self._lora_wgrads_batched(P, ctx, DA1all, DQKVall, lo, hi, M, D)
+                    if BACKWARD_EVENTS["block_done"] is not None:
+                        for lj in range(hi - 1, lo - 1, -1):
+                            BACKWARD_EVENTS["block_done"](lj)
+            elif BACKWARD_EVENTS["block_done"] is not None:
                 BACKWARD_EVENTS["block_done"](li)
         return grads
+
+    def _lora_wgrads_batched(self, P, ctx, DA1all, DQKVall, lo, hi, M, D):
+        """LoRA weight gradients of layers [lo, hi): two batched TN GEMMs + one batched scatter-accumulate into the flat buffer."""
+        from .functional import direct_grad_target
+        v = self.vit
+        n = hi - lo
+        dev = DA1all.device
+        ws = P.setdefault("wg_ws", {})
+        key = (lo, hi, M)
+        w = ws.get(key)
+        if w is None:
+            w = ws[key] = dict(outB=torch.empty(n, R_PAD, 3 * D, dtype=torch.float32, device=dev),
+                               outA=torch.empty(n, R_PAD, D, dtype=torch.float32, device=dev), table=None, sig=None)
+        A1all, XDall = ctx["A1all"], ctx["XDall"]
+        q0 = v.blocks[lo].attn.qkv
+        ops.gemm_tn_batched(A1all[lo:hi, :, D:D + R_PAD], DQKVall[lo:hi], w["outB"], M)                       # dB^T = T^T dqkv
+        Y = XDall[lo:hi] if XDall is not None else A1all[lo:hi, :, :D]
+        ops.gemm_tn_batched(DA1all[lo:hi, :, D:D + R_PAD], Y, w["outA"], M, alpha=q0.scaling)                 # dA = s dT^T drop(LN x)
+        tg = []
+        for l in range(lo, hi):
+            q = v.blocks[l].attn.qkv
+            tg.append((direct_grad_target(q.lora_A["default"].weight), direct_grad_target(q.lora_B["default"].weight), q.r))
+        sig = tuple((a.data_ptr(), b.data_ptr()) for a, b, _ in tg)
+        if w["table"] is None or w["sig"] != sig:
+            jobs = []
+            for i, (tA, tB, r) in enumerate(tg):
+                jobs.append((w["outB"][i], tB, (3 * D, r), (1, 3 * D), (r, 1), True))     # B.grad[n, rr] += outB[rr, n]
+                jobs.append((w["outA"][i], tA, (r, D), (D, 1), (D, 1), True))             # A.grad[rr, k] += outA[rr, k]
+            w["table"], w["sig"] = ops.CopyBatch(jobs), sig
+        w["table"].run()
 
 
 def _refresh_sites(P, sites):

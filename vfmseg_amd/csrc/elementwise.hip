@@ -253,7 +253,9 @@ __global__ void __launch_bounds__(256) k_strided_copy_batch(const vfm_copy_job* 
     const unsigned i2 = r % n2; r /= n2;
     const unsigned i1 = r % n1; r /= n1;
     const float v = t.src[(long)r * t.s[0] + (long)i1 * t.s[1] + (long)i2 * t.s[2] + (long)i3 * t.s[3]];
-    st_any(t.dst, (long)r * t.d[0] + (long)i1 * t.d[1] + (long)i2 * t.d[2] + (long)i3 * t.d[3], (int)t.dst_dt, v);
+    const long o = (long)r * t.d[0] + (long)i1 * t.d[1] + (long)i2 * t.d[2] + (long)i3 * t.d[3];
+    if (t.accumulate) ((float*)t.dst)[o] += v;
+    else st_any(t.dst, o, (int)t.dst_dt, v);
   }
 }
 extern "C" int vfm_strided_copy_batch(const vfm_copy_job* table_dev, int njobs, long max_elems, void* stream) {

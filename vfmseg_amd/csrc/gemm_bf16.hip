@@ -74,6 +74,9 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
       kb_valid = kb_rows - (ldb > 0 ? z * (stride_b / ldb) : 0);
       if (kb_valid > K) kb_valid = K;
       if (kb_valid < 1) kb_valid = 1;
+    } else if (kb_rows < 0) {  // independent batches (one per layer) of -kb_rows valid rows each
+      kb_valid = -kb_rows;
+      if (kb_valid > K) kb_valid = K;
     }
   }
 
@@ -270,7 +273,7 @@ static bool launch_one(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_des
   }
   dim3 grid(tiles_m * tiles_n + sk.nblk, (unsigned)batch), blk(C::THREADS);
   const long ldb = BT ? d->sb_k : d->sb_n;
-  const long kb_rows = d->kb_rows > 0 ? d->kb_rows : 0;
+  const long kb_rows = d->kb_rows;
   hipLaunchKernelGGL((k_gemm_bf16<BM, BN, WM_W, WN_W, NS, VEC, BT, AT>), grid, blk, C::SMEM, s, (const bf16_t*)d->A, AT ? d->sa_k : d->sa_m,
                      (const bf16_t*)d->B, ldb, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c, tiles_m, tiles_n, kb_rows,
                      make_epi(d), sk);

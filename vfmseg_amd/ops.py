@@ -103,11 +103,13 @@ class CopyBatch:
         import struct
         buf = bytearray()
         self.keep, self.max_elems, self.n = [], 0, len(jobs)
-        for (src, dst, shape, sstr, dstr) in jobs:
-            assert src.dtype == torch.float32 and src.is_cuda and dst.is_cuda
+        for job in jobs:
+            src, dst, shape, sstr, dstr = job[:5]
+            acc = int(bool(job[5])) if len(job) > 5 else 0    # optional 6th item: accumulate into an fp32 dst
+            assert src.dtype == torch.float32 and src.is_cuda and dst.is_cuda and (not acc or dst.dtype == torch.float32)
             k = 4 - len(shape)
             n, s_, d_ = [1] * k + list(shape), [0] * k + list(sstr), [0] * k + list(dstr)
-            buf += struct.pack("2Q13q", src.data_ptr(), dst.data_ptr(), L.dt_of(dst), *n, *s_, *d_)
+            buf += struct.pack("2Q14q", src.data_ptr(), dst.data_ptr(), L.dt_of(dst), acc, *n, *s_, *d_)
             self.keep += [src, dst]
             e = 1
             for v in shape:
@@ -472,6 +474,30 @@ def gemm_splitk_tn(xs, y, slabs, kch):
     if fin is not None:
         fin()
     return slabs
+
+
+def gemm_tn_batched(xs, y, out, valid_rows, alpha=1.0):
+    """out[l] = alpha * xs[l]^T @ y[l] for independent problems l (one weight gradient per layer in ONE launch): xs [L, M, P],
+    y [L, M, Q] bf16 views (unit column stride, P % 8 == 0, Q % 8 == 0), out fp32 [L, P, Q]; token rows >= valid_rows read as zeros."""
+    lib = L.load()
+    d = L.GemmDesc()
+    Lb, M, P = xs.shape
+    _, M2, Q = y.shape
+    assert M == M2 and xs.stride(2) == 1 and y.stride(2) == 1 and out.shape == (Lb, P, Q) and out.is_contiguous()
+    d.A, d.B, d.C = L.ptr(xs), L.ptr(y), L.ptr(out)
+    d.in_dt, d.c_dt = L.dt_of(xs), L.dt_of(out)
+    d.M, d.N, d.K = P, Q, (valid_rows + 63) // 64 * 64
+    d.sa_m, d.sa_k = 1, xs.stride(1)
+    d.sb_n, d.sb_k = 1, y.stride(1)
+    d.ldc = Q
+    d.alpha = float(alpha)
+    d.batch, d.stride_a, d.stride_b, d.stride_c = Lb, xs.stride(0), y.stride(0), P * Q
+    d.kb_rows = -int(valid_rows)
+    fin = PROFILE("gemm", 2.0 * P * Q * valid_rows * Lb, REGION[-1]) if PROFILE is not None else None
+    L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
+    if fin is not None:
+        fin()
+    return out
 
 
 def tune(key, value):
