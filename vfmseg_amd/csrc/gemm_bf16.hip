@@ -384,8 +384,10 @@ int vfm_gemm_bf16_impl(const vfm_gemm_desc* d0, hipStream_t s) {
   if (bt) return gemm_main(d0, s);
   // shapes that go to the 64-row tiles (few column tiles, long K: the LoRA T GEMM [4100 x 64 x 1024]) take the tail as one
   // more row tile of the same launch - cheaper than a launch of its own
+  // (a few tiles over the 512 resident slots still beat a second launch: the coarse 512 x 1024 inference pass, M = 2049, N = 1024,
+  // has 33 x 16 tiles and paid 10 us per GEMM for its one [cls] row)
   const bool rows64 = d0->N > 32 && d0->K >= 512 && (long)cdiv(d0->M, 128) * cdiv(d0->N, 128) <= 160 &&
-                      (long)cdiv(d0->M, 64) * cdiv(d0->N, 64) <= 512;
+                      (long)cdiv(d0->M, 64) * cdiv(d0->N, 64) <= 544;
   if (g_split_tail && !(rows64 && (g_split_tail & 2)) && d0->M > 512 && tail > 0 && tail <= 32 && (d0->batch <= 1)) {
     vfm_gemm_desc dm = *d0, dt = *d0;
     const long mm = d0->M - tail;
@@ -434,7 +436,7 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
     const long t128 = (long)cdiv(d->M, 128) * cdiv(d->N, 128) * (g_batch_tiles ? nbatch : 1);
     const long t256 = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
     if (d->N <= 32) cfg = 10;                                        // 64x64 tiles: many rows, few columns
-    else if (t128 <= 160 && d->K >= 512 && (long)cdiv(d->M, 64) * cdiv(d->N, 64) <= 512)
+    else if (t128 <= 160 && d->K >= 512 && (long)cdiv(d->M, 64) * cdiv(d->N, 64) <= 544)
       cfg = 10;  // few tiles, long K (LoRA T GEMM 4096x64x1024, decoder projections): 64x64 tiles with the 4-stage ring
     else if (t128 <= 160) cfg = 18;                                  // small problems: 64x128 tiles fill more CUs
     else if ((g_use_pp & 2) && t128 > 160 && t128 <= 272 && d->K >= 256 && (d->M + 128) * d->sa_m < (1l << 31) && (d->N + 128) * d->sb_n < (1l << 31))

@@ -48,3 +48,19 @@ OPTIM_WRAPPER_CONSTRUCTORS = Registry("optim_wrapper_constructor")
 METRICS = Registry("metric")
 HOOKS = Registry("hook")
 DATASETS = Registry("dataset")
+
+
+def register_into_mmseg(force=True):
+    """Optional: mirror every class into mmseg / mmengine's own registries, so that an UNMODIFIED mmengine Runner
+    (tools/train.py of the reference, `Runner.from_cfg(cfg)`) resolves `type="MsVFMEncoderDecoder"` ... to the HIP-backed
+    classes - what `import rein` does for the reference's classes (rein/__init__.py:1-6).  mmseg is not part of this image, so
+    the call is a no-op returning False here; it is NOT exercised by the test-suite (no mmengine offline)."""
+    try:
+        from mmseg.registry import MODELS as MM_MODELS, METRICS as MM_METRICS  # type: ignore
+        from mmengine.registry import OPTIM_WRAPPER_CONSTRUCTORS as MM_OWC  # type: ignore
+    except Exception:
+        return False
+    for src, dst in ((MODELS, MM_MODELS), (METRICS, MM_METRICS), (OPTIM_WRAPPER_CONSTRUCTORS, MM_OWC)):
+        for name, cls in src._table.items():
+            dst.register_module(name=name, module=cls, force=force)
+    return True
