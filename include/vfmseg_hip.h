@@ -195,7 +195,8 @@ typedef struct vfm_attn_desc {
   /* backward only */
   const void* dout; long ld_do;
   void* dq; void* dk; void* dv; long ld_dq, ld_dk, ld_dv;
-  float* delta; /* workspace fp32 [B,H,nq] */
+  float* delta; /* backward workspace: fp32 [B,H,nq] followed by [B*H*192] floats that must be ZERO on entry (they are zero again on
+                 * return): scratch for the extra-token rows, gathered with fp32 atomics */
 } vfm_attn_desc;
 int vfm_attn_fwd(const vfm_attn_desc* d, void* stream);
 int vfm_attn_bwd(const vfm_attn_desc* d, void* stream);

@@ -177,74 +177,31 @@ __device__ void attn_extra_fwd(const AttnP& p, int b, int hh, int qi, char* smem
   weighted_rowsum(sc, (const bf16_t*)p.v, p.ldv, col0, b, nk, p.nk_main, p.B, 1.f / l, red, (bf16_t*)p.o + qrow * p.ldo + col0);
   if (tid == 0 && p.lse) p.lse[((long)b * p.H + hh) * nq + qi] = m + __logf(l);
 }
-__device__ void attn_extra_dq(const AttnP& p, int b, int hh, int qi, char* smem) {
-  const int tid = threadIdx.x, sub = tid & 7, rg = tid >> 3;
-  const int nk = p.nk_main + p.nk_extra, nq = p.nq_main + p.nq_extra;
-  float* sc = reinterpret_cast<float*>(smem);
-  float* red = sc + ATTN_EXTRA_MAX + 64;
-  const int col0 = hh * 64;
-  const long qrow = tok_row(b, qi, p.nq_main, p.B);
-  const uint4 q8 = *reinterpret_cast<const uint4*>((const bf16_t*)p.q + qrow * p.ldq + col0 + sub * 8);
-  const uint4 g8 = *reinterpret_cast<const uint4*>((const bf16_t*)p.dout + qrow * p.ld_do + col0 + sub * 8);
-  const uint4 o8 = *reinterpret_cast<const uint4*>((const bf16_t*)p.o + qrow * p.ldo + col0 + sub * 8);
-  const float lse = p.lse[((long)b * p.H + hh) * nq + qi], delta = sum8(dot8(g8, o8));
-  if (tid == 0) p.delta[((long)b * p.H + hh) * nq + qi] = delta;
-  const bf16_t* Kc = (const bf16_t*)p.k + col0 + sub * 8;
-  const bf16_t* Vc = (const bf16_t*)p.v + col0 + sub * 8;
-  for (int k0 = 0; k0 < nk; k0 += 128) {
-    uint4 kv[4], vv[4];
+// ------------------------------------------------------------------------------------------- [cls] row of the backward
+// The [cls] token (sequence position n_main, stored after all patch tokens) used to get VALU blocks of its own in the dQ and
+// dK/dV kernels: 64 serial blocks at the end of a 512-block grid (+30 us of a 121-us backward at bs 2).  Its gradients are
+// instead gathered where the products already exist: the ragged last tile of every regular block holds, for each of its 32
+// stationary positions, P and dS against the [cls] token in one accumulator register; the sum over the positions of
+// (that scalar) x (the position's stationary row) is this block's contribution, reduced through a wave-private LDS image and
+// added to an fp32 scratch row with one atomic instruction per wave.  k_attn_cls_finish adds the ([cls], [cls]) pair and
+// writes the three bf16 rows.  (fp32 atomics: the summation order over the 32 waves of an (image, head) pair is not fixed, so
+// these three rows are reproducible to fp32 rounding, not bitwise.)
+//   out[col] += sum_i w[i] * F_i[col]:  w = per-lane scalar (already broadcast to both halves), f = the lane's stationary
+//   fragments (columns 16 kk + 8 h + e), red = 32 x 65 floats of LDS owned by this wave
+__device__ __forceinline__ void cls_partial(float w, const bf16x8 (&f)[4], float* red, int lane, float* dst) {
+  const int fr = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long krow = tok_row(b, min(k0 + u * 32 + rg, nk - 1), p.nk_main, p.B);
-      kv[u] = *reinterpret_cast<const uint4*>(Kc + krow * p.ldk);
-      vv[u] = *reinterpret_cast<const uint4*>(Vc + krow * p.ldv);
-    }
+  for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = k0 + u * 32 + rg;
-      const float sv = sum8(dot8(q8, kv[u])) * p.scale, dp = sum8(dot8(g8, vv[u]));
-      if (k < nk && sub == 0) sc[k] = __expf(sv - lse) * (dp - delta);
-    }
-  }
-  __syncthreads();
-  weighted_rowsum(sc, (const bf16_t*)p.k, p.ldk, col0, b, nk, p.nk_main, p.B, p.scale, red, (bf16_t*)p.dq + qrow * p.ld_dq + col0);
-}
-__device__ void attn_extra_dkv(const AttnP& p, int b, int hh, int ki, char* smem) {
-  const int tid = threadIdx.x, sub = tid & 7, rg = tid >> 3;
-  const int nq = p.nq_main + p.nq_extra;
-  float* pw = reinterpret_cast<float*>(smem);
-  float* dsw = pw + ATTN_EXTRA_MAX + 64;
-  float* red = dsw + ATTN_EXTRA_MAX + 64;
-  const int col0 = hh * 64;
-  const long krow = tok_row(b, ki, p.nk_main, p.B);
-  const uint4 k8 = *reinterpret_cast<const uint4*>((const bf16_t*)p.k + krow * p.ldk + col0 + sub * 8);
-  const uint4 v8 = *reinterpret_cast<const uint4*>((const bf16_t*)p.v + krow * p.ldv + col0 + sub * 8);
-  const float* lse_g = p.lse + ((long)b * p.H + hh) * nq;
-  const float* del_g = p.delta + ((long)b * p.H + hh) * nq;
-  const bf16_t* Qc = (const bf16_t*)p.q + col0 + sub * 8;
-  const bf16_t* Gc = (const bf16_t*)p.dout + col0 + sub * 8;
-  for (int i0 = 0; i0 < nq; i0 += 128) {
-    uint4 qv[4], gv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const long qrow = tok_row(b, min(i0 + u * 32 + rg, nq - 1), p.nq_main, p.B);
-      qv[u] = *reinterpret_cast<const uint4*>(Qc + qrow * p.ldq);
-      gv[u] = *reinterpret_cast<const uint4*>(Gc + qrow * p.ld_do);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * 32 + rg;
-      const float sv = sum8(dot8(k8, qv[u])) * p.scale, dp = sum8(dot8(v8, gv[u]));
-      if (i < nq && sub == 0) {
-        const float pv = __expf(sv - lse_g[i]);
-        pw[i] = pv;
-        dsw[i] = pv * (dp - del_g[i]);
-      }
-    }
-  }
-  __syncthreads();
-  weighted_rowsum(pw, (const bf16_t*)p.dout, p.ld_do, col0, b, nq, p.nq_main, p.B, 1.f, red, (bf16_t*)p.dv + krow * p.ld_dv + col0);
-  weighted_rowsum(dsw, (const bf16_t*)p.q, p.ldq, col0, b, nq, p.nq_main, p.B, p.scale, red, (bf16_t*)p.dk + krow * p.ld_dk + col0);
+    for (int e = 0; e < 8; ++e) red[fr * 65 + 16 * kk + 8 * h + e] = w * (float)f[kk][e];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  float sv = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < 32; ++i) sv += red[i * 65 + lane];
+  atomicAdd(dst + lane, sv);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
 }
 
 // ------------------------------------------------------------------------------------------------------ forward
@@ -261,15 +218,19 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
     // The [cls] query gets a block of its own that runs the VALU path.  Those blocks take the LAST linear ids: workgroups
     // are placed on the CUs in id order at launch, and a light block in the middle of the order pushes a third full block
     // onto some CUs (measured: +8 us on a 39-us kernel even when the light block returns at once).
-    const int gx = gridDim.x, nfull = (gx - 1) * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
-    if (lin >= nfull) {
-      const int e = lin - nfull;
-      if (DQ) attn_extra_dq(p, e / p.H, e % p.H, p.nq_main, smem);
-      else attn_extra_fwd(p, e / p.H, e % p.H, p.nq_main, smem);
-      return;
+    if constexpr (!DQ) {
+      const int gx = gridDim.x, nfull = (gx - 1) * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
+      if (lin >= nfull) {
+        const int e = lin - nfull;
+        attn_extra_fwd(p, e / p.H, e % p.H, p.nq_main, smem);
+        return;
+      }
+      bx = lin % (gx - 1), bh = lin / (gx - 1);
     }
-    bx = lin % (gx - 1), bh = lin / (gx - 1);
   }
+  // backward: the [cls] query has no block (its dQ comes from the dK/dV kernel's partials, see cls_partial); this kernel gathers
+  // the [cls] KEY's dK / dV from its regular blocks
+  const bool cls_key = DQ && NW == 4 && p.nk_extra == 1 && p.cls_scratch != nullptr;
   const int b = bh / p.H, hh = bh % p.H;
   const int col0 = hh * 64;
   const int h = lane >> 5;
@@ -296,7 +257,21 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
       for (int e2 = 0; e2 < 8; ++e2) dsum = fmaf((float)dof[kk][e2], (float)of[kk][e2], dsum);
     delta_l = dsum + __shfl_xor(dsum, 32, 64);
     if (qvalid && h == 0) p.delta[((long)b * p.H + hh) * nq + qi] = delta_l;
+    if (cls_key && p.nq_extra == 1 && bx == 0 && wave == 0) {   // delta of the [cls] query, for the dK/dV kernel's last query tile
+      const long crow = tok_row(b, p.nq_main, p.nq_main, p.B);
+      bf16x8 cg[4], co[4];
+      load_stationary((const bf16_t*)p.dout, p.ld_do, crow, col0, h, cg);
+      load_stationary((const bf16_t*)p.o, p.ldo, crow, col0, h, co);
+      float cs = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int e2 = 0; e2 < 8; ++e2) cs = fmaf((float)cg[kk][e2], (float)co[kk][e2], cs);
+      cs += __shfl_xor(cs, 32, 64);
+      if (lane == 0) p.delta[((long)b * p.H + hh) * nq + p.nq_main] = cs;
+    }
   }
+  float p_cls = 0.f, ds_cls = 0.f;   // P^T / dS^T of this lane's query against the [cls] key (row 0 of the ragged last tile)
   const float c = p.scale * LOG2E;
   f32x16 oacc[2] = {zero16(), zero16()};
   float m = -INFINITY, l = 0.f;
@@ -384,6 +359,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
         for (int r = 0; r < 16; ++r) {
           const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -lse_l));
           sacc[kb][r] = pv * (dpacc[kb][r] - delta_l);
+          if (kb == 0 && r == 0) p_cls = pv, ds_cls = sacc[0][0];   // meaningful in the last tile, lanes h == 0
         }
       if (tail) {  asm volatile("" ::: "memory");  // keeps this a real branch; wave-uniform: clamped duplicate keys of the ragged last tile contribute nothing
 #pragma unroll
@@ -404,6 +380,17 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
         for (int j = 0; j < 2; ++j) oacc[j] = MFMA(tr_frag(t2, kb, s, j, lane), pb, oacc[j]);
       }
     buf = nbuf;
+  }
+  if constexpr (DQ) {
+    if (cls_key) {   // this wave's 32 queries -> contribution to dK[cls] (unscaled) and dV[cls]
+      __syncthreads();   // every wave is done with the K/V stages: the LDS becomes reduction scratch
+      float* red = reinterpret_cast<float*>(smem) + wave * (32 * 65);
+      float* scr = p.cls_scratch + ((long)b * p.H + hh) * 192;
+      float wp = __shfl(p_cls, lane & 31, 64), wd = __shfl(ds_cls, lane & 31, 64);
+      if (!qvalid) wp = 0.f, wd = 0.f;
+      cls_partial(wd, qf, red, lane, scr + 64);    // dK[cls] += sum_q dS[q, cls] q[q, :]
+      cls_partial(wp, dof, red, lane, scr + 128);  // dV[cls] += sum_q P[q, cls] dO[q, :]
+    }
   }
   // ---- epilogue: lane = query, registers = output columns acc_row(r, h) + 32 j
   float mult;
@@ -440,15 +427,9 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nq = p.nq_main + p.nq_extra, nk = p.nk_main + p.nk_extra;
   int bx = blockIdx.x, bh = blockIdx.y;
-  if (NW == 4 && p.nk_extra == 1 && (p.nk_main & 127) == 0 && nq <= ATTN_EXTRA_MAX) {  // [cls] key: VALU path, last linear ids
-    const int gx = gridDim.x, nfull = (gx - 1) * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
-    if (lin >= nfull) {
-      const int e = lin - nfull;
-      attn_extra_dkv(p, e / p.H, e % p.H, p.nk_main, smem);
-      return;
-    }
-    bx = lin % (gx - 1), bh = lin / (gx - 1);
-  }
+  // the [cls] key has no block here: its dK / dV are gathered by the dQ kernel (cls_partial); this kernel gathers dQ[cls]
+  const bool cls_query = NW == 4 && p.nq_extra == 1 && p.cls_scratch != nullptr;
+  float ds_cls = 0.f;
   const int b = bh / p.H, hh = bh % p.H;
   const int col0 = hh * 64;
   const int h = lane >> 5;
@@ -513,6 +494,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
           const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -lsv[e] * LOG2E));
           pacc[r] = pv;
           sacc[r] = pv * (dpacc[r] - dlv[e]);
+          if (qb == 0 && r == 0) ds_cls = sacc[0];   // dS[cls, key]: meaningful in the last query tile, lanes h == 0
         }
       }
       if (tail) {  asm volatile("" ::: "memory");  // keeps this a real branch; wave-uniform: clamped duplicate queries of the ragged last tile contribute nothing
@@ -531,6 +513,13 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
       }
     }
     buf = nbuf;
+  }
+  if (cls_query) {   // this wave's 32 keys -> contribution to dQ[cls] (unscaled)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem) + wave * (32 * 65);
+    float wd = __shfl(ds_cls, lane & 31, 64);
+    if (!kvalid) wd = 0.f;
+    cls_partial(wd, kf, red, lane, p.cls_scratch + ((long)b * p.H + hh) * 192);
   }
   if (kvalid) {
     bf16_t* odk = (bf16_t*)p.dk;
@@ -564,25 +553,57 @@ static bool aligned_ok(const vfm_attn_desc* d, bool bwd) {
 // 2-wave blocks when the 4-wave grid would not even give every CU one block
 static bool short_grid(const vfm_attn_desc* d, int n) { return (long)cdiv(n, 128) * d->B * d->H < 256; }
 
+int g_attn_lds_pad = 0;   // vfm_tune("attn_lds_pad"): extra dynamic LDS per forward block (occupancy experiments)
 int vfm_attn_bf16_fwd_impl(const vfm_attn_desc* d, hipStream_t s) {
   VFM_CHECK(aligned_ok(d, false), VFM_E_ALIGN, "vfm_attn_fwd(bf16): operands must be 16-byte aligned, ld %% 8 == 0");
   const AttnP p = to_p(d);
   const int nq = d->nq_main + d->nq_extra;
-  const size_t shm = 6 * TILE_BYTES;
+  const size_t shm = 6 * TILE_BYTES + g_attn_lds_pad;
+  static int attr_pad = -1;
+  if (attr_pad != g_attn_lds_pad) {
+    (void)hipFuncSetAttribute((const void*)k_attn_bf16_q<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr_pad = g_attn_lds_pad;
+  }
   if (short_grid(d, nq)) hipLaunchKernelGGL((k_attn_bf16_q<false, 2>), dim3(cdiv(nq, 64), d->B * d->H), dim3(128), shm, s, p);
   else hipLaunchKernelGGL((k_attn_bf16_q<false, 4>), dim3(cdiv(nq, 128), d->B * d->H), dim3(256), shm, s, p);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }
 
+// ([cls], [cls]) pair + fp32 scratch -> the bf16 [cls] rows of dq / dk / dv; the scratch is left zeroed for the next call.
+// One 64-lane block per (image, head): lane = column.
+__global__ void __launch_bounds__(64) k_attn_cls_finish(AttnP p) {
+  const int bh = blockIdx.x, b = bh / p.H, hh = bh % p.H, lane = threadIdx.x;
+  const int nq = p.nq_main + p.nq_extra;
+  const long row = tok_row(b, p.nq_main, p.nq_main, p.B);
+  const int col = hh * 64 + lane;
+  const float qc = bf16_to_f32(((const bf16_t*)p.q)[row * p.ldq + col]), kc = bf16_to_f32(((const bf16_t*)p.k)[row * p.ldk + col]);
+  const float vc = bf16_to_f32(((const bf16_t*)p.v)[row * p.ldv + col]), gc = bf16_to_f32(((const bf16_t*)p.dout)[row * p.ld_do + col]);
+  const float s = wave_sum(qc * kc) * p.scale, dp = wave_sum(gc * vc);
+  const float lse = p.lse[(long)bh * nq + p.nq_main], delta = p.delta[(long)bh * nq + p.nq_main];
+  const float pv = __expf(s - lse), ds = pv * (dp - delta);
+  float* scr = p.cls_scratch + (long)bh * 192;
+  ((bf16_t*)p.dq)[row * p.ld_dq + col] = f32_to_bf16((scr[lane] + ds * kc) * p.scale);
+  ((bf16_t*)p.dk)[row * p.ld_dk + col] = f32_to_bf16((scr[64 + lane] + ds * qc) * p.scale);
+  ((bf16_t*)p.dv)[row * p.ld_dv + col] = f32_to_bf16(scr[128 + lane] + pv * gc);
+  scr[lane] = 0.f, scr[64 + lane] = 0.f, scr[128 + lane] = 0.f;
+}
+
 int vfm_attn_bf16_bwd_impl(const vfm_attn_desc* d, hipStream_t s) {
   VFM_CHECK(aligned_ok(d, true), VFM_E_ALIGN, "vfm_attn_bwd(bf16): operands must be 16-byte aligned, ld %% 8 == 0");
-  const AttnP p = to_p(d);
+  AttnP p = to_p(d);
   const int nq = d->nq_main + d->nq_extra, nk = d->nk_main + d->nk_extra;
+  // one extra [cls] token on both sides of a 4-wave grid (the ViT backbones): its rows are gathered from the regular blocks into
+  // the fp32 scratch that follows delta[B, H, nq] in the workspace (192 floats per (image, head), zero on entry, zeroed again
+  // by the finishing kernel) - no VALU blocks of their own
+  const bool cls = d->nq_extra == 1 && d->nk_extra == 1 && d->nq_main == d->nk_main && (d->nq_main % 128) == 0 && !short_grid(d, nq);
+  p.cls_scratch = cls ? d->delta + (long)d->B * d->H * nq : nullptr;
+  // (any other shape with extra tokens runs them through the ragged last blocks / tiles of the regular path)
   if (short_grid(d, nq)) hipLaunchKernelGGL((k_attn_bf16_q<true, 2>), dim3(cdiv(nq, 64), d->B * d->H), dim3(128), 6 * TILE_BYTES, s, p);
-  else hipLaunchKernelGGL((k_attn_bf16_q<true, 4>), dim3(cdiv(nq, 128), d->B * d->H), dim3(256), 6 * TILE_BYTES, s, p);
+  else hipLaunchKernelGGL((k_attn_bf16_q<true, 4>), dim3(cdiv(cls ? d->nq_main : nq, 128), d->B * d->H), dim3(256), 6 * TILE_BYTES, s, p);
   if (short_grid(d, nk)) hipLaunchKernelGGL((k_attn_bf16_dkv<2>), dim3(cdiv(nk, 64), d->B * d->H), dim3(128), 3 * (2 * TILE_BYTES + 1024), s, p);
-  else hipLaunchKernelGGL((k_attn_bf16_dkv<4>), dim3(cdiv(nk, 128), d->B * d->H), dim3(256), 3 * (2 * TILE_BYTES + 1024), s, p);
+  else hipLaunchKernelGGL((k_attn_bf16_dkv<4>), dim3(cdiv(cls ? d->nk_main : nk, 128), d->B * d->H), dim3(256), 3 * (2 * TILE_BYTES + 1024), s, p);
+  if (cls) hipLaunchKernelGGL(k_attn_cls_finish, dim3(d->B * d->H), dim3(64), 0, s, p);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }

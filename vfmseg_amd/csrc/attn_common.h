@@ -12,6 +12,7 @@ struct AttnP {
   const void* dout; long ld_do;
   void* dq; void* dk; void* dv; long ld_dq, ld_dk, ld_dv;
   float* delta;
+  float* cls_scratch;   // backward: fp32 [B*H][3][64] partial dq / dk / dv rows of the extra ([cls]) token, or null
 };
 
 __device__ __forceinline__ long tok_row(int b, int i, int n_main, int B) {
@@ -29,6 +30,7 @@ static inline AttnP to_p(const vfm_attn_desc* d) {
   p.dout = d->dout; p.ld_do = d->ld_do;
   p.dq = d->dq; p.dk = d->dk; p.dv = d->dv; p.ld_dq = d->ld_dq; p.ld_dk = d->ld_dk; p.ld_dv = d->ld_dv;
   p.delta = d->delta;
+  p.cls_scratch = nullptr;
   return p;
 }
 

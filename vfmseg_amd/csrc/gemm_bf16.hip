@@ -331,6 +331,11 @@ extern "C" int vfm_tune(const char* key, int value) {
     g_pp_dbg = value;
     return VFM_OK;
   }
+  if (key && strcmp(key, "attn_lds_pad") == 0) {
+    extern int g_attn_lds_pad;
+    g_attn_lds_pad = value;
+    return VFM_OK;
+  }
   if (key && strcmp(key, "gemm_use_pp") == 0) {
     g_use_pp = value;
     return VFM_OK;

@@ -517,6 +517,9 @@ def _attn_desc(q, k, v, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale,
     return a
 
 
+_attn_bwd_ws = {}
+
+
 def attn_fwd(q, k, v, o, lse, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale):
     """q,k,v,o: 2-D row-major views [rows, >=H*d] (column slices of a packed qkv buffer are fine)."""
     lib = L.load()
@@ -536,7 +539,11 @@ def attn_bwd(q, k, v, o, lse, dout, dq, dk, dv, B, H, d, nq_main, nq_extra, nk_m
     a.dout, a.ld_do = L.ptr(dout), dout.stride(0)
     a.dq, a.dk, a.dv = L.ptr(dq), L.ptr(dk), L.ptr(dv)
     a.ld_dq, a.ld_dk, a.ld_dv = dq.stride(0), dk.stride(0), dv.stride(0)
-    delta = workspace(B * H * (nq_main + nq_extra), q.device, "attn_delta")
+    # delta[B, H, nq] + the zero-on-entry scratch of the extra-token rows (the kernels leave it zeroed): one buffer per shape
+    key = (str(q.device), B, H, nq_main + nq_extra)
+    delta = _attn_bwd_ws.get(key)
+    if delta is None:
+        delta = _attn_bwd_ws[key] = torch.zeros(B * H * (nq_main + nq_extra) + B * H * 192, dtype=torch.float32, device=q.device)
     a.delta = L.ptr(delta)
     fin = None
     if PROFILE is not None and q.dtype == torch.bfloat16:   # algorithmic: S, dP, dV, dK, dQ = five products = 10 B H Nq Nk d
