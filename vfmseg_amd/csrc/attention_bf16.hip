@@ -204,6 +204,28 @@ __device__ __forceinline__ void cls_partial(float w, const bf16x8 (&f)[4], float
   __builtin_amdgcn_wave_barrier();
 }
 
+// Rank-1 form of ONE extra streamed position (the [cls] key for the query-stationary kernels, the [cls] query for dK/dV): a tile
+// of 64 for a single row would cost 8 + 8 MFMAs and 32 exponentials per wave; the same mathematics is a dot product per lane
+// (its stationary row against the extra row) and one scalar-times-row update of the accumulators.
+__device__ __forceinline__ float dot_frag(const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {   // full 64-column dot (both lane halves)
+  float s = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf((float)a[kk][e], (float)b[kk][e], s);
+  return s + __shfl_xor(s, 32, 64);
+}
+// v[j][r] = X[row, col0 + 32 j + acc_row(r, h)]: a row in the accumulators' (output-column) layout
+__device__ __forceinline__ void load_outcols(const bf16_t* base, long ld, long row, int col0, int h, float (&v)[2][16]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const ushort4 u = *reinterpret_cast<const ushort4*>(base + row * ld + col0 + 32 * j + 8 * g + 4 * h);
+      v[j][4 * g + 0] = bf16_to_f32(u.x), v[j][4 * g + 1] = bf16_to_f32(u.y), v[j][4 * g + 2] = bf16_to_f32(u.z), v[j][4 * g + 3] = bf16_to_f32(u.w);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------ forward
 // NW = waves per block (32 stationary positions each): 4, or 2 for short problems whose 4-wave grid would leave CUs idle
 // (the decoder's 16 (image, head) pairs x 1024 queries are only 128 blocks of 128 queries).
@@ -275,15 +297,46 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
   const float c = p.scale * LOG2E;
   f32x16 oacc[2] = {zero16(), zero16()};
   float m = -INFINITY, l = 0.f;
-  const int nt = (nk + TROWS - 1) / TROWS;
+  // the [cls] key in rank-1 form (4-wave grids): forward always, dQ when the [cls] partial sums are gathered here
+  const bool r1 = NW == 4 && p.nk_extra == 1 && (!DQ || cls_key);
+  const int nk_loop = r1 ? p.nk_main : nk;
+  const int nt = (nk_loop + TROWS - 1) / TROWS;
   auto stage = [&](int buf, int t) {
     char* kt = smem + buf * 2 * TILE_BYTES;
-    stage_tile<NW>(Kb, p.ldk, col0, b, t * TROWS, nk, p.nk_main, p.B, kt, wave, lane);
-    stage_tile<NW>(Vb, p.ldv, col0, b, t * TROWS, nk, p.nk_main, p.B, kt + TILE_BYTES, wave, lane);
+    stage_tile<NW>(Kb, p.ldk, col0, b, t * TROWS, nk_loop, p.nk_main, p.B, kt, wave, lane);
+    stage_tile<NW>(Vb, p.ldv, col0, b, t * TROWS, nk_loop, p.nk_main, p.B, kt + TILE_BYTES, wave, lane);
   };
   // three K/V stages, ONE barrier per tile: the barrier that publishes tile t also certifies that every wave is done with tile
   // t-1, whose stage is the one tile t+2 will be written to (by the stage() call of the NEXT iteration)
   stage(0, 0);
+  // (the extra row's loads are issued behind the first tile's DMA: their latency is the DMA's)
+  if (r1) {
+    const long crow = tok_row(b, p.nk_main, p.nk_main, p.B);
+    bf16x8 kcf[4];
+    load_stationary(Kb, p.ldk, crow, col0, h, kcf);
+    const float s_e = dot_frag(qf, kcf);
+    float oc[2][16];
+    if (!DQ) {   // the online softmax starts from the [cls] key: m = its score, p = 1, O = v_cls
+      load_outcols(Vb, p.ldv, crow, col0, h, oc);
+      m = s_e;
+      l = h == 0 ? 1.f : 0.f;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[j][r] = oc[j][r];
+    } else {     // dS against the [cls] key: dQ^T += dS k_cls; P / dS kept for the [cls] key's own gradients
+      bf16x8 vcf[4];
+      load_stationary(Vb, p.ldv, crow, col0, h, vcf);
+      const float dp_e = dot_frag(dof, vcf);
+      p_cls = __builtin_amdgcn_exp2f(fmaf(s_e, c, -lse_l));
+      ds_cls = p_cls * (dp_e - delta_l);
+      load_outcols(Kb, p.ldk, crow, col0, h, oc);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[j][r] = ds_cls * oc[j][r];
+    }
+  }
   int buf = 0;
   for (int t = 0; t < nt; ++t) {
     const int nbuf = buf == 2 ? 0 : buf + 1;
@@ -302,7 +355,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) sacc[kb] = MFMA(row_frag(kt, kb, kk, lane), qf[kk], sacc[kb]);
-    const bool tail = (t == nt - 1) && (nk % TROWS != 0);
+    const bool tail = (t == nt - 1) && (nk_loop % TROWS != 0);
     if (!DQ) {
       // ---- online softmax over this lane's 32 keys of the tile (the other 32 live in lane ^ 32)
       float mx = -INFINITY;
@@ -311,7 +364,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (t * TROWS + kb * 32 + acc_row(r, h) >= nk) sacc[kb][r] = -INFINITY;
+            if (t * TROWS + kb * 32 + acc_row(r, h) >= nk_loop) sacc[kb][r] = -INFINITY;
       }
       {  // four independent max chains (a single 32-deep dependent chain leaves the VALU idle at two waves per SIMD)
         float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -359,14 +412,13 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
         for (int r = 0; r < 16; ++r) {
           const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -lse_l));
           sacc[kb][r] = pv * (dpacc[kb][r] - delta_l);
-          if (kb == 0 && r == 0) p_cls = pv, ds_cls = sacc[0][0];   // meaningful in the last tile, lanes h == 0
         }
       if (tail) {  asm volatile("" ::: "memory");  // keeps this a real branch; wave-uniform: clamped duplicate keys of the ragged last tile contribute nothing
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (t * TROWS + kb * 32 + acc_row(r, h) >= nk) sacc[kb][r] = 0.f;
+            if (t * TROWS + kb * 32 + acc_row(r, h) >= nk_loop) sacc[kb][r] = 0.f;
       }
     }
     // ---- second product: acc^T[col, query] += tile^T[col x key] * X[key x query]
@@ -386,7 +438,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
       __syncthreads();   // every wave is done with the K/V stages: the LDS becomes reduction scratch
       float* red = reinterpret_cast<float*>(smem) + wave * (32 * 65);
       float* scr = p.cls_scratch + ((long)b * p.H + hh) * 192;
-      float wp = __shfl(p_cls, lane & 31, 64), wd = __shfl(ds_cls, lane & 31, 64);
+      float wp = p_cls, wd = ds_cls;   // (rank-1 form: every lane holds its query's values)
       if (!qvalid) wp = 0.f, wd = 0.f;
       cls_partial(wd, qf, red, lane, scr + 64);    // dK[cls] += sum_q dS[q, cls] q[q, :]
       cls_partial(wp, dof, red, lane, scr + 128);  // dV[cls] += sum_q P[q, cls] dO[q, :]
@@ -446,18 +498,39 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
   const float* del_g = p.delta + ((long)b * p.H + hh) * nq;
   const float c = p.scale * LOG2E;
   f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
-  const int nt = (nq + TROWS - 1) / TROWS;
+  const int nq_loop = cls_query ? p.nq_main : nq;
+  const int nt = (nq_loop + TROWS - 1) / TROWS;
   auto stage = [&](int buf, int t) {
     char* qt = smem + buf * STAGE;
-    stage_tile<NW>(Qb, p.ldq, col0, b, t * TROWS, nq, p.nq_main, p.B, qt, wave, lane);
-    stage_tile<NW>(Ob, p.ld_do, col0, b, t * TROWS, nq, p.nq_main, p.B, qt + TILE_BYTES, wave, lane);
+    stage_tile<NW>(Qb, p.ldq, col0, b, t * TROWS, nq_loop, p.nq_main, p.B, qt, wave, lane);
+    stage_tile<NW>(Ob, p.ld_do, col0, b, t * TROWS, nq_loop, p.nq_main, p.B, qt + TILE_BYTES, wave, lane);
     int qq = t * TROWS + lane;
-    if (qq > nq - 1) qq = nq - 1;
+    if (qq > nq_loop - 1) qq = nq_loop - 1;
     // one 256-byte piece per wave: wave 0 -> lse, wave 1 -> delta, waves 2,3 -> scratch (keeps vmcnt uniform)
     const float* src = (wave & 1) ? del_g : lse_g;
     glds4(src + qq, qt + 2 * TILE_BYTES + wave * 256);
   };
   stage(0, 0);
+  if (cls_query) {   // the [cls] query in rank-1 form: dV^T += P dO_cls, dK^T += dS q_cls; dS kept for dQ[cls]
+    const long crow = tok_row(b, p.nq_main, p.nq_main, p.B);
+    bf16x8 qcf[4], gcf[4];
+    load_stationary(Qb, p.ldq, crow, col0, h, qcf);
+    load_stationary(Ob, p.ld_do, crow, col0, h, gcf);
+    const float s_e = dot_frag(kf, qcf), dp_e = dot_frag(vf, gcf);
+    const float p_e = __builtin_amdgcn_exp2f(fmaf(s_e, c, -lse_g[p.nq_main] * LOG2E));
+    ds_cls = p_e * (dp_e - del_g[p.nq_main]);
+    float oc[2][16];
+    load_outcols(Ob, p.ld_do, crow, col0, h, oc);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dv[j][r] = p_e * oc[j][r];
+    load_outcols(Qb, p.ldq, crow, col0, h, oc);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dk[j][r] = ds_cls * oc[j][r];
+  }
   int buf = 0;
   for (int t = 0; t < nt; ++t) {  // three stages, one barrier per tile (see k_attn_bf16_q)
     const int nbuf = buf == 2 ? 0 : buf + 1;
@@ -473,7 +546,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
     const char* ot = qt + TILE_BYTES;
     const float* lse_s = reinterpret_cast<const float*>(qt + 2 * TILE_BYTES);
     const float* del_s = lse_s + 64;
-    const bool tail = (t == nt - 1) && (nq % TROWS != 0);
+    const bool tail = (t == nt - 1) && (nq_loop % TROWS != 0);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       f32x16 sacc = zero16(), dpacc = zero16();
@@ -494,13 +567,12 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
           const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -lsv[e] * LOG2E));
           pacc[r] = pv;
           sacc[r] = pv * (dpacc[r] - dlv[e]);
-          if (qb == 0 && r == 0) ds_cls = sacc[0];   // dS[cls, key]: meaningful in the last query tile, lanes h == 0
         }
       }
       if (tail) {  asm volatile("" ::: "memory");  // keeps this a real branch; wave-uniform: clamped duplicate queries of the ragged last tile contribute nothing
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (t * TROWS + qb * 32 + acc_row(r, h) >= nq) pacc[r] = 0.f, sacc[r] = 0.f;
+          if (t * TROWS + qb * 32 + acc_row(r, h) >= nq_loop) pacc[r] = 0.f, sacc[r] = 0.f;
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -517,7 +589,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
   if (cls_query) {   // this wave's 32 keys -> contribution to dQ[cls] (unscaled)
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem) + wave * (32 * 65);
-    float wd = __shfl(ds_cls, lane & 31, 64);
+    float wd = ds_cls;   // (rank-1 form: every lane holds its key's value)
     if (!kvalid) wd = 0.f;
     cls_partial(wd, kf, red, lane, p.cls_scratch + ((long)b * p.H + hh) * 192);
   }

@@ -321,6 +321,7 @@ static int g_fold_tail = 1;  // run the tail rows as extra blocks of the tile ke
 // per shape (+2.6 % images/s).  The big-tile kernels win on long-K / light-epilogue shapes (4096^3: 1.26 PF vs 1.0) and stay
 // selectable per call (vfm_tune gemm_cfg 30..33).
 static int g_use_pp = 40;
+static int g_deep_tail_k = 0;  // K from which one-tile-per-CU launches WITH tail blocks take the seven-chunk ring (0 = never)
 extern "C" int vfm_tune(const char* key, int value) {
   if (key && strcmp(key, "gemm_cfg") == 0) {
     g_force_cfg = value;
@@ -334,6 +335,10 @@ extern "C" int vfm_tune(const char* key, int value) {
   if (key && strcmp(key, "attn_lds_pad") == 0) {
     extern int g_attn_lds_pad;
     g_attn_lds_pad = value;
+    return VFM_OK;
+  }
+  if (key && strcmp(key, "gemm_deep_tail_k") == 0) {
+    g_deep_tail_k = value;
     return VFM_OK;
   }
   if (key && strcmp(key, "gemm_use_pp") == 0) {
@@ -456,6 +461,9 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
       cfg = 34;  // same tile and wave layout, operands through the five-chunk (2.5 K-tile) LDS-DMA ring of gemm_w4.hip
     // at most one tile per CU and no tail blocks to squeeze in: the second block's LDS buys a seven-chunk ring instead
     if (cfg == 34 && !tail && t128 <= 256 && d->K >= 256 && d->M % 128 == 0) cfg = 35;
+    // ... and with tail blocks riding along when K is long: one tile per CU streams its operands latency-bound (bytes in flight /
+    // latency), so the deeper ring wins more than the tail blocks lose by waiting for a CU (they cannot share the ring's LDS)
+    if (cfg == 34 && tail && t128 <= 256 && d->M % 128 == 0 && d->K >= g_deep_tail_k && g_deep_tail_k > 0) cfg = 35;
   }
   switch (cfg) {
     case 0: fd = launch_cfg<128, 128, 2, 2, 2>(d, s, vec, tail); break;
