@@ -574,7 +574,7 @@ def test_resize_and_labels():
     assert torch.equal(u.cpu(), e)
 
 
-@pytest.mark.parametrize("h,H", [(32, 128), (8, 128), (16, 16), (12, 48), (128, 512)])
+@pytest.mark.parametrize("h,H", [(32, 128), (8, 128), (16, 16), (12, 48), (128, 512), (3, 5), (32, 512), (7, 100)])
 def test_upsample_ce(h, H):
     B, C = 2, 19
     lg = rnd(B, h, h, C, seed=54, scale=2.0)

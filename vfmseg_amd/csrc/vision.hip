@@ -268,9 +268,12 @@ __global__ void __launch_bounds__(256) k_upsample_ce(const float* __restrict__ l
                                                       float inv_total, float* __restrict__ loss_parts,
                                                       int32_t* __restrict__ counts, float* __restrict__ dlogits) {
   __shared__ float red[4][CE_CMAX + 4];
+  constexpr int PS = CE_CMAX + 1;                // odd stride: the four corner vectors of a lane sit in different banks
+  __shared__ float nb[WPP == 1 ? 4 : 1][9 * PS];  // the 3x3 low-res logit vectors a pixel's members interpolate from
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long pix = WPP == 1 ? (long)blockIdx.x * 4 + wv : (long)blockIdx.x;
-  if (pix >= (long)B * h * w) return;
+  const long pix_raw = WPP == 1 ? (long)blockIdx.x * 4 + wv : (long)blockIdx.x;
+  const bool active = pix_raw < (long)B * h * w;  // tail waves of the WPP==1 form compute on the last pixel, write nothing
+  const long pix = active ? pix_raw : (long)B * h * w - 1;
   const int x = (int)(pix % w);
   const long t = pix / w;
   const int y = (int)(t % h);
@@ -288,6 +291,13 @@ __global__ void __launch_bounds__(256) k_upsample_ce(const float* __restrict__ l
   float loss = 0.f;
   int hits = 0, valid = 0;
   const float* lb = lg + b * (long)h * w * C;
+  float* Ls = nb[WPP == 1 ? wv : 0];
+  for (int i = (WPP == 1 ? lane : (int)threadIdx.x); i < 9 * C; i += 64 * WPP) {
+    const int c = i % C, p = i / C;
+    const int yy = min(max(y - 1 + p / 3, 0), h - 1), xx = min(max(x - 1 + p % 3, 0), w - 1);
+    Ls[p * PS + c] = lb[((long)yy * w + xx) * C + c];
+  }
+  __syncthreads();
   for (int i = (WPP == 1 ? lane : (int)threadIdx.x); i < nx * ny; i += 64 * WPP) {
     const int hy = hy0 + i / nx, hx = hx0 + i % nx;
     const Lerp ly = lerp_idx(hy, sy, h), lx = lerp_idx(hx, sx, w);
@@ -299,10 +309,11 @@ __global__ void __launch_bounds__(256) k_upsample_ce(const float* __restrict__ l
     const bool is_valid = lab != ignore;
     const bool owner = (ly.i0 == y) && (lx.i0 == x);
     if (!is_valid && !owner) continue;
-    const float* p00 = lb + ((long)ly.i0 * w + lx.i0) * C;
-    const float* p01 = lb + ((long)ly.i0 * w + lx.i1) * C;
-    const float* p10 = lb + ((long)ly.i1 * w + lx.i0) * C;
-    const float* p11 = lb + ((long)ly.i1 * w + lx.i1) * C;
+    // members have i0 in {y-1, y} and i1 in {y, y+1}
+    const float* p00 = Ls + ((ly.i0 - y + 1) * 3 + (lx.i0 - x + 1)) * PS;
+    const float* p01 = Ls + ((ly.i0 - y + 1) * 3 + (lx.i1 - x + 1)) * PS;
+    const float* p10 = Ls + ((ly.i1 - y + 1) * 3 + (lx.i0 - x + 1)) * PS;
+    const float* p11 = Ls + ((ly.i1 - y + 1) * 3 + (lx.i1 - x + 1)) * PS;
     float v[CE_CMAX];
     float m = -INFINITY;
     int am = 0;
@@ -351,11 +362,11 @@ __global__ void __launch_bounds__(256) k_upsample_ce(const float* __restrict__ l
       for (int c = 0; c < CE_CMAX; ++c) {
         if (c < C) {
           const float s = wave_sum(acc[c]);
-          if (lane == 0) dlogits[pix * C + c] = s;
+          if (lane == 0 && active) dlogits[pix * C + c] = s;
         }
       }
     }
-    if (lane == 0) {
+    if (lane == 0 && active) {
       loss_parts[pix] = loss;
       if (valid) {
         atomicAdd(&counts[0], hits);
@@ -392,121 +403,139 @@ __global__ void __launch_bounds__(256) k_upsample_ce(const float* __restrict__ l
     }
   }
 }
-// Tiled form for integer scale factors S (H = S*h, W = S*w; the x4 LinearHead loss): a block owns T x T low-res pixels.
-//   1. the (T+2)^2 low-res logit vectors it touches go to LDS,
-//   2. every high-res pixel of the (T+1)S x (T+1)S region whose footprint touches an owned pixel gets its interpolated
-//      logits / softmax ONCE per block (all operands from LDS): probabilities, label, loss term are kept in LDS,
-//   3. each (owned pixel, class) pair gathers its gradient from its 2S x 2S members in a fixed order (no float atomics,
-//      bitwise reproducible); class 0's thread also accounts the loss / accuracy of the high-res pixels the pixel owns.
-// The one-wave-per-low-res-pixel kernel above spends its time in uncoalesced 4-byte loads (76 per candidate) and visits
-// every high-res pixel four times; here the redundancy is ((T+1)/T)^2 and global memory sees each operand once.
-template <int S, int T>
+// Tiled form for integer scale factors S and a compile-time class count (H = S*h, W = S*w; the x4 LinearHead and x16 VFMHead
+// losses with 19 classes): a block owns T x T low-res pixels, i.e. a (T+1)S x (T+1)S high-res region, walked in strips of RS rows.
+//   1. the (T+2)^2 low-res logit vectors it touches and the 2S bilinear weights of each owned row / column go to LDS; every
+//      thread fetches the labels of all its high-res pixels up front (one exposed global latency per block),
+//   2. per strip, every high-res pixel gets its interpolated logits / softmax ONCE per block (operands from LDS) and leaves
+//      d = softmax - onehot in LDS (0 outside the image / ignored); the thread also accounts loss / accuracy of the pixels whose
+//      owner (i0y, i0x) lies in the tile,
+//   3. the gather is separable: a horizontal pass per strip (RS x T x C sums of 2S terms) and one vertical pass (T x T x C sums
+//      of 2S terms), each in a fixed order (no float atomics, bitwise reproducible).
+// LDS per block is 25-40 KB and the kernel stays under 128 VGPRs, so four or more blocks share a CU; the redundancy is
+// ((T+1)/T)^2 softmax evaluations per high-res pixel, which is cheap next to the exposed latencies of an under-occupied CU.
+// The block's loss goes to loss_parts[first owned pixel]; its other owned pixels get 0.
+template <int S, int T, int C, int RS>
 __global__ void __launch_bounds__(256) k_upsample_ce_tile(const float* __restrict__ lg, const int64_t* __restrict__ label, int B, int h,
-                                                           int w, int C, int H, int W, int ignore, float inv_total,
+                                                           int w, int H, int W, int ignore, float inv_total,
                                                            float* __restrict__ loss_parts, int32_t* __restrict__ counts,
                                                            float* __restrict__ dlogits) {
-  constexpr int R = (T + 1) * S, LT = T + 2, PS = CE_CMAX + 1;  // odd LDS stride: conflict-free per-pixel vectors
-  extern __shared__ float ce_smem[];
-  float* Ls = ce_smem;                    // [LT*LT][C]
-  float* Ps = Ls + LT * LT * PS;     // [R*R][C]   probabilities
-  float* Lv = Ps + R * R * PS;       // [R*R]      loss term (lse - v[label]) of valid pixels
-  int* Lb = (int*)(Lv + R * R);           // [R*R]      label, -1 = outside the image / ignored; bit 8 set = arg-max hit
-  __shared__ int cnt_s[2];
-  const int tid = threadIdx.x;
-  if (tid < 2) cnt_s[tid] = 0;
+  constexpr int R = (T + 1) * S, LT = T + 2, PS = C | 1;  // odd LDS stride: conflict-free per-pixel vectors
+  constexpr int NSTRIP = R / RS, PPT = (RS * R + 255) / 256;
+  static_assert(R % RS == 0, "strips tile the region");
+  __shared__ float Ls[LT * LT * PS];  // low-res logits
+  __shared__ float Ds[RS * R * PS];   // softmax - onehot per high-res pixel of the strip
+  __shared__ float Hs[R * T * PS];    // horizontal pass
+  __shared__ float Wy[T][2 * S], Wx[T][2 * S];
+  __shared__ float red_l[4];
+  __shared__ int red_h[4], red_v[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int tiles_x = w / T, tiles_y = h / T;
   const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y;
   const long b = blockIdx.x / (tiles_x * tiles_y);
   const int y0 = by * T, x0 = bx * T;
   const float sc = 1.0f / S;
+  const int hy_base = S * y0 - S / 2, hx_base = S * x0 - S / 2;
   const float* lb = lg + b * (long)h * w * C;
+  int labs[NSTRIP * PPT];  // -1: outside the image / ignored / no pixel
+#pragma unroll
+  for (int k = 0; k < NSTRIP * PPT; ++k) {
+    const int i = tid + (k % PPT) * 256;
+    const int hy = hy_base + (k / PPT) * RS + i / R, hx = hx_base + i % R;
+    int lab = -1;
+    if (i < RS * R && hy >= 0 && hy < H && hx >= 0 && hx < W) {
+      const int64_t l64 = label[(b * H + hy) * (long)W + hx];
+      if (l64 != ignore) lab = (int)l64;
+    }
+    labs[k] = lab;
+  }
   for (int i = tid; i < LT * LT * C; i += 256) {
     const int c = i % C, p = i / C;
     const int yy = min(max(y0 - 1 + p / LT, 0), h - 1), xx = min(max(x0 - 1 + p % LT, 0), w - 1);
     Ls[p * PS + c] = lb[((long)yy * w + xx) * C + c];
   }
-  __syncthreads();
-  const int hy_base = S * y0 - S / 2, hx_base = S * x0 - S / 2;
-  for (int i = tid; i < R * R; i += 256) {
-    const int ry = i / R, rx = i % R;
-    const int hy = hy_base + ry, hx = hx_base + rx;
-    int lab = -1;
-    float lossv = 0.f;
-    if (hy >= 0 && hy < H && hx >= 0 && hx < W) {
-      const int64_t l64 = label[(b * H + hy) * (long)W + hx];
-      if (l64 != ignore) {
-        lab = (int)l64;
+  for (int i = tid; i < 2 * T * 2 * S; i += 256) {  // the share of owned row / column t in member d (0 outside the image)
+    const int d = i % (2 * S), t = (i / (2 * S)) % T, isx = i / (2 * S * T);
+    const int hp = (isx ? hx_base : hy_base) + t * S + d, own = (isx ? x0 : y0) + t, lim = isx ? W : H;
+    float wgt = 0.f;
+    if (hp >= 0 && hp < lim) {
+      const Lerp l = lerp_idx(hp, sc, isx ? w : h);
+      wgt = (l.i0 == own ? l.l0 : 0.f) + (l.i1 == own ? l.l1 : 0.f);
+    }
+    if (isx) Wx[t][d] = wgt * inv_total;
+    else Wy[t][d] = wgt;
+  }
+  float loss = 0.f;
+  int hits = 0, valid = 0;
+#pragma unroll
+  for (int st = 0; st < NSTRIP; ++st) {
+    __syncthreads();  // Ls / weights ready (st == 0); previous strip's horizontal pass done with Ds
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int i = tid + j * 256;
+      if (i >= RS * R) break;
+      const int lab = labs[st * PPT + j];
+      float v[C];
+      if (lab >= 0) {
+        const int hy = hy_base + st * RS + i / R, hx = hx_base + i % R;
         const Lerp ly = lerp_idx(hy, sc, h), lx = lerp_idx(hx, sc, w);
         const float* p00 = Ls + ((ly.i0 - y0 + 1) * LT + (lx.i0 - x0 + 1)) * PS;
         const float* p01 = Ls + ((ly.i0 - y0 + 1) * LT + (lx.i1 - x0 + 1)) * PS;
         const float* p10 = Ls + ((ly.i1 - y0 + 1) * LT + (lx.i0 - x0 + 1)) * PS;
         const float* p11 = Ls + ((ly.i1 - y0 + 1) * LT + (lx.i1 - x0 + 1)) * PS;
-        float v[CE_CMAX];
         float m = -INFINITY, vl = 0.f;
         int am = 0;
 #pragma unroll
-        for (int c = 0; c < CE_CMAX; ++c) {
-          if (c < C) {
-            v[c] = ly.l0 * (lx.l0 * p00[c] + lx.l1 * p01[c]) + ly.l1 * (lx.l0 * p10[c] + lx.l1 * p11[c]);
-            if (v[c] > m) m = v[c], am = c;
-            if (c == lab) vl = v[c];
-          }
+        for (int c = 0; c < C; ++c) {
+          v[c] = ly.l0 * (lx.l0 * p00[c] + lx.l1 * p01[c]) + ly.l1 * (lx.l0 * p10[c] + lx.l1 * p11[c]);
+          if (v[c] > m) m = v[c], am = c;
+          if (c == lab) vl = v[c];
         }
         float se = 0.f;
 #pragma unroll
-        for (int c = 0; c < CE_CMAX; ++c)
-          if (c < C) v[c] = __expf(v[c] - m), se += v[c];
+        for (int c = 0; c < C; ++c) v[c] = __expf(v[c] - m), se += v[c];
         const float inv_se = 1.f / se;
 #pragma unroll
-        for (int c = 0; c < CE_CMAX; ++c)
-          if (c < C) Ps[i * PS + c] = v[c] * inv_se;
-        lossv = m + __logf(se) - vl;
-        if (am == lab) lab |= 256;
-      }
-    }
-    Lb[i] = lab;
-    Lv[i] = lossv;
-  }
-  __syncthreads();
-  for (int task = tid; task < T * T * C; task += 256) {
-    const int c = task % C, lp = task / C;
-    const int ty = lp / T, tx = lp % T;
-    const int y = y0 + ty, x = x0 + tx;
-    float g = 0.f, loss = 0.f;
-    int hits = 0, valid = 0;
-    for (int dy = 0; dy < 2 * S; ++dy) {
-      const int ry = ty * S + dy, hy = hy_base + ry;
-      if (hy < 0 || hy >= H) continue;
-      const Lerp ly = lerp_idx(hy, sc, h);
-      const float wy = (ly.i0 == y ? ly.l0 : 0.f) + (ly.i1 == y ? ly.l1 : 0.f);
-      for (int dx = 0; dx < 2 * S; ++dx) {
-        const int rx = tx * S + dx, hx = hx_base + rx;
-        if (hx < 0 || hx >= W) continue;
-        const int i = ry * R + rx;
-        const int lab = Lb[i];
-        if (lab < 0) continue;
-        const Lerp lx = lerp_idx(hx, sc, w);
-        const float wx = (lx.i0 == x ? lx.l0 : 0.f) + (lx.i1 == x ? lx.l1 : 0.f);
-        g += wy * wx * inv_total * (Ps[i * PS + c] - ((lab & 255) == c ? 1.f : 0.f));
-        if (c == 0 && ly.i0 == y && lx.i0 == x) {
-          loss += Lv[i];
+        for (int c = 0; c < C; ++c) v[c] = v[c] * inv_se - (c == lab ? 1.f : 0.f);
+        if (ly.i0 >= y0 && ly.i0 < y0 + T && lx.i0 >= x0 && lx.i0 < x0 + T) {
+          loss += m + __logf(se) - vl;
           valid += 1;
-          hits += (lab >> 8) & 1;
+          hits += am == lab ? 1 : 0;
         }
       }
+#pragma unroll
+      for (int c = 0; c < C; ++c) Ds[i * PS + c] = lab >= 0 ? v[c] : 0.f;
     }
-    const long pix = (b * h + y) * (long)w + x;
-    if (dlogits) dlogits[pix * C + c] = g;
-    if (c == 0) {
-      loss_parts[pix] = loss;
-      if (valid) {  // block-level tally first: same-address global atomics serialise (2 per low-res pixel cost ~250 us)
-        atomicAdd(&cnt_s[0], hits);
-        atomicAdd(&cnt_s[1], valid);
-      }
+    __syncthreads();
+    for (int task = tid; task < RS * T * C; task += 256) {
+      const int c = task % C, tx = (task / C) % T, ry = task / (C * T);
+      const float* dp = Ds + (ry * R + tx * S) * PS + c;
+      float acc = 0.f;
+#pragma unroll
+      for (int dx = 0; dx < 2 * S; ++dx) acc += Wx[tx][dx] * dp[dx * PS];
+      Hs[((st * RS + ry) * T + tx) * PS + c] = acc;
     }
   }
+  loss = wave_sum(loss);
+  for (int o = 32; o > 0; o >>= 1) {
+    hits += __shfl_xor(hits, o, 64);
+    valid += __shfl_xor(valid, o, 64);
+  }
+  if (lane == 0) red_l[wv] = loss, red_h[wv] = hits, red_v[wv] = valid;
   __syncthreads();
-  if (tid < 2 && cnt_s[tid]) atomicAdd(&counts[tid], cnt_s[tid]);
+  for (int task = tid; task < T * T * C; task += 256) {
+    const int c = task % C, tx = (task / C) % T, ty = task / (C * T);
+    const float* hp = Hs + (ty * S * T + tx) * PS + c;
+    float g = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2 * S; ++dy) g += Wy[ty][dy] * hp[dy * T * PS];
+    if (dlogits) dlogits[((b * h + y0 + ty) * (long)w + x0 + tx) * C + c] = g;
+  }
+  if (tid < T * T) loss_parts[(b * h + y0 + tid / T) * (long)w + x0 + tid % T] = tid ? 0.f : (red_l[0] + red_l[1]) + (red_l[2] + red_l[3]);
+  if (tid < 2) {  // one global tally per block: same-address global atomics serialise
+    const int n = tid ? (red_v[0] + red_v[1]) + (red_v[2] + red_v[3]) : (red_h[0] + red_h[1]) + (red_h[2] + red_h[3]);
+    if (n) atomicAdd(&counts[tid], n);
+  }
 }
 
 extern "C" int vfm_upsample_ce(const float* logits_low, const int64_t* label, int B, int h, int w, int C, int H, int W,
@@ -516,11 +545,12 @@ extern "C" int vfm_upsample_ce(const float* logits_low, const int64_t* label, in
   const long npix = (long)B * h * w;
   if (npix == 0) return VFM_OK;
   const bool big = ((long)H * W) >= 64L * h * w;  // footprint (2*scale)^2 >= 256 candidates per low-res pixel
-  if (H == 4 * h && W == 4 * w && h % 4 == 0 && w % 4 == 0) {
-    constexpr int S = 4, T = 4, R = (T + 1) * S, LT = T + 2;
-    const size_t smem = (size_t)(LT * LT * (CE_CMAX + 1) + R * R * (CE_CMAX + 1) + 2 * R * R) * 4;
-    hipLaunchKernelGGL((k_upsample_ce_tile<S, T>), dim3((unsigned)(B * (h / T) * (w / T))), dim3(256), smem, (hipStream_t)stream,
-                       logits_low, label, B, h, w, C, H, W, ignore_index, 1.0f / ((float)B * H * W), loss_parts, counts, dlogits);
+  if (H == 4 * h && W == 4 * w && h % 4 == 0 && w % 4 == 0 && C == 19) {
+    hipLaunchKernelGGL((k_upsample_ce_tile<4, 4, 19, 20>), dim3((unsigned)(B * (h / 4) * (w / 4))), dim3(256), 0, (hipStream_t)stream,
+                       logits_low, label, B, h, w, H, W, ignore_index, 1.0f / ((float)B * H * W), loss_parts, counts, dlogits);
+  } else if (H == 16 * h && W == 16 * w && C == 19) {
+    hipLaunchKernelGGL((k_upsample_ce_tile<16, 1, 19, 8>), dim3((unsigned)npix), dim3(256), 0, (hipStream_t)stream, logits_low, label, B,
+                       h, w, H, W, ignore_index, 1.0f / ((float)B * H * W), loss_parts, counts, dlogits);
   } else if (big)
     hipLaunchKernelGGL(k_upsample_ce<4>, dim3((unsigned)npix), dim3(256), 0, (hipStream_t)stream, logits_low, label, B, h, w, C, H, W,
                        ignore_index, (float)h / (float)H, (float)w / (float)W, 1.0f / ((float)B * H * W), loss_parts, counts,
