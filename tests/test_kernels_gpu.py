@@ -472,11 +472,14 @@ def test_gemm_bf16_transposed_b(P, M, Q):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("nq_extra,nk_extra,nq,nk", [(1, 1, 200, 200), (0, 0, 256, 256), (0, 0, 130, 70), (1, 1, 1024, 1024), (1, 1, 128, 384)])
-def test_attention(dt, nq_extra, nk_extra, nq, nk):
-    # (B, H) = (2, 3): short grids -> the 2-wave-per-block kernels; the 1024-token case runs with 40 (image, head) pairs so that
-    # the 4-wave kernels and their single-row [cls] blocks (last linear block ids) are exercised as in the backbones
-    B, H, d = (2, 3, 64) if nq < 1024 else (5, 8, 64)
+@pytest.mark.parametrize("nq_extra,nk_extra,nq,nk,B1024", [(1, 1, 200, 200, 0), (0, 0, 256, 256, 0), (0, 0, 130, 70, 0), (1, 1, 1024, 1024, 6),
+                                                            (1, 1, 128, 384, 0), (0, 0, 512, 512, 0), (1, 1, 1024, 1024, 5)])
+def test_attention(dt, nq_extra, nk_extra, nq, nk, B1024):
+    # (B, H) = (2, 3): short grids -> the 2-wave-per-block kernels; the 1024-token case runs with 48 (image, head) pairs and the
+    # 512-token case with 96 (192 blocks of 256 queries) so that the 64-queries-per-wave forward, the 4-wave backward kernels and
+    # their single-row [cls] blocks (last linear block ids) are exercised as in the backbones; with 40 pairs the 1024-token case
+    # stays on the 32-queries-per-wave forward
+    B, H, d = (2, 3, 64) if nq < 512 else ((12, 8, 64) if nq == 512 else (B1024, 8, 64))
     hd = H * d
     tol = 2e-5 if dt == torch.float32 else 2e-2
     # token-major buffers: main tokens first, then the per-image extra (cls) rows
@@ -517,6 +520,25 @@ def test_attention(dt, nq_extra, nk_extra, nq, nk):
     assert relerr(dq.float(), scatter(qq.grad, nq, nq_extra)) < tol * 2
     assert relerr(dk.float(), scatter(kk.grad, nk, nk_extra)) < tol * 2
     assert relerr(dv.float(), scatter(vv.grad, nk, nk_extra)) < tol * 2
+
+
+def test_attention_fwd64_experimental():
+    # the 64-queries-per-wave forward (vfm_tune attn_fwd64, off by default) against the regular kernel on the backbone shape
+    from vfmseg_amd import lib as L
+    B, H, d, n = 4, 16, 64, 1024
+    lib = L.load()
+    for ex in (1, 0):
+        q, k, v = [rnd(B * n + B * ex, H * d, seed=60 + i).to(torch.bfloat16).to(DEV) for i in range(3)]
+        outs = []
+        for mode in (0, 1):
+            assert lib.vfm_tune(b"attn_fwd64", mode) == 0
+            o = torch.empty_like(q)
+            lse = torch.empty(B, H, n + ex, device=DEV)
+            ops.attn_fwd(q, k, v, o, lse, B, H, d, n, ex, n, ex, d ** -0.5)
+            outs.append((o.float(), lse.clone()))
+        lib.vfm_tune(b"attn_fwd64", 0)
+        assert relerr(outs[1][0], outs[0][0]) < 1e-2
+        assert (outs[1][1] - outs[0][1]).abs().max().item() < 2e-3
 
 
 def test_patchify_tokens():

@@ -10,221 +10,7 @@
 // The streamed operand (K,V / Q,dO) is staged in 64-row LDS tiles by LDS-DMA (global_load_lds_dwordx4), double
 // buffered, 16-byte chunks XOR-swizzled by row so that both the row reads (ds_read_b128, first product) and the
 // transposed reads (ds_read_b64_tr_b16, second product) spread over the banks.
-#include "attn_common.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-#define TROWS 64
-#define TILE_BYTES (TROWS * 128)
-#define LOG2E 1.4426950408889634f
-
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
-__device__ __forceinline__ void glds4(const void* g, void* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 4, 0, 0);
-}
-__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// stage one [64 x 64] bf16 tile: sequence positions s0..s0+63 of image b (clamped), columns col0..col0+63
-template <int NW = 4>
-__device__ __forceinline__ void stage_tile(const bf16_t* base, long ld, int col0, int b, int s0, int n, int n_main, int B, char* tile,
-                                           int wave, int lane) {
-#pragma unroll
-  for (int j = 0; j < 8 / NW; ++j) {
-    const int piece = wave * (8 / NW) + j;
-    const int r = piece * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ swz(r);
-    int s = s0 + r;
-    if (s > n - 1) s = n - 1;
-    glds16(base + tok_row(b, s, n_main, B) * ld + col0 + c * 8, tile + piece * 1024);
-  }
-}
-// first-product A operand: rows rb*32 + (lane&31), 8 consecutive columns of k-step kk (16 columns per step)
-__device__ __forceinline__ bf16x8 row_frag(const char* tile, int rb, int kk, int lane) {
-  const int r = rb * 32 + (lane & 31);
-  return *reinterpret_cast<const bf16x8*>(tile + r * 128 + (((2 * kk + (lane >> 5)) ^ swz(r)) << 4));
-}
-// second-product A operand = (tile^T)[32 columns of block j][16 rows of step s in row-block rb], delivered in the
-// permuted k order of an accumulator-derived B operand: element e <-> tile row rb*32 + 16s + 8(e>>2) + 4h + (e&3)
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rb, int s, int j, int lane) {
-  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, h = g >> 1;
-  const int chunk = 4 * j + 2 * (g & 1) + (p >> 1);
-  const int r0 = rb * 32 + 16 * s + 4 * h + q;
-  const int r1 = r0 + 8;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4*)(tile + r0 * 128 + ((chunk ^ swz(r0)) << 4) + ((p & 1) << 3)));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4*)(tile + r1 * 128 + ((chunk ^ swz(r1)) << 4) + ((p & 1) << 3)));
-  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
-  u.s.a = lo;
-  u.s.b = hi;
-  return u.v;
-}
-// registers 8s..8s+7 of a 32x32 f32 accumulator -> bf16x8 B operand of k-step s
-__device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
-  bf16x8 r;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) r[e] = (__bf16)a[8 * s + e];
-  return r;
-}
-__device__ __forceinline__ f32x16 zero16() {
-  f32x16 z;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) z[i] = 0.f;
-  return z;
-}
-__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }  // row of register r
-
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
-
-// load the stationary operand's B fragments: 4 k-steps x 8 bf16 of row `row`, columns col0 + 16kk + 8h ..
-__device__ __forceinline__ void load_stationary(const bf16_t* base, long ld, long row, int col0, int h, bf16x8 (&f)[4]) {
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) f[kk] = *reinterpret_cast<const bf16x8*>(base + row * ld + col0 + 16 * kk + 8 * h);
-}
-
-// ------------------------------------------------------------------------------------------- single extra row ([cls])
-// With the cls-last layout a ViT sequence is nq_main = 1024 patch tokens + 1 [cls] token: as a 9th query block (one valid
-// query in 128) and a 9th key block it made 576 equal-cost blocks for 512 resident slots (+30 % forward, +21 % backward).
-// The block that owns only the extra row runs these VALU paths instead: dot products with v_dot2c_f32_bf16, one thread
-// per streamed row for the scores, (row group, 8 columns) per thread for the weighted sums, fixed-order LDS reductions.
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float dot2u(unsigned a, unsigned b, float acc) {
-  return __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<bf16x2v*>(&a), *reinterpret_cast<bf16x2v*>(&b), acc, false);
-}
-__device__ __forceinline__ float dot8(uint4 a, uint4 b) {
-  return dot2u(a.w, b.w, dot2u(a.z, b.z, dot2u(a.y, b.y, dot2u(a.x, b.x, 0.f))));
-}
-__device__ __forceinline__ float sum8(float v) {  // over the 8 lanes that share a row
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  return v;
-}
-__device__ __forceinline__ void fma8(float (&acc)[8], float w, uint4 x) {
-  acc[0] = fmaf(w, __uint_as_float(x.x << 16), acc[0]), acc[1] = fmaf(w, __uint_as_float(x.x & 0xffff0000u), acc[1]);
-  acc[2] = fmaf(w, __uint_as_float(x.y << 16), acc[2]), acc[3] = fmaf(w, __uint_as_float(x.y & 0xffff0000u), acc[3]);
-  acc[4] = fmaf(w, __uint_as_float(x.z << 16), acc[4]), acc[5] = fmaf(w, __uint_as_float(x.z & 0xffff0000u), acc[5]);
-  acc[6] = fmaf(w, __uint_as_float(x.w << 16), acc[6]), acc[7] = fmaf(w, __uint_as_float(x.w & 0xffff0000u), acc[7]);
-}
-// out[d] = mult * sum_i w[i] * X[row(i)][col0 + d], i < n: thread (i-group tid>>3, 8 columns tid&7), then 32-way LDS reduce
-__device__ __forceinline__ void weighted_rowsum(const float* w, const bf16_t* X, long ld, int col0, int b, int n, int n_main, int B,
-                                                float mult, float* red, bf16_t* out) {
-  const int tid = threadIdx.x, kg = tid >> 3, d8 = tid & 7;
-  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-  for (int i = kg; i < n; i += 32)
-    fma8(acc, w[i], *reinterpret_cast<const uint4*>(X + tok_row(b, i, n_main, B) * ld + col0 + d8 * 8));
-#pragma unroll
-  for (int e = 0; e < 8; ++e) red[kg * 64 + d8 * 8 + e] = acc[e];
-  __syncthreads();
-  if (tid < 64) {
-    float o = 0.f;
-    for (int g = 0; g < 32; ++g) o += red[g * 64 + tid];
-    out[tid] = f32_to_bf16(o * mult);
-  }
-  __syncthreads();
-}
-#define ATTN_EXTRA_MAX 2048  // the score arrays live in the kernels' 32-KiB staging area
-
-// Scores: 8 lanes per streamed row (16 B each, one 128-B row per 8 lanes), 32 rows per step, 4 steps in flight.
-__device__ void attn_extra_fwd(const AttnP& p, int b, int hh, int qi, char* smem) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = tid & 7, rg = tid >> 3;
-  const int nk = p.nk_main + p.nk_extra, nq = p.nq_main + p.nq_extra;
-  float* sc = reinterpret_cast<float*>(smem);
-  float* red = sc + ATTN_EXTRA_MAX + 64;
-  float* sh = red + 32 * 64;
-  const int col0 = hh * 64;
-  const long qrow = tok_row(b, qi, p.nq_main, p.B);
-  const uint4 q8 = *reinterpret_cast<const uint4*>((const bf16_t*)p.q + qrow * p.ldq + col0 + sub * 8);
-  const bf16_t* Kc = (const bf16_t*)p.k + col0 + sub * 8;
-  float mx = -INFINITY;
-  for (int k0 = 0; k0 < nk; k0 += 128) {
-    uint4 kv[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = min(k0 + u * 32 + rg, nk - 1);
-      kv[u] = *reinterpret_cast<const uint4*>(Kc + tok_row(b, k, p.nk_main, p.B) * p.ldk);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = k0 + u * 32 + rg;
-      const float sv = sum8(dot8(q8, kv[u])) * p.scale;
-      if (k < nk) {
-        if (sub == 0) sc[k] = sv;
-        mx = fmaxf(mx, sv);
-      }
-    }
-  }
-  mx = wave_max(mx);
-  if (lane == 0) sh[wave] = mx;
-  __syncthreads();
-  const float m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
-  float sum = 0.f;
-  for (int k = tid; k < nk; k += 256) {
-    const float pv = __expf(sc[k] - m);
-    sc[k] = pv;
-    sum += pv;
-  }
-  sum = wave_sum(sum);
-  if (lane == 0) sh[4 + wave] = sum;
-  __syncthreads();
-  const float l = (sh[4] + sh[5]) + (sh[6] + sh[7]);
-  weighted_rowsum(sc, (const bf16_t*)p.v, p.ldv, col0, b, nk, p.nk_main, p.B, 1.f / l, red, (bf16_t*)p.o + qrow * p.ldo + col0);
-  if (tid == 0 && p.lse) p.lse[((long)b * p.H + hh) * nq + qi] = m + __logf(l);
-}
-// ------------------------------------------------------------------------------------------- [cls] row of the backward
-// The [cls] token (sequence position n_main, stored after all patch tokens) used to get VALU blocks of its own in the dQ and
-// dK/dV kernels: 64 serial blocks at the end of a 512-block grid (+30 us of a 121-us backward at bs 2).  Its gradients are
-// instead gathered where the products already exist: the ragged last tile of every regular block holds, for each of its 32
-// stationary positions, P and dS against the [cls] token in one accumulator register; the sum over the positions of
-// (that scalar) x (the position's stationary row) is this block's contribution, reduced through a wave-private LDS image and
-// added to an fp32 scratch row with one atomic instruction per wave.  k_attn_cls_finish adds the ([cls], [cls]) pair and
-// writes the three bf16 rows.  (fp32 atomics: the summation order over the 32 waves of an (image, head) pair is not fixed, so
-// these three rows are reproducible to fp32 rounding, not bitwise.)
-//   out[col] += sum_i w[i] * F_i[col]:  w = per-lane scalar (already broadcast to both halves), f = the lane's stationary
-//   fragments (columns 16 kk + 8 h + e), red = 32 x 65 floats of LDS owned by this wave
-__device__ __forceinline__ void cls_partial(float w, const bf16x8 (&f)[4], float* red, int lane, float* dst) {
-  const int fr = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[fr * 65 + 16 * kk + 8 * h + e] = w * (float)f[kk][e];
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-  float sv = 0.f;
-#pragma unroll 8
-  for (int i = 0; i < 32; ++i) sv += red[i * 65 + lane];
-  atomicAdd(dst + lane, sv);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
-
-// Rank-1 form of ONE extra streamed position (the [cls] key for the query-stationary kernels, the [cls] query for dK/dV): a tile
-// of 64 for a single row would cost 8 + 8 MFMAs and 32 exponentials per wave; the same mathematics is a dot product per lane
-// (its stationary row against the extra row) and one scalar-times-row update of the accumulators.
-__device__ __forceinline__ float dot_frag(const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {   // full 64-column dot (both lane halves)
-  float s = 0.f;
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s = fmaf((float)a[kk][e], (float)b[kk][e], s);
-  return s + __shfl_xor(s, 32, 64);
-}
-// v[j][r] = X[row, col0 + 32 j + acc_row(r, h)]: a row in the accumulators' (output-column) layout
-__device__ __forceinline__ void load_outcols(const bf16_t* base, long ld, long row, int col0, int h, float (&v)[2][16]) {
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const ushort4 u = *reinterpret_cast<const ushort4*>(base + row * ld + col0 + 32 * j + 8 * g + 4 * h);
-      v[j][4 * g + 0] = bf16_to_f32(u.x), v[j][4 * g + 1] = bf16_to_f32(u.y), v[j][4 * g + 2] = bf16_to_f32(u.z), v[j][4 * g + 3] = bf16_to_f32(u.w);
-    }
-}
+#include "attn_bf16_dev.h"
 
 // ------------------------------------------------------------------------------------------------------ forward
 // NW = waves per block (32 stationary positions each): 4, or 2 for short problems whose 4-wave grid would leave CUs idle
@@ -277,7 +63,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
       for (int e2 = 0; e2 < 8; ++e2) dsum = fmaf((float)dof[kk][e2], (float)of[kk][e2], dsum);
-    delta_l = dsum + __shfl_xor(dsum, 32, 64);
+    delta_l = half_sum(dsum);
     if (qvalid && h == 0) p.delta[((long)b * p.H + hh) * nq + qi] = delta_l;
     if (cls_key && p.nq_extra == 1 && bx == 0 && wave == 0) {   // delta of the [cls] query, for the dK/dV kernel's last query tile
       const long crow = tok_row(b, p.nq_main, p.nq_main, p.B);
@@ -289,7 +75,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
         for (int e2 = 0; e2 < 8; ++e2) cs = fmaf((float)cg[kk][e2], (float)co[kk][e2], cs);
-      cs += __shfl_xor(cs, 32, 64);
+      cs = half_sum(cs);
       if (lane == 0) p.delta[((long)b * p.H + hh) * nq + p.nq_main] = cs;
     }
   }
@@ -374,7 +160,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
           for (int r = 0; r < 16; ++r) m4[r & 3] = fmaxf(m4[r & 3], sacc[kb][r]);
         mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = half_max(mx);
       // lazy rescale: the reference maximum m only moves when the tile maximum exceeds it by more than 2^8 in the exp2
       // domain (p <= 256 stays exact enough in bf16 / fp32 sums); after the first tiles the 32 accumulator rescales and
       // the alpha exp are skipped for the whole wave.  m = -inf on the first tile, so it always takes the update there.
@@ -447,7 +233,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
   // ---- epilogue: lane = query, registers = output columns acc_row(r, h) + 32 j
   float mult;
   if (!DQ) {
-    l += __shfl_xor(l, 32, 64);
+    l = half_sum(l);
     mult = 1.f / l;
     if (qvalid && h == 0 && p.lse) p.lse[((long)b * p.H + hh) * nq + qi] = m * p.scale + __logf(l);
   } else {
@@ -625,11 +411,17 @@ static bool aligned_ok(const vfm_attn_desc* d, bool bwd) {
 // 2-wave blocks when the 4-wave grid would not even give every CU one block
 static bool short_grid(const vfm_attn_desc* d, int n) { return (long)cdiv(n, 128) * d->B * d->H < 256; }
 
+int g_attn_fwd64 = 0;     // vfm_tune("attn_fwd64"): 1 = use the experimental 64-queries-per-wave forward (attention_fwd64.hip) where it fits
+bool vfm_attn_fwd64_launch(const vfm_attn_desc* d, const AttnP& p, hipStream_t s);
 int g_attn_lds_pad = 0;   // vfm_tune("attn_lds_pad"): extra dynamic LDS per forward block (occupancy experiments)
 int vfm_attn_bf16_fwd_impl(const vfm_attn_desc* d, hipStream_t s) {
   VFM_CHECK(aligned_ok(d, false), VFM_E_ALIGN, "vfm_attn_fwd(bf16): operands must be 16-byte aligned, ld %% 8 == 0");
   const AttnP p = to_p(d);
   const int nq = d->nq_main + d->nq_extra;
+  if (g_attn_fwd64 && vfm_attn_fwd64_launch(d, p, s)) {
+    VFM_LAUNCH_CHECK();
+    return VFM_OK;
+  }
   const size_t shm = 6 * TILE_BYTES + g_attn_lds_pad;
   static int attr_pad = -1;
   if (attr_pad != g_attn_lds_pad) {

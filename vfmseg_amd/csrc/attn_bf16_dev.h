@@ -1,0 +1,235 @@
+// Device helpers shared by the bf16 flash-attention kernels (attention_bf16.hip, attention_fwd64.hip): LDS tile staging,
+// MFMA fragment reads, the [cls]-row VALU paths.
+#pragma once
+#include "attn_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+#define TROWS 64
+#define TILE_BYTES (TROWS * 128)
+#define LOG2E 1.4426950408889634f
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+__device__ __forceinline__ void glds4(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 4, 0, 0);
+}
+// XOR swizzle of the eight 16-byte chunks of a 128-byte tile row.  Rows are 128 B = all 32 banks apart, so whatever rows one LDS
+// cycle touches must land in different chunks:
+//   ds_read_b128 row fragments: eight consecutive rows per cycle            -> eight different chunks,
+//   ds_read_b64_tr_b16: sixteen lanes = four consecutive rows x 32 bytes    -> four different 32-byte windows (chunk >> 1).
+// ((row >> 1) & 7, the first version, put rows r and r+1 in the same chunk and all four rows of a transposed read in the same
+// window.  Measured with this one: SQ_LDS_BANK_CONFLICT of the forward 1.05 M -> 0.53 M, dK/dV 2.24 M -> 2.10 M, dQ 1.12 M -> 2.10 M,
+// and kernel times unchanged within noise - LDS bank conflicts are not what bounds these kernels; profiles/r02_pmc_attention_*.txt.)
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 1) | ((row >> 2) & 1); }
+// combine a value with the one in lane ^ 32 on the VALU (v_permlane32_swap; __shfl_xor(v, 32) is an LDS round trip - ds_bpermute)
+__device__ __forceinline__ float half_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);   // r[0]: lanes 0..31 seen by both halves, r[1]: lanes 32..63
+}
+__device__ __forceinline__ float half_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// stage one [64 x 64] bf16 tile: sequence positions s0..s0+63 of image b (clamped), columns col0..col0+63
+template <int NW = 4>
+__device__ __forceinline__ void stage_tile(const bf16_t* base, long ld, int col0, int b, int s0, int n, int n_main, int B, char* tile,
+                                           int wave, int lane) {
+#pragma unroll
+  for (int j = 0; j < 8 / NW; ++j) {
+    const int piece = wave * (8 / NW) + j;
+    const int r = piece * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz(r);
+    int s = s0 + r;
+    if (s > n - 1) s = n - 1;
+    glds16(base + tok_row(b, s, n_main, B) * ld + col0 + c * 8, tile + piece * 1024);
+  }
+}
+// first-product A operand: rows rb*32 + (lane&31), 8 consecutive columns of k-step kk (16 columns per step)
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int rb, int kk, int lane) {
+  const int r = rb * 32 + (lane & 31);
+  return *reinterpret_cast<const bf16x8*>(tile + r * 128 + (((2 * kk + (lane >> 5)) ^ swz(r)) << 4));
+}
+// second-product A operand = (tile^T)[32 columns of block j][16 rows of step s in row-block rb], delivered in the
+// permuted k order of an accumulator-derived B operand: element e <-> tile row rb*32 + 16s + 8(e>>2) + 4h + (e&3)
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rb, int s, int j, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, h = g >> 1;
+  const int chunk = 4 * j + 2 * (g & 1) + (p >> 1);
+  const int r0 = rb * 32 + 16 * s + 4 * h + q;
+  const int r1 = r0 + 8;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(tile + r0 * 128 + ((chunk ^ swz(r0)) << 4) + ((p & 1) << 3)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(tile + r1 * 128 + ((chunk ^ swz(r1)) << 4) + ((p & 1) << 3)));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo;
+  u.s.b = hi;
+  return u.v;
+}
+// registers 8s..8s+7 of a 32x32 f32 accumulator -> bf16x8 B operand of k-step s
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) r[e] = (__bf16)a[8 * s + e];
+  return r;
+}
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }  // row of register r
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+// load the stationary operand's B fragments: 4 k-steps x 8 bf16 of row `row`, columns col0 + 16kk + 8h ..
+__device__ __forceinline__ void load_stationary(const bf16_t* base, long ld, long row, int col0, int h, bf16x8 (&f)[4]) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) f[kk] = *reinterpret_cast<const bf16x8*>(base + row * ld + col0 + 16 * kk + 8 * h);
+}
+
+// ------------------------------------------------------------------------------------------- single extra row ([cls])
+// With the cls-last layout a ViT sequence is nq_main = 1024 patch tokens + 1 [cls] token: as a 9th query block (one valid
+// query in 128) and a 9th key block it made 576 equal-cost blocks for 512 resident slots (+30 % forward, +21 % backward).
+// The block that owns only the extra row runs these VALU paths instead: dot products with v_dot2c_f32_bf16, one thread
+// per streamed row for the scores, (row group, 8 columns) per thread for the weighted sums, fixed-order LDS reductions.
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2u(unsigned a, unsigned b, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<bf16x2v*>(&a), *reinterpret_cast<bf16x2v*>(&b), acc, false);
+}
+__device__ __forceinline__ float dot8(uint4 a, uint4 b) {
+  return dot2u(a.w, b.w, dot2u(a.z, b.z, dot2u(a.y, b.y, dot2u(a.x, b.x, 0.f))));
+}
+__device__ __forceinline__ float sum8(float v) {  // over the 8 lanes that share a row
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  return v;
+}
+__device__ __forceinline__ void fma8(float (&acc)[8], float w, uint4 x) {
+  acc[0] = fmaf(w, __uint_as_float(x.x << 16), acc[0]), acc[1] = fmaf(w, __uint_as_float(x.x & 0xffff0000u), acc[1]);
+  acc[2] = fmaf(w, __uint_as_float(x.y << 16), acc[2]), acc[3] = fmaf(w, __uint_as_float(x.y & 0xffff0000u), acc[3]);
+  acc[4] = fmaf(w, __uint_as_float(x.z << 16), acc[4]), acc[5] = fmaf(w, __uint_as_float(x.z & 0xffff0000u), acc[5]);
+  acc[6] = fmaf(w, __uint_as_float(x.w << 16), acc[6]), acc[7] = fmaf(w, __uint_as_float(x.w & 0xffff0000u), acc[7]);
+}
+// out[d] = mult * sum_i w[i] * X[row(i)][col0 + d], i < n: thread (i-group tid>>3, 8 columns tid&7), then 32-way LDS reduce
+__device__ __forceinline__ void weighted_rowsum(const float* w, const bf16_t* X, long ld, int col0, int b, int n, int n_main, int B,
+                                                float mult, float* red, bf16_t* out) {
+  const int tid = threadIdx.x, kg = tid >> 3, d8 = tid & 7;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int i = kg; i < n; i += 32)
+    fma8(acc, w[i], *reinterpret_cast<const uint4*>(X + tok_row(b, i, n_main, B) * ld + col0 + d8 * 8));
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[kg * 64 + d8 * 8 + e] = acc[e];
+  __syncthreads();
+  if (tid < 64) {
+    float o = 0.f;
+    for (int g = 0; g < 32; ++g) o += red[g * 64 + tid];
+    out[tid] = f32_to_bf16(o * mult);
+  }
+  __syncthreads();
+}
+#define ATTN_EXTRA_MAX 2048  // the score arrays live in the kernels' 32-KiB staging area
+
+// Scores: 8 lanes per streamed row (16 B each, one 128-B row per 8 lanes), 32 rows per step, 4 steps in flight.
+static __device__ void attn_extra_fwd(const AttnP& p, int b, int hh, int qi, char* smem) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = tid & 7, rg = tid >> 3;
+  const int nk = p.nk_main + p.nk_extra, nq = p.nq_main + p.nq_extra;
+  float* sc = reinterpret_cast<float*>(smem);
+  float* red = sc + ATTN_EXTRA_MAX + 64;
+  float* sh = red + 32 * 64;
+  const int col0 = hh * 64;
+  const long qrow = tok_row(b, qi, p.nq_main, p.B);
+  const uint4 q8 = *reinterpret_cast<const uint4*>((const bf16_t*)p.q + qrow * p.ldq + col0 + sub * 8);
+  const bf16_t* Kc = (const bf16_t*)p.k + col0 + sub * 8;
+  float mx = -INFINITY;
+  for (int k0 = 0; k0 < nk; k0 += 128) {
+    uint4 kv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = min(k0 + u * 32 + rg, nk - 1);
+      kv[u] = *reinterpret_cast<const uint4*>(Kc + tok_row(b, k, p.nk_main, p.B) * p.ldk);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + u * 32 + rg;
+      const float sv = sum8(dot8(q8, kv[u])) * p.scale;
+      if (k < nk) {
+        if (sub == 0) sc[k] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) sh[wave] = mx;
+  __syncthreads();
+  const float m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  float sum = 0.f;
+  for (int k = tid; k < nk; k += 256) {
+    const float pv = __expf(sc[k] - m);
+    sc[k] = pv;
+    sum += pv;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) sh[4 + wave] = sum;
+  __syncthreads();
+  const float l = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+  weighted_rowsum(sc, (const bf16_t*)p.v, p.ldv, col0, b, nk, p.nk_main, p.B, 1.f / l, red, (bf16_t*)p.o + qrow * p.ldo + col0);
+  if (tid == 0 && p.lse) p.lse[((long)b * p.H + hh) * nq + qi] = m + __logf(l);
+}
+// ------------------------------------------------------------------------------------------- [cls] row of the backward
+// The [cls] token (sequence position n_main, stored after all patch tokens) used to get VALU blocks of its own in the dQ and
+// dK/dV kernels: 64 serial blocks at the end of a 512-block grid (+30 us of a 121-us backward at bs 2).  Its gradients are
+// instead gathered where the products already exist: the ragged last tile of every regular block holds, for each of its 32
+// stationary positions, P and dS against the [cls] token in one accumulator register; the sum over the positions of
+// (that scalar) x (the position's stationary row) is this block's contribution, reduced through a wave-private LDS image and
+// added to an fp32 scratch row with one atomic instruction per wave.  k_attn_cls_finish adds the ([cls], [cls]) pair and
+// writes the three bf16 rows.  (fp32 atomics: the summation order over the 32 waves of an (image, head) pair is not fixed, so
+// these three rows are reproducible to fp32 rounding, not bitwise.)
+//   out[col] += sum_i w[i] * F_i[col]:  w = per-lane scalar (already broadcast to both halves), f = the lane's stationary
+//   fragments (columns 16 kk + 8 h + e), red = 32 x 65 floats of LDS owned by this wave
+__device__ __forceinline__ void cls_partial(float w, const bf16x8 (&f)[4], float* red, int lane, float* dst) {
+  const int fr = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[fr * 65 + 16 * kk + 8 * h + e] = w * (float)f[kk][e];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  float sv = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < 32; ++i) sv += red[i * 65 + lane];
+  atomicAdd(dst + lane, sv);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Rank-1 form of ONE extra streamed position (the [cls] key for the query-stationary kernels, the [cls] query for dK/dV): a tile
+// of 64 for a single row would cost 8 + 8 MFMAs and 32 exponentials per wave; the same mathematics is a dot product per lane
+// (its stationary row against the extra row) and one scalar-times-row update of the accumulators.
+__device__ __forceinline__ float dot_frag(const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {   // full 64-column dot (both lane halves)
+  float s = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf((float)a[kk][e], (float)b[kk][e], s);
+  return half_sum(s);
+}
+// v[j][r] = X[row, col0 + 32 j + acc_row(r, h)]: a row in the accumulators' (output-column) layout
+__device__ __forceinline__ void load_outcols(const bf16_t* base, long ld, long row, int col0, int h, float (&v)[2][16]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const ushort4 u = *reinterpret_cast<const ushort4*>(base + row * ld + col0 + 32 * j + 8 * g + 4 * h);
+      v[j][4 * g + 0] = bf16_to_f32(u.x), v[j][4 * g + 1] = bf16_to_f32(u.y), v[j][4 * g + 2] = bf16_to_f32(u.z), v[j][4 * g + 3] = bf16_to_f32(u.w);
+    }
+}
+

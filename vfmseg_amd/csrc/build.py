@@ -13,6 +13,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=f
          "-I" + os.path.join(ROOT, "include")]
 
 
+# per-file extras.  attention_fwd64.hip places every VALU instruction by hand between MFMAs: SLP-packed f32 adds (v_pk_add_f32)
+# cost more issue cycles there than the two scalar adds they replace
+EXTRA = {"attention_fwd64.hip": ["-fno-slp-vectorize"]}
+
+
 def _hipcc():
     for c in ("/opt/rocm/bin/hipcc", "hipcc"):
         if os.path.exists(c) or c == "hipcc":
@@ -40,7 +45,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         s, o = job
-        cmd = [_hipcc()] + FLAGS + ["-c", s, "-o", o]
+        cmd = [_hipcc()] + FLAGS + EXTRA.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (s, r.stderr[-6000:]))
