@@ -3,7 +3,7 @@ MsVFMEncoderDecoder through the product's DP plumbing (parallel.attach: paramete
 side stream launched from backward, SyncBN moment / gradient exchange) and writes rank 0's results.
 
     RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the env (gloo: the ranks share the one GPU of the test box)
-    argv: OUT.pt MODE(f32|bf16)
+    argv: OUT.pt MODE(f32|bf16) [BACKEND(gloo|nccl)]   (nccl: only with WORLD_SIZE=1 and VFMSEG_DIST_SINGLE=1 on a one-GPU box)
 
 world 1 trains on the global batch [s0, s1]; world 2 gives sample r to rank r - what DDP + SyncBatchNorm make equivalent
 (configs/_base_/default_runtime.py:5, rein/models/heads/linear_head.py:44)."""
@@ -18,7 +18,8 @@ import torch  # noqa: E402
 
 def main():
     out_path, mode = sys.argv[1], sys.argv[2]
-    os.environ["VFMSEG_DIST_BACKEND"] = "gloo"
+    backend = sys.argv[3] if len(sys.argv) > 3 else "gloo"
+    os.environ["VFMSEG_DIST_BACKEND"] = backend
     import vfmseg_amd  # noqa: F401
     from tests.helpers import full_state_dict
     from vfmseg_amd import lib as L, parallel, presets
@@ -27,7 +28,7 @@ def main():
     from vfmseg_amd.registry import MODELS
     from vfmseg_amd.segmentors import SegDataSample
     from vfmseg_amd.synth import synth_image, synth_label
-    rank, world, _ = parallel.init_from_env("gloo")
+    rank, world, _ = parallel.init_from_env(backend)
     torch.cuda.set_device(0)
     L.set_device_index(0)
     set_compute_dtype(mode)
@@ -77,7 +78,7 @@ def main():
     if rank == 0:
         state = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if "lora_" in k or not k.startswith("backbone.")}
         torch.save(dict(state=state, logs=torch.stack(logs), events=events, world=world), out_path)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -23,13 +23,14 @@ def _free_port():
     return p
 
 
-def _run(world, out, mode):
+def _run(world, out, mode, backend="gloo", single=False):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, WORKER, out, mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", VFMSEG_DIST_SINGLE="1" if single else "0")
+        procs.append(subprocess.Popen([sys.executable, WORKER, out, mode, backend], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                      text=True))
     outs = []
     for p in procs:
         try:
@@ -76,3 +77,21 @@ def test_two_ranks_equal_one_rank_with_the_global_batch(tmp_path, mode, ptol, lt
     per_step = ev[:len(ev) // 2]
     assert per_step[0] == "aux_decoder" and per_step[1] == "decode_head" and all(e.startswith("lora") for e in per_step[2:]), ev
     print(f"[dp equivalence {mode}] worst relative parameter difference {worst:.2e} over {n} tensors; bucket launch order {per_step}")
+
+
+@pytest.mark.timeout(900)
+def test_rccl_path_with_a_single_rank(tmp_path):
+    """The `nccl` (= RCCL) code path itself on the one-GPU test box: a world of ONE rank runs the full DP plumbing - process group
+    over RCCL, parameter broadcast, the four gradient buckets all-reduced in place on the side stream from inside backward,
+    the SyncBN exchange - and must reproduce the non-distributed step (an all-reduce over one rank is the identity; what is
+    tested is RCCL initialisation on this image, stream ordering and the hooks).  Not bitwise: the [cls] rows of the attention
+    backward are summed with fp32 atomics, so two runs of the same step differ in the last bits."""
+    plain = _run(1, str(tmp_path / "plain.pt"), "f32")
+    rccl = _run(1, str(tmp_path / "rccl.pt"), "f32", backend="nccl", single=True)
+    assert rccl["events"][:2] == ["aux_decoder", "decode_head"] and len(rccl["events"]) == 8, rccl["events"]
+    assert torch.allclose(plain["logs"], rccl["logs"], rtol=1e-6, atol=1e-7), (plain["logs"], rccl["logs"])
+    for k, a in plain["state"].items():
+        if k == "decode_head.output_upscaling.0.bias":
+            continue   # exact gradient 0 (bias before BatchNorm): Adam turns rounding noise into +-lr steps
+        d = (a - rccl["state"][k]).abs().mean().item() / max(a.abs().mean().item(), 1e-12)
+        assert d < 2e-5, (k, d)

@@ -13,12 +13,19 @@ import torch
 import torch.distributed as dist
 
 
+def single_rank_rehearsal():
+    """VFMSEG_DIST_SINGLE=1: run the whole DP plumbing (process group, parameter broadcast, bucketed all-reduce on the side
+    stream, SyncBN exchange) with a world of ONE rank.  A box with one GPU cannot host two RCCL ranks, so this is how the `nccl`
+    code path itself gets exercised there (tests/test_dp_equivalence_gpu.py); results must equal the non-distributed step."""
+    return os.environ.get("VFMSEG_DIST_SINGLE", "0") == "1"
+
+
 def init_from_env(backend=None):
     """torchrun-style env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT). Returns (rank, world, local)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_rehearsal()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = os.environ.get("VFMSEG_DIST_BACKEND", backend)
@@ -39,7 +46,7 @@ def shard_indices(n_total, rank, world, seed=0):
 
 def broadcast_params(model, src=0):
     """DDP-constructor semantics: rank 0's parameters and buffers win (C3)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not single_rank_rehearsal()):
         return
     for t in list(model.parameters()) + list(model.buffers()):
         dist.broadcast(t.data, src)
@@ -86,6 +93,7 @@ class GradSync:
     def __init__(self, gflat, buckets, group=None):
         self.gflat, self.buckets, self.group = gflat, buckets, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (dist.is_initialized() and single_rank_rehearsal())
         self.cuda = gflat.is_cuda
         self.stream = torch.cuda.Stream() if self.cuda else None
         self.done = [False] * len(buckets)
@@ -93,7 +101,7 @@ class GradSync:
         self.post_scale = (1.0 / self.world) if self.cuda else 1.0  # consumed by OptimWrapper -> vfm_adamw grad_scale
 
     def ready(self, i):
-        if self.world == 1 or self.done[i]:
+        if not self.active or self.done[i]:
             return
         _, a, b = self.buckets[i]
         sl = self.gflat[a:b]
@@ -108,7 +116,7 @@ class GradSync:
     def finish(self):
         for i in range(len(self.buckets)):
             self.ready(i)
-        if self.world > 1:
+        if self.active:
             if self.cuda:
                 torch.cuda.current_stream().wait_stream(self.stream)
             else:
@@ -134,7 +142,7 @@ def attach(model, optim_wrapper, group=None):
     backward-time bucket launches (heads' buckets when the backbone backward starts, the first LoRA bucket once the
     blocks it covers are done; GradSync.finish() sends the rest and joins the side stream)."""
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized() and single_rank_rehearsal()):
         return None
     broadcast_params(model)
     opt = optim_wrapper.optimizer
