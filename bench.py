@@ -217,7 +217,18 @@ def cpu_baseline(seconds_cap=40.0, model_kw=None):
     return out
 
 
+def _reserve_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner from rank 0 when its
+    first communicator is built), so file descriptor 1 is pointed at stderr for the whole run and the JSON line goes to a private
+    duplicate of the original stdout."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
+    real_stdout = _reserve_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -345,8 +356,9 @@ def main():
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        print(json.dumps(out))
-    if world > 1:
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
