@@ -91,8 +91,8 @@ class KernelTimer:
     def reset(self):
         self.recs, self.calls = [], 0
 
-    def summary(self, kinds=None, region=None):
-        sel = [r for r in self.recs if (kinds is None or r[0] in kinds) and (region is None or r[1] == region)]
+    def summary(self, kinds=None, region=None, min_flops=0.0):
+        sel = [r for r in self.recs if (kinds is None or r[0] in kinds) and (region is None or r[1] == region) and r[2] >= min_flops]
         if not sel:
             return None
         fl = sum(r[2] for r in sel)
@@ -309,7 +309,11 @@ def main():
         out["metric"] = "train images/sec @512x512 DINOv2-L+LoRA + LinearHead, single 512^2 pass per sample (not the headline metric)"
         out["config"]["workload"] = "single-pass variant of configs[1]: EncoderDecoder(LoRABackbone(DINOv2-L), LinearHead), 512^2 inputs, bs=%d/GPU" % a.batch
     if rank == 0:
-        g = timer.summary(kinds=("gemm",))
+        GEMMS = ("gemm", "gemm_tn")
+        allg = timer.summary(kinds=GEMMS)
+        # the dominant kernel: k_gemm_w4<2,1,2,4,2> (128x128 tiles, LDS-DMA chunk ring) = the backbone's QKV / proj / fc1 / fc2 forward
+        # and input-gradient launches (>= 8.6 GFLOP each; 193 launches and ~46 % of the step's GPU time in profiles/*_kernel_stats.csv)
+        g = timer.summary(kinds=("gemm",), region="backbone", min_flops=8e9) or allg
         if g is not None:
             traffic, traffic_src = None, None
             for tj_name in ("r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
@@ -323,15 +327,22 @@ def main():
             est = lambda r: round(r["ms"] * timer.every / a.steps, 3)   # noqa: E731
             out["roofline"] = {"bound": "mfma", "achieved": round(g["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(g["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                               "kernel": "bf16 MFMA GEMM: every GEMM launch of the timed steps (backbone + heads + weight gradients)",
-                               "launches_timed": g["launches"], "sampled_every": timer.every, "gemm_ms_per_step_est": est(g)}
+                               "kernel": "k_gemm_w4<true,2,1,2,4,2,0>: the backbone's QKV / proj / fc1 / fc2 forward + input-gradient GEMMs "
+                                         "(algorithmic FLOPs of the sampled launches / their HIP-event time)",
+                               "launches_timed": g["launches"], "sampled_every": timer.every,
+                               "avg_launch_us": round(g["ms"] * 1e3 / g["launches"], 2),
+                               "avg_launch_gflop": round(g["flops"] / g["launches"] / 1e9, 2), "ms_per_step_est": est(g),
+                               "all_gemms": None if allg is None else {
+                                   "what": "every bf16 GEMM launch of the timed steps (backbone + heads + weight gradients)",
+                                   "tflops": round(allg["tflops"], 2), "frac": round(allg["tflops"] / PEAK_BF16_TFLOPS, 4),
+                                   "launches_timed": allg["launches"], "ms_per_step_est": est(allg)}}
             # the block-level figure north_star's 40 % target is stated on: the ViT-L attention + MLP kernels of the backbone
             # (QKV / proj / fc1 / fc2 GEMMs forward + dgrad, LoRA GEMMs, flash attention forward + backward) as ONE family:
             # algorithmic FLOPs (attention backward counted as its five products) / summed kernel time of the sampled launches
-            bg = timer.summary(kinds=("gemm",), region="backbone")
+            bg = timer.summary(kinds=GEMMS, region="backbone")
             af = timer.summary(kinds=("attn_fwd",), region="backbone")
             ab = timer.summary(kinds=("attn_bwd",), region="backbone")
-            blk = timer.summary(kinds=("gemm", "attn_fwd", "attn_bwd"), region="backbone")
+            blk = timer.summary(kinds=GEMMS + ("attn_fwd", "attn_bwd"), region="backbone")
             if blk is not None:
                 out["roofline"]["blocks_frac"] = round(blk["tflops"] / PEAK_BF16_TFLOPS, 4)
                 out["roofline"]["blocks"] = {

@@ -1,43 +1,63 @@
-"""Per-launch HBM-side traffic of the dominant kernel from a rocprofv3 --pmc FETCH_SIZE WRITE_SIZE pass over bench.py.
+"""Per-launch HBM-side traffic of the GEMM kernels inside the train step, from two SEPARATE rocprofv3 --pmc passes over bench.py
+(tools/pmc_gemm_traffic.sh):
 
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE WRITE_SIZE -d OUT -o p --output-format csv -- python bench.py ...
-    python tools/pmc_traffic.py OUT/p_counter_collection.csv profiles/r01_pmc_gemm_traffic.json
+    python tools/pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv OUT.json
 
-FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide streaming read, so it is
-doubled (MI355X_MICROARCH.md, HBM section).  Infinity-Cache hits are included in these counters (they sit on the fabric side
-of L2), so this is L2-miss traffic, an upper bound of the HBM bytes."""
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide streaming read, so it is doubled
+(MI355X_MICROARCH.md, HBM section).  The counters sit on the fabric side of L2, so Infinity-Cache hits are included: this is
+L2-miss traffic, an upper bound of the HBM bytes.  `mean_bytes_per_launch` of the dominant kernel is what bench.py reports as
+roofline.traffic; its algorithmic operand + result bytes are listed beside it."""
 import collections
 import csv
 import json
 import sys
 
-rows = list(csv.DictReader(open(sys.argv[1])))
-per = collections.defaultdict(lambda: collections.defaultdict(float))
-name = {}
-for r in rows:
-    k = r["Dispatch_Id"]
-    per[k][r["Counter_Name"]] += float(r["Counter_Value"])
-    name[k] = r["Kernel_Name"]
-fam = collections.defaultdict(lambda: [0, 0.0, 0.0])
-for k, c in per.items():
-    n = name[k].split("(")[0]
-    f = fam[n]
-    f[0] += 1
-    f[1] += c.get("FETCH_SIZE", 0.0) * 2 * 1024
-    f[2] += c.get("WRITE_SIZE", 0.0) * 1024
-top = sorted(fam.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))
-out = {"source": "rocprofv3 --pmc FETCH_SIZE WRITE_SIZE over bench.py (separate pass); FETCH_SIZE doubled (gfx950), KiB -> bytes",
+
+def per_kernel(path, counter, scale):
+    fam = collections.defaultdict(lambda: [0, 0.0])
+    per = collections.defaultdict(float)
+    name = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        per[r["Dispatch_Id"]] += float(r["Counter_Value"])
+        name[r["Dispatch_Id"]] = r["Kernel_Name"].split("(")[0]
+    for k, v in per.items():
+        fam[name[k]][0] += 1
+        fam[name[k]][1] += v * scale
+    return fam
+
+
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE", 2 * 1024)
+write = per_kernel(sys.argv[2], "WRITE_SIZE", 1024)
+out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) over bench.py --steps 2 --warmup 1; "
+                 "FETCH_SIZE doubled (gfx950), KiB -> bytes; fabric side of L2 (Infinity-Cache hits included: upper bound of HBM bytes)",
        "kernels": []}
-out["per_dispatch"] = []
-for k in sorted(per, key=int):
-    if "gemm" in name[k]:
-        out["per_dispatch"].append({"kernel": name[k].split("(")[0][:60], "fetch_bytes": per[k].get("FETCH_SIZE", 0.0) * 2048,
-                                    "write_bytes": per[k].get("WRITE_SIZE", 0.0) * 1024})
-for n, (cnt, fb, wb) in top[:12]:
-    out["kernels"].append({"kernel": n, "launches": cnt, "fetch_bytes_per_launch": fb / cnt, "write_bytes_per_launch": wb / cnt,
-                           "bytes_per_launch": (fb + wb) / cnt})
-    print(f"{cnt:6d}  fetch {fb / cnt / 1e6:8.2f} MB  write {wb / cnt / 1e6:8.2f} MB  {n[:90]}")
-dom = [k for k in out["kernels"] if "k_gemm_w4" in k["kernel"] or "k_gemm_bf16<128, 128, 2, 4, 2, true, false, false>" in k["kernel"]]
+rows = []
+for n in set(fetch) | set(write):
+    cf, fb = fetch.get(n, [0, 0.0])
+    cw, wb = write.get(n, [0, 0.0])
+    cnt = max(cf, cw, 1)
+    rows.append((fb + wb, n, cnt, fb / max(cf, 1), wb / max(cw, 1)))
+rows.sort(reverse=True)
+for tot, n, cnt, fpl, wpl in rows[:12]:
+    out["kernels"].append({"kernel": n, "launches": cnt, "fetch_bytes_per_launch": fpl, "write_bytes_per_launch": wpl,
+                           "bytes_per_launch": fpl + wpl})
+    print(f"{cnt:6d}  fetch {fpl / 1e6:8.2f} MB  write {wpl / 1e6:8.2f} MB  {n[:90]}")
+dom = [k for k in out["kernels"] if "k_gemm_w4<true, 2, 1, 2, 4, 2, 0>" in k["kernel"]]
 if dom:
     out["dominant"] = dom[0]
-json.dump(out, open(sys.argv[2], "w"), indent=1)
+    out["mean_bytes_per_launch"] = dom[0]["bytes_per_launch"]
+    # algorithmic bytes of the same launches (bs 2: M = 4100 token rows, bf16 operands and results; per train step 24 layers x
+    # {qkv+LoRA fwd [4100x3072x1088], qkv dgrad [4100x1088x3072], proj fwd+dgrad [4100x1024x1024] x2 (+fp32 residual read/write fwd),
+    #  fc1 fwd [4100x4096x1024] (two bf16 results), fc2 dgrad [4100x4096x1024] (+bf16 aux read), fc2 fwd / fc1 dgrad [4100x1024x4096] x2})
+    M = 4100
+
+    def gemm_bytes(n, k, extra=0.0):
+        return 2.0 * (M * k + n * k + M * n) + extra
+    per_layer = [gemm_bytes(3072, 1088), gemm_bytes(1088, 3072), gemm_bytes(1024, 1024, 8.0 * M * 1024), gemm_bytes(1024, 1024),
+                 gemm_bytes(4096, 1024, 2.0 * M * 4096), gemm_bytes(4096, 1024, 2.0 * M * 4096), gemm_bytes(1024, 4096, 8.0 * M * 1024),
+                 gemm_bytes(1024, 4096)]
+    out["algorithmic_mean_bytes_per_launch"] = sum(per_layer) / len(per_layer)
+    out["ratio"] = out["mean_bytes_per_launch"] / out["algorithmic_mean_bytes_per_launch"]
+json.dump(out, open(sys.argv[3], "w"), indent=1)

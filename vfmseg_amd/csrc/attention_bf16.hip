@@ -21,20 +21,19 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nq = p.nq_main + p.nq_extra, nk = p.nk_main + p.nk_extra;
-  int bx = blockIdx.x, bh = blockIdx.y;
-  if (NW == 4 && p.nq_extra == 1 && (p.nq_main & 127) == 0 && nk <= ATTN_EXTRA_MAX) {
-    // The [cls] query gets a block of its own that runs the VALU path.  Those blocks take the LAST linear ids: workgroups
-    // are placed on the CUs in id order at launch, and a light block in the middle of the order pushes a third full block
-    // onto some CUs (measured: +8 us on a 39-us kernel even when the light block returns at once).
-    if constexpr (!DQ) {
-      const int gx = gridDim.x, nfull = (gx - 1) * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
-      if (lin >= nfull) {
-        const int e = lin - nfull;
-        attn_extra_fwd(p, e / p.H, e % p.H, p.nq_main, smem);
-        return;
-      }
-      bx = lin % (gx - 1), bh = lin / (gx - 1);
+  int bx, bh;
+  {
+    // The [cls] query of the forward gets a block of its own that runs the VALU path.  Those blocks take the LAST linear ids:
+    // workgroups are placed on the CUs in id order at launch, and a light block in the middle of the order pushes a third full
+    // block onto some CUs (measured: +8 us on a 39-us kernel even when the light block returns at once).
+    const bool light = !DQ && NW == 4 && p.nq_extra == 1 && (p.nq_main & 127) == 0 && nk <= ATTN_EXTRA_MAX;
+    const int gx = gridDim.x, nbx = gx - (light ? 1 : 0), nfull = nbx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
+    if (lin >= nfull) {
+      const int e = lin - nfull;
+      if constexpr (!DQ) attn_extra_fwd(p, e / p.H, e % p.H, p.nq_main, smem);
+      return;
     }
+    xcd_map(lin, nbx, gridDim.y, bx, bh);
   }
   // backward: the [cls] query has no block (its dQ comes from the dK/dV kernel's partials, see cls_partial); this kernel gathers
   // the [cls] KEY's dK / dV from its regular blocks
@@ -264,7 +263,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nq = p.nq_main + p.nq_extra, nk = p.nk_main + p.nk_extra;
-  int bx = blockIdx.x, bh = blockIdx.y;
+  int bx, bh;
+  xcd_map(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, bx, bh);
   // the [cls] key has no block here: its dK / dV are gathered by the dQ kernel (cls_partial); this kernel gathers dQ[cls]
   const bool cls_query = NW == 4 && p.nq_extra == 1 && p.cls_scratch != nullptr;
   float ds_cls = 0.f;

@@ -86,15 +86,15 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd64(AttnP p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nq = p.nq_main + p.nq_extra;
-  int bx = blockIdx.x, bh = blockIdx.y;
-  if (p.nq_extra == 1) {  // the [cls] query's VALU blocks take the last linear ids (see k_attn_bf16_q)
-    const int gx = gridDim.x, nfull = (gx - 1) * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
+  int bx, bh;
+  {  // the [cls] query's VALU blocks take the last linear ids (see k_attn_bf16_q); the others go to the XCD of their pair
+    const int gx = gridDim.x, nbx = gx - (p.nq_extra == 1 ? 1 : 0), nfull = nbx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
     if (lin >= nfull) {
       const int e = lin - nfull;
       attn_extra_fwd(p, e / p.H, e % p.H, p.nq_main, smem);
       return;
     }
-    bx = lin % (gx - 1), bh = lin / (gx - 1);
+    xcd_map(lin, nbx, gridDim.y, bx, bh);
   }
   const int b = bh / p.H, hh = bh % p.H;
   const int col0 = hh * 64;

@@ -25,6 +25,21 @@ __device__ __forceinline__ void glds4(const void* g, void* l) {
 // window.  Measured with this one: SQ_LDS_BANK_CONFLICT of the forward 1.05 M -> 0.53 M, dK/dV 2.24 M -> 2.10 M, dQ 1.12 M -> 2.10 M,
 // and kernel times unchanged within noise - LDS bank conflicts are not what bounds these kernels; profiles/r02_pmc_attention_*.txt.)
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 1) | ((row >> 2) & 1); }
+// Workgroups are handed to the eight XCDs round-robin by linear id, and each XCD has its own L2.  With the plain (block, pair)
+// order the blocks of one (image, head) pair land on eight different XCDs and every one of them pulls that pair's whole streamed
+// operand (K, V or Q, dO) through the fabric: measured 152-160 MB fetched per attention launch at bs 2 against 25-42 MB of
+// operands (profiles/r02_pmc_gemm_traffic.json).  xcd_map sends all nbx blocks of a pair to the same XCD (pairs p with equal
+// p % 8 share one) whenever the pair count is a multiple of eight: linear id -> (block bx, pair bh).
+__device__ __forceinline__ void xcd_map(int lin, int nbx, int npairs, int& bx, int& bh) {
+  if ((npairs & 7) == 0) {
+    const int xcd = lin & 7, idx = lin >> 3;
+    bx = idx % nbx;
+    bh = (idx / nbx) * 8 + xcd;
+  } else {
+    bx = lin % nbx;
+    bh = lin / nbx;
+  }
+}
 // combine a value with the one in lane ^ 32 on the VALU (v_permlane32_swap; __shfl_xor(v, 32) is an LDS round trip - ds_bpermute)
 __device__ __forceinline__ float half_sum(float v) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);

@@ -441,7 +441,7 @@ def gemm_splitk_bt(at, y, slabs, kch):
     d.alpha = 1.0
     d.batch, d.stride_a, d.stride_b, d.stride_c = kch, ck, ck * y.stride(0), slabs.stride(0)
     d.kb_rows = int(M)
-    fin = PROFILE("gemm", 2.0 * P * Q * mp, REGION[-1]) if PROFILE is not None else None
+    fin = PROFILE("gemm_tn", 2.0 * P * Q * mp, REGION[-1]) if PROFILE is not None else None
     L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
     if fin is not None:
         fin()
@@ -469,7 +469,7 @@ def gemm_splitk_tn(xs, y, slabs, kch):
     d.alpha = 1.0
     d.batch, d.stride_a, d.stride_b, d.stride_c = kch, ck * xs.stride(0), ck * y.stride(0), slabs.stride(0)
     d.kb_rows = int(M)
-    fin = PROFILE("gemm", 2.0 * P * Q * mp, REGION[-1]) if PROFILE is not None else None
+    fin = PROFILE("gemm_tn", 2.0 * P * Q * mp, REGION[-1]) if PROFILE is not None else None
     L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
     if fin is not None:
         fin()
@@ -493,7 +493,7 @@ def gemm_tn_batched(xs, y, out, valid_rows, alpha=1.0):
     d.alpha = float(alpha)
     d.batch, d.stride_a, d.stride_b, d.stride_c = Lb, xs.stride(0), y.stride(0), P * Q
     d.kb_rows = -int(valid_rows)
-    fin = PROFILE("gemm", 2.0 * P * Q * valid_rows * Lb, REGION[-1]) if PROFILE is not None else None
+    fin = PROFILE("gemm_tn", 2.0 * P * Q * valid_rows * Lb, REGION[-1]) if PROFILE is not None else None
     L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
     if fin is not None:
         fin()
