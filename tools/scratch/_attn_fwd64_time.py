@@ -10,7 +10,7 @@ for ex in (1, 0):
     q, k, v = [(torch.randn(B * n + B * ex, H * d, generator=g)).to(torch.bfloat16).cuda() for _ in range(3)]
     o = torch.empty_like(q)
     lse = torch.empty(B, H, n + ex, device="cuda")
-    for mode in (0, 1, 3, 5, 7):
+    for mode in (0, 1, 3, 9, 5, 7):
         lib.vfm_tune(b"attn_fwd64", mode)
         for _ in range(5):
             ops.attn_fwd(q, k, v, o, lse, B, H, d, n, ex, n, ex, d ** -0.5)

@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
       if constexpr (!DQ) attn_extra_fwd(p, e / p.H, e % p.H, p.nq_main, smem);
       return;
     }
-    xcd_map(lin, nbx, gridDim.y, bx, bh);
+    xcd_map(lin, nbx, gridDim.y, p.xcd, bx, bh);
   }
   // backward: the [cls] query has no block (its dQ comes from the dK/dV kernel's partials, see cls_partial); this kernel gathers
   // the [cls] KEY's dK / dV from its regular blocks
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nq = p.nq_main + p.nq_extra, nk = p.nk_main + p.nk_extra;
   int bx, bh;
-  xcd_map(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, bx, bh);
+  xcd_map(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, p.xcd, bx, bh);
   // the [cls] key has no block here: its dK / dV are gathered by the dQ kernel (cls_partial); this kernel gathers dQ[cls]
   const bool cls_query = NW == 4 && p.nq_extra == 1 && p.cls_scratch != nullptr;
   float ds_cls = 0.f;
@@ -411,6 +411,7 @@ static bool aligned_ok(const vfm_attn_desc* d, bool bwd) {
 // 2-wave blocks when the 4-wave grid would not even give every CU one block
 static bool short_grid(const vfm_attn_desc* d, int n) { return (long)cdiv(n, 128) * d->B * d->H < 256; }
 
+int g_attn_xcd = 1;       // vfm_tune("attn_xcd"): 0 = plain (block, pair) order (A/B of the XCD-local order)
 int g_attn_fwd64 = 0;     // vfm_tune("attn_fwd64"): 1 = use the experimental 64-queries-per-wave forward (attention_fwd64.hip) where it fits
 bool vfm_attn_fwd64_launch(const vfm_attn_desc* d, const AttnP& p, hipStream_t s);
 int g_attn_lds_pad = 0;   // vfm_tune("attn_lds_pad"): extra dynamic LDS per forward block (occupancy experiments)

@@ -1,7 +1,8 @@
 // bf16 MFMA flash-attention forward for head dim 64 with 64 queries per wave, one wave per SIMD (gfx950).
 // EXPERIMENTAL (vfm_tune("attn_fwd64", 1); off by default): at the train-step shape (4 images x 16 heads x 1025 tokens) it runs
-// as fast as the 32-queries-per-wave kernel of attention_bf16.hip, not faster (35.5 vs 34.4 us back to back); see "what was
-// learned" below.
+// 7-9 % faster than the 32-queries-per-wave kernel of attention_bf16.hip back to back (31.6 vs 34.7 us with the [cls] token, 30.4
+// vs 32.1 without) and makes no measurable difference inside the train step (125.1 vs 125.2 images/s), so the proven kernel stays
+// the default; see "what was learned" below.
 //
 // Why it was written: the 32-queries-per-wave kernel lives on two waves per SIMD that are supposed to fill each other's stalls;
 // measured (profiles/r02_pmc_attention_before.txt) the matrix pipe is busy 18 % of the time, every wave reads the whole K and V
@@ -23,22 +24,25 @@
 // runs in VALU blocks at the end of the grid, exactly as in the 32-query kernel.  Every memory and VALU instruction is placed by
 // hand between two MFMAs (sched_barrier after each gap).
 //
-// What was learned (timing variants DBG 1 / 2 / 3 = no LDS fragment reads / no exponentials / neither; PMC in
-// profiles/r02_pmc_attention_fwd64.txt):
+// What was learned (timing variants DBG 1 / 2 / 3 / 5 = no LDS fragment reads / no exponentials / neither / reads issued but
+// feeding nothing; PMC in profiles/r02_pmc_attention_fwd64.txt; 4 x 16 x 1024 tokens, back-to-back launches incl. ~4 us of gap):
+//      as built 30.4 us | no exponentials 26.0 | reads issued but not consumed 25.7 | no fragment reads 21.1 | neither 19.2
 //  * a wave issues 330 VALU instructions per 32 MFMAs and tile; with one wave per SIMD a gap costs 8 cycles for the MFMA plus the
-//    issue cycles of everything placed in it (exp 8, the rest 4): ~1700 cycles per tile, 14 us for the loop.  The kernel takes
-//    twice that; the waves are parked half of the time (SQ_WAIT_ANY 26 k of 65 k cycles per wave) although SQ_WAIT_INST_LDS is
-//    small (0.6 k) and LDS bank conflicts were halved by the new tile swizzle without any effect on the time;
-//  * taking the LDS fragment reads out (operands constant) saves 12 us, taking the exponentials out 2 us: the loss sits between
-//    LDS read issue and MFMA issue, not in arithmetic; deeper LDS-DMA prefetch (3 -> 5 stages) and earlier fragment requests
-//    changed nothing;
+//    issue cycles of everything placed in it (exp 8, the rest 4): ~1700 cycles per tile, 14 us for the loop - the kernel is bound
+//    by VALU issue, so the exponentials have to be spread evenly over ALL gaps (first version: all in the S phases, 20 % slower);
+//  * on top of that, ~5 us are MFMAs waiting for LDS fragments although every fragment is requested 3-8 MFMAs (100-500 cycles)
+//    ahead, and ~4 us are the LDS read instructions themselves; halving the LDS bank conflicts (new tile swizzle) and going from
+//    3 to 5 LDS-DMA stages changed nothing;
+//  * what DID help both forwards and the backward: sending all blocks of an (image, head) pair to one XCD (xcd_map) - the K/V
+//    stream then comes from that XCD's L2 instead of the fabric (152 MB fetched per launch before);
 //  * pitfalls met on the way, all visible only in the ISA: a basic-block boundary inside the pipelined region (the `if (t + 2 <
 //    nt)` around the DMA issue, the rescale branch) lets the optimiser SINK the exponentials and the row-sum adds out of their
 //    gaps down to their first use (sched_barrier does not stop IR-level sinking; fixed by removing the branch and by an empty
 //    asm volatile that pins the row sums); fmaxf() on accumulator values emits a canonicalising v_max(x, x) per operand (inline
 //    v_max3_f32 instead); __shfl_xor(v, 32) is an LDS round trip (v_permlane32_swap instead); 32-bit DMA offsets hoisted out of
 //    the loop become 64-bit per-lane addresses and lose the SGPR-base form (an empty asm keeps the zero-extension in the loop);
-//    SLP packs the row-sum adds into v_pk_add_f32 (-fno-slp-vectorize for this file).
+//    SLP packs the row-sum adds into v_pk_add_f32 (-fno-slp-vectorize for this file); __builtin_amdgcn_readfirstlane returns
+//    int - OR-ing a sign-extended low word into a 64-bit address faults.
 #include "attn_bf16_dev.h"
 
 template <int V>
@@ -94,7 +98,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd64(AttnP p) {
       attn_extra_fwd(p, e / p.H, e % p.H, p.nq_main, smem);
       return;
     }
-    xcd_map(lin, nbx, gridDim.y, bx, bh);
+    xcd_map(lin, nbx, gridDim.y, p.xcd, bx, bh);
   }
   const int b = bh / p.H, hh = bh % p.H;
   const int col0 = hh * 64;
@@ -212,14 +216,24 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd64(AttnP p) {
     for (int k = 0; k < 4; ++k) vf[k][0] = vf[k][1] = qf[0][1];
   }
 
+  bf16x8 kd[8], vd[4][2];  // DBG & 4: the fragment reads are issued but land here and feed nothing (sunk at the end of the phase)
+  auto sink = [&](bf16x8& v) INL {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(v));
+#endif
+  };
   auto ldk = [&](auto Ic) INL {
     constexpr int i = decltype(Ic)::value;
+    if constexpr (DBG & 4) {
+      kd[i] = *reinterpret_cast<const bf16x8*>(kc[i & 3] + (i >> 2) * 4096);
+      return;
+    }
     if constexpr (DBG & 1) return;  // timing experiment: no LDS fragment reads (results are garbage)
     kf[i] = *reinterpret_cast<const bf16x8*>(kc[i & 3] + (i >> 2) * 4096);
   };
   auto ldv = [&](auto Kc) INL {  // step k = 2 * kb + s: rows kb * 32 + 16 s + ...; both column blocks
     constexpr int k = decltype(Kc)::value;
-    if constexpr (DBG & 1) return;
+    if constexpr ((DBG & 1) && !(DBG & 4)) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vl[j] + k * 2048));
@@ -231,7 +245,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd64(AttnP p) {
         bf16x8 v;
       } u;
       u.s.a = lo, u.s.b = hi;
-      vf[k][j] = u.v;
+      if constexpr (DBG & 4) vd[k][j] = u.v;
+      else vf[k][j] = u.v;
     }
   };
   auto estep = [&](auto Qc, auto Ec) INL {  // element e of 32: p = exp2(s * c - m * c); four row-sum chains; packed per eight
@@ -318,6 +333,10 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd64(AttnP p) {
       if constexpr (HASM) sm1(QMc, Ic);
       __builtin_amdgcn_sched_barrier(0);
     });
+    if constexpr (DBG & 4) {
+      if constexpr (RK) sfor<8>([&](auto Ic) INL { sink(kd[decltype(Ic)::value]); });
+      if constexpr (HASPV) sink(vd[2][0]), sink(vd[2][1]), sink(vd[3][0]), sink(vd[3][1]);
+    }
   };
   // S / exp phase: S[QS] = K Q[QS]^T from the held K fragments (HASS); in the gaps: the second half of q-block QE's softmax and
   // the V fragments (steps 0, 1) of the PV phase that follows
@@ -334,6 +353,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd64(AttnP p) {
       sm2(QEc, Ic);
       __builtin_amdgcn_sched_barrier(0);
     });
+    if constexpr (DBG & 4) sink(vd[0][0]), sink(vd[0][1]), sink(vd[1][0]), sink(vd[1][1]);
   };
 
   const int nt = p.nk_main / TROWS;  // >= NST + 1 (checked by the dispatcher); tile t lives in stage t % NST
@@ -413,11 +433,13 @@ bool vfm_attn_fwd64_launch(const vfm_attn_desc* d, const AttnP& p, hipStream_t s
     (void)hipFuncSetAttribute((const void*)k_attn_fwd64<1, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     (void)hipFuncSetAttribute((const void*)k_attn_fwd64<2, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     (void)hipFuncSetAttribute((const void*)k_attn_fwd64<3, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipFuncSetAttribute((const void*)k_attn_fwd64<5, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr = true;
   }
   if (g_attn_fwd64 == 3) hipLaunchKernelGGL((k_attn_fwd64<1, NST>), grid, dim3(256), SMEM, s, p);  // timing experiments
   else if (g_attn_fwd64 == 5) hipLaunchKernelGGL((k_attn_fwd64<2, NST>), grid, dim3(256), SMEM, s, p);
   else if (g_attn_fwd64 == 7) hipLaunchKernelGGL((k_attn_fwd64<3, NST>), grid, dim3(256), SMEM, s, p);
+  else if (g_attn_fwd64 == 9) hipLaunchKernelGGL((k_attn_fwd64<5, NST>), grid, dim3(256), SMEM, s, p);  // reads issued, feed nothing
   else hipLaunchKernelGGL((k_attn_fwd64<0, NST>), grid, dim3(256), SMEM, s, p);
   return true;
 }

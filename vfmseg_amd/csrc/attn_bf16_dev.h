@@ -30,8 +30,8 @@ __device__ __forceinline__ int swz(int row) { return ((row & 3) << 1) | ((row >>
 // operand (K, V or Q, dO) through the fabric: measured 152-160 MB fetched per attention launch at bs 2 against 25-42 MB of
 // operands (profiles/r02_pmc_gemm_traffic.json).  xcd_map sends all nbx blocks of a pair to the same XCD (pairs p with equal
 // p % 8 share one) whenever the pair count is a multiple of eight: linear id -> (block bx, pair bh).
-__device__ __forceinline__ void xcd_map(int lin, int nbx, int npairs, int& bx, int& bh) {
-  if ((npairs & 7) == 0) {
+__device__ __forceinline__ void xcd_map(int lin, int nbx, int npairs, int on, int& bx, int& bh) {
+  if (on && (npairs & 7) == 0) {
     const int xcd = lin & 7, idx = lin >> 3;
     bx = idx % nbx;
     bh = (idx / nbx) * 8 + xcd;

@@ -13,6 +13,7 @@ struct AttnP {
   void* dq; void* dk; void* dv; long ld_dq, ld_dk, ld_dv;
   float* delta;
   float* cls_scratch;   // backward: fp32 [B*H][3][64] partial dq / dk / dv rows of the extra ([cls]) token, or null
+  int xcd;              // 1: all blocks of an (image, head) pair on one XCD (vfm_tune "attn_xcd", default 1)
 };
 
 __device__ __forceinline__ long tok_row(int b, int i, int n_main, int B) {
@@ -31,6 +32,8 @@ static inline AttnP to_p(const vfm_attn_desc* d) {
   p.dq = d->dq; p.dk = d->dk; p.dv = d->dv; p.ld_dq = d->ld_dq; p.ld_dk = d->ld_dk; p.ld_dv = d->ld_dv;
   p.delta = d->delta;
   p.cls_scratch = nullptr;
+  extern int g_attn_xcd;
+  p.xcd = g_attn_xcd;
   return p;
 }
 

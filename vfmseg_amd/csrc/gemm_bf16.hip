@@ -332,6 +332,11 @@ extern "C" int vfm_tune(const char* key, int value) {
     g_pp_dbg = value;
     return VFM_OK;
   }
+  if (key && strcmp(key, "attn_xcd") == 0) {
+    extern int g_attn_xcd;
+    g_attn_xcd = value;
+    return VFM_OK;
+  }
   if (key && strcmp(key, "attn_fwd64") == 0) {
     extern int g_attn_fwd64;
     g_attn_fwd64 = value;
