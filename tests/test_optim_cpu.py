@@ -68,3 +68,67 @@ def test_find_latest_checkpoint_orders_numerically(tmp_path):
     assert os.path.basename(find_latest_checkpoint(str(tmp_path))) == "iter_12000.pth"   # the pointer file wins (mmengine)
     (tmp_path / "last_checkpoint").write_text(str(tmp_path / "gone.pth"))
     assert os.path.basename(find_latest_checkpoint(str(tmp_path))) == "iter_40000.pth"
+
+
+class _StubOpt:
+    """What AmpOptimWrapper needs of FusedAdamW: the flat gradient buffer, step(lr, grad_scale, zero_grad), zero_grad()."""
+
+    def __init__(self, n=8):
+        self.w = torch.zeros(n)
+        self.gflat = torch.zeros(n)
+        self.param_groups = [dict(lr=0.0)]
+        self.steps = []
+
+    def step(self, lr=None, grad_scale=1.0, zero_grad=False):
+        self.steps.append(float(grad_scale))
+        self.w -= 0.1 * self.gflat * grad_scale
+        if zero_grad:
+            self.gflat.zero_()
+
+    def zero_grad(self):
+        self.gflat.zero_()
+
+
+class _Loss:
+    """Stands in for the loss tensor: backward() deposits grad * (whatever the loss was multiplied by) into the stub's buffer."""
+
+    def __init__(self, opt, grad, mult=1.0):
+        self.opt, self.grad, self.mult = opt, grad, mult
+
+    def __mul__(self, k):
+        return _Loss(self.opt, self.grad, self.mult * k)
+
+    def backward(self):
+        self.opt.gflat += self.grad * self.mult
+
+
+def test_amp_optim_wrapper_follows_gradscaler():
+    # mmengine AmpOptimWrapper / torch GradScaler semantics (tools/train.py:87-102): scaled backward, un-scaled step, a step with
+    # inf / NaN gradients is skipped and halves the scale, `growth_interval` good steps double it; the iteration counter (PolyLR)
+    # advances either way
+    from vfmseg_amd.optim import AmpOptimWrapper
+    opt = _StubOpt()
+    ow = AmpOptimWrapper(opt, None, None, loss_scale=dict(init_scale=1024.0, growth_interval=3))
+    g = torch.arange(8, dtype=torch.float32)
+    ow.update_params(_Loss(opt, g))
+    assert opt.steps == [1.0 / 1024.0] and torch.allclose(opt.w, -0.1 * g) and ow.scale == 1024.0 and ow.iter == 1
+    bad = g.clone()
+    bad[3] = float("inf")
+    w_before = opt.w.clone()
+    ow.update_params(_Loss(opt, bad))
+    assert len(opt.steps) == 1 and torch.equal(opt.w, w_before) and ow.scale == 512.0 and ow.skipped == 1 and ow.iter == 2
+    assert float(opt.gflat.abs().sum()) == 0.0          # the poisoned gradients are cleared
+    for _ in range(3):
+        ow.update_params(_Loss(opt, g))
+    assert ow.scale == 1024.0 and ow.growth_tracker == 0 and len(opt.steps) == 4 and opt.steps[-1] == 1.0 / 512.0
+    sd = ow.state_dict()
+    ow2 = AmpOptimWrapper(_StubOpt(), None, None, loss_scale="dynamic")
+    assert ow2.scale == 65536.0
+    ow2.load_state_dict(sd)
+    assert ow2.scale == 1024.0 and ow2.iter == 5
+    fixed = AmpOptimWrapper(_StubOpt(), None, None, loss_scale=128.0)
+    fixed.update_params(_Loss(fixed.optimizer, bad))
+    assert fixed.scale == 128.0 and fixed.skipped == 1   # a static scale never moves
+    import pytest
+    with pytest.raises(NotImplementedError):
+        AmpOptimWrapper(_StubOpt(), None, None, dtype="float16")

@@ -14,7 +14,7 @@ def main():
     ap.add_argument("config")
     ap.add_argument("--work-dir")
     ap.add_argument("--resume", action="store_true")
-    ap.add_argument("--amp", action="store_true", help="accepted for CLI parity; bf16 MFMA compute is the default")
+    ap.add_argument("--amp", action="store_true", help="AmpOptimWrapper with a dynamic loss scale; autocast dtype bf16")
     ap.add_argument("--cfg-options", nargs="+")
     ap.add_argument("--launcher", choices=["none", "pytorch", "slurm", "mpi"], default="none")
     ap.add_argument("--local_rank", "--local-rank", type=int, default=0)
@@ -28,14 +28,19 @@ def main():
     from vfmseg_amd.precision import set_compute_dtype
     from vfmseg_amd.runner import Runner
     set_compute_dtype(a.dtype)
-    if a.amp:
-        import warnings
-        warnings.warn("--amp (tools/train.py:87-102: AmpOptimWrapper, fp16 autocast + dynamic loss scale) has no fp16 path here: "
-                      "GEMM / attention operands are bf16 with fp32 accumulation, the residual stream, statistics, losses and "
-                      "the optimiser are fp32 (--dtype bf16, the default); bf16's exponent range needs no loss scaling, so the "
-                      "flag changes nothing")
     cfg = Config.fromfile(a.config)
     cfg.merge_from_dict(parse_cfg_options(a.cfg_options))
+    if a.amp:   # tools/train.py:87-102: OptimWrapper -> AmpOptimWrapper with a dynamic loss scale
+        ow_type = cfg["optim_wrapper"].get("type", "OptimWrapper")
+        if ow_type == "AmpOptimWrapper":
+            print("AMP training is already enabled in your config.")
+        else:
+            assert ow_type == "OptimWrapper", f"`--amp` is only supported when the optimizer wrapper type is `OptimWrapper` but got {ow_type}."
+            cfg["optim_wrapper"]["type"] = "AmpOptimWrapper"
+            cfg["optim_wrapper"]["loss_scale"] = "dynamic"
+        if a.dtype != "bf16":
+            print("--amp: the autocast dtype of this backend is bf16 (vfmseg_amd.optim.AmpOptimWrapper); switching --dtype to bf16")
+            set_compute_dtype("bf16")
     cfg["work_dir"] = a.work_dir or cfg.get("work_dir") or os.path.join("./work_dirs", os.path.splitext(os.path.basename(a.config))[0])
     if "train_cfg" not in cfg["model"] or cfg["model"]["train_cfg"] is None:
         cfg["model"]["train_cfg"] = {}

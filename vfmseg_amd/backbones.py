@@ -475,9 +475,9 @@ class DinoEngine:
             S.update(a1=a1, st1=st1, qkv=qkv, ao=ao, lse=lse, x_mid=xm, a2=a2, st2=st2, hpre=hpre, g=g)
             saved.append(S)
             x = xo
-            if li in v.out_indices:
-                i = v.out_indices.index(li)
-                ops.cast(x[:Mp], xcat[:, i * D:(i + 1) * D])
+            for i, oi in enumerate(v.out_indices):   # (an index may be listed more than once: every copy is a tap of its own)
+                if oi == li:
+                    ops.cast(x[:Mp], xcat[:, i * D:(i + 1) * D])
         ctx = dict(saved=saved, nimg=nimg, Np=Np, M=M, Mp=Mp, P=P, training=training, A1all=A1all, XDall=XDall)
         return xcat, (hp, wp), ctx
 
@@ -509,10 +509,10 @@ class DinoEngine:
         half = nL // 2
         fuse_t = cd == torch.bfloat16 and D % 256 == 0  # LN backward emits the next dgrad operand bf16(dx * gamma) itself
         def add_tap(li):
-            if li in v.out_indices:
-                i = v.out_indices.index(li)
-                src = dxcat[:, i * D:(i + 1) * D]
-                ops.strided_copy(src, dx, (Mp, D), (src.stride(0), 1), (D, 1), accumulate=True)
+            for i, oi in enumerate(v.out_indices):
+                if oi == li:
+                    src = dxcat[:, i * D:(i + 1) * D]
+                    ops.strided_copy(src, dx, (Mp, D), (src.stride(0), 1), (D, 1), accumulate=True)
         t = None
         for li in range(len(v.blocks) - 1, -1, -1):
             blk, Lp, S = v.blocks[li], P["layers"][li], ctx["saved"][li]

@@ -295,9 +295,9 @@ class ClipEngine:
                      xd2=xd2, mask2=mask2)
             saved.append(S)
             x = xo
-            if li in v.out_indices:
-                i = v.out_indices.index(li)
-                ops.cast(x[:Mp], xcat[:, i * D:(i + 1) * D])
+            for i, oi in enumerate(v.out_indices):   # (an index may be listed more than once: every copy is a tap of its own)
+                if oi == li:
+                    ops.cast(x[:Mp], xcat[:, i * D:(i + 1) * D])
         ctx = dict(saved=saved, nimg=nimg, Np=Np, M=M, Mp=Mp, P=P, training=training)
         return xcat, (hp, wp), ctx
 
@@ -340,10 +340,10 @@ class ClipEngine:
             P["ones"] = torch.ones(D, dtype=torch.float32, device=dev)
 
         def add_tap(li):
-            if li in v.out_indices:
-                i = v.out_indices.index(li)
-                src = dxcat[:, i * D:(i + 1) * D]
-                ops.strided_copy(src, dx, (Mp, D), (src.stride(0), 1), (D, 1), accumulate=True)
+            for i, oi in enumerate(v.out_indices):
+                if oi == li:
+                    src = dxcat[:, i * D:(i + 1) * D]
+                    ops.strided_copy(src, dx, (Mp, D), (src.stride(0), 1), (D, 1), accumulate=True)
         t = None
         for li in range(len(v.blocks) - 1, -1, -1):
             blk, Lp, S = v.blocks[li], P["layers"][li], ctx["saved"][li]

@@ -275,9 +275,9 @@ class EvaEngine:
             S.update(a1=a1, st1=st1, qkv=qkv, ao=ao, lse=lse, x_mid=xm, a2=a2, st2=st2, h12=h12, hidden=hidden, st3=st3, hn=hn)
             saved.append(S)
             x = xo
-            if li in v.out_indices:
-                i = v.out_indices.index(li)
-                ops.cast(x[:Mp], xcat[:, i * D:(i + 1) * D])
+            for i, oi in enumerate(v.out_indices):   # (an index may be listed more than once: every copy is a tap of its own)
+                if oi == li:
+                    ops.cast(x[:Mp], xcat[:, i * D:(i + 1) * D])
         ctx = dict(saved=saved, nimg=nimg, Np=Np, M=M, Mp=Mp, P=P, training=training)
         return xcat, (hp, wp), ctx
 
@@ -296,10 +296,10 @@ class EvaEngine:
             P["ones"] = torch.ones(D, dtype=torch.float32, device=dev)
 
         def add_tap(li):
-            if li in v.out_indices:
-                i = v.out_indices.index(li)
-                src = dxcat[:, i * D:(i + 1) * D]
-                ops.strided_copy(src, dx, (Mp, D), (src.stride(0), 1), (D, 1), accumulate=True)
+            for i, oi in enumerate(v.out_indices):
+                if oi == li:
+                    src = dxcat[:, i * D:(i + 1) * D]
+                    ops.strided_copy(src, dx, (Mp, D), (src.stride(0), 1), (D, 1), accumulate=True)
         t = None
         for li in range(len(v.blocks) - 1, -1, -1):
             blk, Lp, S = v.blocks[li], P["layers"][li], ctx["saved"][li]

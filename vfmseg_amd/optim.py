@@ -180,6 +180,79 @@ class OptimWrapper:
     def get_lr(self):
         return self.optimizer.param_groups[0]["lr"]
 
+    def state_dict(self):
+        return dict(iter=self.iter)
+
+    def load_state_dict(self, sd):
+        self.iter = int(sd.get("iter", self.iter))
+
+
+class AmpOptimWrapper(OptimWrapper):
+    """mmengine AmpOptimWrapper (what tools/train.py:87-102 switches to under `--amp`): the loss is multiplied by a loss scale
+    before backward, the gradients are un-scaled inside the optimiser step, a step whose gradients hold an inf / NaN is skipped,
+    and with `loss_scale='dynamic'` the scale follows torch.cuda.amp.GradScaler's schedule (init 2**16, x0.5 after a skipped
+    step, x2 after `growth_interval` = 2000 consecutive good ones).  A number or a dict(init_scale=, growth_factor=,
+    backoff_factor=, growth_interval=) is accepted as in mmengine.
+
+    Autocast dtype: the reference autocasts to fp16 (CUDA default).  This library's low-precision mode is bf16 (MFMA bf16 GEMMs /
+    attention with fp32 accumulation and an fp32 residual stream, vfmseg_amd.precision); fp16 kernels are not offered, so `dtype`
+    other than None / 'bfloat16' raises.  With bf16 the scale never has to back off in practice; the machinery is kept because
+    configs and checkpoints carry it.  The un-scale costs nothing: 1/scale rides on the fused AdamW kernel's grad_scale."""
+
+    def __init__(self, optimizer, scheduler=None, grad_sync=None, loss_scale="dynamic", dtype=None):
+        super().__init__(optimizer, scheduler, grad_sync)
+        if dtype not in (None, "bfloat16", "bf16", torch.bfloat16):
+            raise NotImplementedError("AmpOptimWrapper: autocast dtype %r is not offered on this backend (bf16 only)" % (dtype,))
+        self.growth_factor, self.backoff_factor, self.growth_interval = 2.0, 0.5, 2000
+        self.dynamic = True
+        if loss_scale == "dynamic":
+            self.scale = 2.0 ** 16
+        elif isinstance(loss_scale, dict):
+            self.scale = float(loss_scale.get("init_scale", 2.0 ** 16))
+            self.growth_factor = float(loss_scale.get("growth_factor", 2.0))
+            self.backoff_factor = float(loss_scale.get("backoff_factor", 0.5))
+            self.growth_interval = int(loss_scale.get("growth_interval", 2000))
+        elif isinstance(loss_scale, (int, float)):
+            self.scale, self.dynamic = float(loss_scale), False
+        else:
+            raise TypeError("loss_scale must be 'dynamic', a number or a dict, got %r" % (loss_scale,))
+        self.growth_tracker = 0
+        self.skipped = 0
+
+    def update_params(self, loss):
+        (loss * self.scale).backward()
+        if self.grad_sync is not None:
+            self.grad_sync()
+        # after the all-reduce every rank sees the same sums, hence the same decision (an inf / NaN survives the reduction)
+        found_inf = not bool(torch.isfinite(self.optimizer.gflat.sum()).item())
+        lr = self.scheduler.lr(self.iter) if self.scheduler is not None else None
+        if found_inf:
+            self.skipped += 1
+            self.optimizer._grads_cleared = False
+        else:
+            self.optimizer.step(lr, grad_scale=getattr(self.grad_sync, "post_scale", 1.0) / self.scale, zero_grad=True)
+        self.optimizer.zero_grad()
+        if self.dynamic:   # GradScaler.update
+            if found_inf:
+                self.scale *= self.backoff_factor
+                self.growth_tracker = 0
+            else:
+                self.growth_tracker += 1
+                if self.growth_tracker == self.growth_interval:
+                    self.scale *= self.growth_factor
+                    self.growth_tracker = 0
+        self.iter += 1
+
+    def state_dict(self):
+        return dict(iter=self.iter, loss_scaler=dict(scale=self.scale, growth_factor=self.growth_factor, backoff_factor=self.backoff_factor,
+                                                     growth_interval=self.growth_interval, _growth_tracker=self.growth_tracker))
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        ls = sd.get("loss_scaler")
+        if ls:
+            self.scale, self.growth_tracker = float(ls["scale"]), int(ls.get("_growth_tracker", 0))
+
 
 @OPTIM_WRAPPER_CONSTRUCTORS.register_module()
 class PEFTOptimWrapperConstructor:
@@ -203,4 +276,9 @@ class PEFTOptimWrapperConstructor:
             assert sc.pop("type", "PolyLR") == "PolyLR"
             sc.pop("by_epoch", None)
             sched = PolyLR(opt.lr, **sc)
+        wtype = self.cfg.get("type", "OptimWrapper")
+        if wtype == "AmpOptimWrapper":
+            return AmpOptimWrapper(opt, sched, loss_scale=self.cfg.get("loss_scale", "dynamic"), dtype=self.cfg.get("dtype"))
+        if wtype != "OptimWrapper":
+            raise NotImplementedError("optim_wrapper type %r (OptimWrapper and AmpOptimWrapper are the ones tools/train.py uses)" % (wtype,))
         return OptimWrapper(opt, sched)

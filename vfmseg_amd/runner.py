@@ -101,7 +101,7 @@ class Runner:
         sd = {k: v.detach().cpu() for k, v in self.model.state_dict().items()}
         meta = dict(iter=self.iter, loader_pos=getattr(self.loader, "i", None), np_random=np.random.get_state(),
                     mask_rng=dict(Fh._seed_state), torch_rng=torch.get_rng_state())
-        torch.save(dict(state_dict=sd, meta=meta, optimizer=self.ow.optimizer.state_dict()), path)
+        torch.save(dict(state_dict=sd, meta=meta, optimizer=self.ow.optimizer.state_dict(), optim_wrapper=self.ow.state_dict()), path)
         with open(os.path.join(os.path.dirname(path) or ".", "last_checkpoint"), "w") as f:
             f.write(os.path.abspath(path))
 
@@ -111,6 +111,8 @@ class Runner:
         self.model.load_state_dict(ck["state_dict"], strict=False)
         self.ow.optimizer.load_state_dict({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in ck["optimizer"].items()})
         meta = ck["meta"]
+        if "optim_wrapper" in ck:   # AmpOptimWrapper: the loss scaler's state
+            self.ow.load_state_dict(ck["optim_wrapper"])
         self.iter = self.ow.iter = meta["iter"]
         if meta.get("loader_pos") is not None and hasattr(self.loader, "i"):
             self.loader.i = meta["loader_pos"]

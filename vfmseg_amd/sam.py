@@ -305,9 +305,9 @@ class SamEngine:
                 S_.update(a1=a1, st1=st1, qkv=qkv, pr=pr, x_mid=xm, st2=st2, hpre=hpre, xd=xd, mask=mask)
                 saved.append(S_)
             x = xo
-            if li in v.out_indices:
-                i = v.out_indices.index(li)
-                ops.cast(x, xcat[:, i * D:(i + 1) * D])
+            for i, oi in enumerate(v.out_indices):   # (an index may be listed more than once: every copy is a tap of its own)
+                if oi == li:
+                    ops.cast(x, xcat[:, i * D:(i + 1) * D])
         return xcat, (G, G), dict(saved=saved if keep else None, nimg=nimg, M=M, P=P, G=G)
 
     # ---- backward: d(xcat) -> LoRA grads [dA0, dB0, dA1, dB1, ...]
@@ -324,10 +324,10 @@ class SamEngine:
         for li in range(len(v.blocks) - 1, -1, -1):
             blk, Lp, S_ = v.blocks[li], P["layers"][li], ctx["saved"][li]
             q = blk.attn.qkv
-            if li in v.out_indices:
-                i = v.out_indices.index(li)
-                src = dxcat[:, i * D:(i + 1) * D]
-                ops.strided_copy(src, dx, (M, D), (src.stride(0), 1), (D, 1), accumulate=True)
+            for i, oi in enumerate(v.out_indices):
+                if oi == li:
+                    src = dxcat[:, i * D:(i + 1) * D]
+                    ops.strided_copy(src, dx, (M, D), (src.stride(0), 1), (D, 1), accumulate=True)
             # ---- MLP branch: x_out = x_mid + lin2(gelu(lin1(LN2(x_mid))))
             ops.cast(dx, t)
             hid = Lp["fc1"].n
