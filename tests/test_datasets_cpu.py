@@ -1,0 +1,140 @@
+"""Input pipeline (vfmseg_amd.datasets): folder dataset, the mmseg transform chain of configs/_base_/datasets/*.py, rare class
+sampling (rein/datasets/uda_dataset.py:15-107) and the infinite rank-sharded loader - on a tiny Cityscapes-shaped tree written
+to a temp dir."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import vfmseg_amd  # noqa: F401
+from vfmseg_amd import datasets as D
+from vfmseg_amd.registry import DATASETS
+
+
+def _tree(root, n=6, h=96, w=160):
+    from PIL import Image
+    rng = np.random.RandomState(0)
+    os.makedirs(os.path.join(root, "images", "a"))
+    os.makedirs(os.path.join(root, "labels", "a"))
+    stats, swc = [], {}
+    for i in range(n):
+        img = rng.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        lab = np.full((h, w), 0, np.uint8)
+        lab[:, w // 2:] = 1 + i % 3              # classes 1..3 on the right half
+        lab[: h // 8] = 255                      # ignore band
+        if i == 4:
+            lab[h // 2:, : w // 4] = 18          # the rare class lives in one file only
+        Image.fromarray(img).save(os.path.join(root, "images", "a", f"s{i}.png"))
+        fn = os.path.join(root, "labels", "a", f"s{i}_labelTrainIds.png")
+        Image.fromarray(lab).save(fn)
+        st = {"file": fn}
+        for c in np.unique(lab):
+            if c != 255:
+                st[str(int(c))] = int((lab == c).sum())
+                swc.setdefault(str(int(c)), []).append([fn, int((lab == c).sum())])
+        stats.append(st)
+    json.dump(stats, open(os.path.join(root, "sample_class_stats.json"), "w"))
+    json.dump(swc, open(os.path.join(root, "samples_with_class.json"), "w"))
+
+
+def _cfg(root, crop=(64, 64), rcs=True):
+    pipeline = [dict(type="LoadImageFromFile"), dict(type="LoadAnnotations"), dict(type="Resize", scale=(240, 144)),
+                dict(type="RandomCrop", crop_size=crop, cat_max_ratio=0.75), dict(type="RandomFlip", prob=0.5),
+                dict(type="PhotoMetricDistortion"), dict(type="PackSegInputs")]
+    src = dict(type="CityscapesDataset", data_root=root, data_prefix=dict(img_path="images", seg_map_path="labels"), img_suffix=".png",
+               seg_map_suffix="_labelTrainIds.png", pipeline=pipeline, serialize_data=False)
+    cfg = dict(type="DGDataset", source=src)
+    if rcs:
+        cfg["rare_class_sampling"] = dict(class_temp=0.01, min_crop_ratio=2, min_pixels=100)
+    return cfg
+
+
+def test_folder_dataset_and_transform_chain(tmp_path):
+    root = str(tmp_path)
+    _tree(root)
+    ds = DATASETS.build(_cfg(root, rcs=False))
+    assert len(ds) == 6 and ds.CLASSES[0] == "road" and ds.ignore_index == 255
+    assert ds.source.data_list[2]["seg_map_path"].endswith(os.path.join("labels", "a", "s2_labelTrainIds.png"))
+    np.random.seed(0)
+    s = ds[1]
+    assert s["inputs"].dtype == torch.uint8 and tuple(s["inputs"].shape) == (3, 64, 64)
+    gt = s["data_samples"].gt_sem_seg.data
+    assert gt.dtype == torch.int64 and tuple(gt.shape) == (1, 64, 64) and set(gt.unique().tolist()) <= {0, 2, 255}
+    m = s["data_samples"].metainfo
+    assert m["ori_shape"] == (96, 160) and m["img_shape"] == (64, 64) and m["scale_factor"] == (1.5, 1.5) and m["flip"] in (True, False)
+
+
+def test_resize_crop_flip_keep_image_and_label_aligned(tmp_path):
+    root = str(tmp_path)
+    _tree(root)
+    res = dict(img_path=os.path.join(root, "images", "a", "s1.png"), seg_map_path=os.path.join(root, "labels", "a", "s1_labelTrainIds.png"),
+               seg_fields=[])
+    res = D.LoadAnnotations()(D.LoadImageFromFile()(res))
+    res["img"][..., 0] = res["gt_seg_map"]        # paint the label into the blue channel: the two must move together
+    np.random.seed(3)
+    res = D.RandomCrop((48, 80), cat_max_ratio=0.75)(D.Resize(scale=(320, 192))(res))
+    labels, cnt = np.unique(res["gt_seg_map"], return_counts=True)
+    cnt = cnt[labels != 255]
+    assert len(cnt) > 1 and cnt.max() / cnt.sum() < 0.75
+    res = D.RandomFlip(prob=1.0)(res)
+    assert res["flip"] and res["flip_direction"] == "horizontal"
+    # nearest label resize and bilinear image resize agree wherever the image is away from a label edge
+    same = res["img"][..., 0] == res["gt_seg_map"]
+    assert same.mean() > 0.9
+    kr = D.Resize(scale=(2048, 64), keep_ratio=True)(dict(img=np.zeros((96, 160, 3), np.uint8), seg_fields=[]))
+    assert kr["img_shape"] == (64, 107)            # mmcv.rescale_size: the short edge decides, int(x + 0.5)
+
+
+def test_hsv_round_trip_and_photometric_range():
+    rng = np.random.RandomState(1)
+    img = rng.randint(0, 256, (40, 50, 3), dtype=np.uint8)
+    back = D.hsv2bgr_u8(D.bgr2hsv_u8(img))
+    assert np.abs(back.astype(int) - img.astype(int)).max() <= 4      # 8-bit HSV quantisation (H in 2-degree steps), as with OpenCV
+    hsv = D.bgr2hsv_u8(np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [128, 128, 128]]], np.uint8))   # BGR: blue, green, red, grey
+    assert hsv[0, :, 0].tolist() == [120, 60, 0, 0] and hsv[0, :3, 1].tolist() == [255, 255, 255] and hsv[0, 3].tolist() == [0, 0, 128]
+    np.random.seed(5)
+    outs = [D.PhotoMetricDistortion()(dict(img=img.copy()))["img"] for _ in range(8)]
+    assert all(o.dtype == np.uint8 and o.shape == img.shape for o in outs) and any((o != img).any() for o in outs)
+
+
+def test_rare_class_sampling(tmp_path):
+    root = str(tmp_path)
+    _tree(root)
+    classes, probs = D.get_rcs_class_probs(root, 0.01)
+    stats = json.load(open(os.path.join(root, "sample_class_stats.json")))
+    tot = {}
+    for s in stats:
+        for c, n in s.items():
+            if c != "file":
+                tot[int(c)] = tot.get(int(c), 0) + n
+    order = sorted(tot, key=lambda c: tot[c])
+    freq = np.array([tot[c] for c in order], np.float64)
+    ref = np.exp((1 - freq / freq.sum()) / 0.01)
+    ref /= ref.sum()
+    assert classes == order and np.allclose(probs, ref, rtol=1e-4) and classes[0] == 18   # the rarest class leads
+    ds = DATASETS.build(_cfg(root, crop=(96, 160)))
+    np.random.seed(0)
+    got = [ds[0] for _ in range(12)]
+    names = {os.path.basename(g["data_samples"].metainfo["seg_map_path"]) for g in got}
+    assert "s4_labelTrainIds.png" in names       # class 18 dominates p(c) at T = 0.01 and only s4 holds it
+    rare = [g for g in got if g["data_samples"].metainfo["seg_map_path"].endswith("s4_labelTrainIds.png")]
+    assert all(int((g["data_samples"].gt_sem_seg.data == 18).sum()) > 200 for g in rare)   # min_pixels * min_crop_ratio, full-size crop
+
+
+def test_infinite_sampler_shards_one_stream(tmp_path):
+    a = D.InfiniteSampler(7, True, seed=3, rank=0, world=2)
+    b = D.InfiniteSampler(7, True, seed=3, rank=1, world=2)
+    one = D.InfiniteSampler(7, True, seed=3)
+    ia, ib, io = iter(a), iter(b), iter(one)
+    merged = [next(io) for _ in range(28)]
+    assert [next(ia) for _ in range(14)] == merged[0::2] and [next(ib) for _ in range(14)] == merged[1::2]
+    assert sorted(merged[:7]) == list(range(7)) and sorted(merged[7:14]) == list(range(7))
+    root = str(tmp_path)
+    _tree(root)
+    it = D.DataLoaderIter(_cfg(root), batch_size=2, num_workers=0, seed=0)
+    batch = next(it)
+    assert len(batch["inputs"]) == 2 and batch["inputs"][0].dtype == torch.uint8 and len(batch["data_samples"]) == 2 and it.i == 1
+    with pytest.raises(FileNotFoundError):
+        DATASETS.build(dict(type="CityscapesDataset", data_root=os.path.join(root, "nope"), data_prefix=dict(img_path="x", seg_map_path="y")))

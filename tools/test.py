@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Evaluation entry point (tools/test.py:96-145): CONFIG CHECKPOINT [--backbone PTH --work-dir --cfg-options].
-Runs the configured test mode (ms_slide_inference / slide) over synthetic images and reports mIoU against the
-labels (mmseg IoUMetric semantics) and ms/img."""
+Runs the configured test mode (ms_slide_inference / slide) over the config's test_dataloader.dataset when its data_root exists
+(test pipeline: LoadImageFromFile, Resize(keep_ratio), LoadAnnotations, PackSegInputs -> SegDataPreProcessor -> predict ->
+postprocess to ori_shape), else over synthetic images, and reports mIoU against the labels (mmseg IoUMetric / DGIoUMetric
+semantics) and ms/img."""
 import argparse
 import os
 import sys
@@ -20,6 +22,7 @@ def main():
     ap.add_argument("--images", type=int, default=4)
     ap.add_argument("--size", type=int, nargs=2, default=[1024, 1024])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--data", choices=["auto", "synthetic", "real"], default="auto")
     a = ap.parse_args()
     import torch
     import vfmseg_amd  # noqa: F401
@@ -46,6 +49,31 @@ def main():
     metric = METRICS.build(ev)      # DGIoUMetric (rein/dg_metrics.py) with the config's dataset_keys, or mmseg's IoUMetric
     keys = list(getattr(metric, "dataset_keys", [])) or ["synthetic"]
     t = 0.0
+    dl = dict(cfg.get("test_dataloader") or cfg.get("val_dataloader") or {})
+    ds_cfg = dl.get("dataset")
+    root = (ds_cfg.get("source", ds_cfg) if isinstance(ds_cfg, dict) else {}).get("data_root") if ds_cfg else None
+    real = a.data == "real" or (a.data == "auto" and root and os.path.isdir(root))
+    if real:
+        from vfmseg_amd.datasets import DataLoaderIter
+        it = DataLoaderIter(ds_cfg, 1, dl.get("num_workers", 0), shuffle=False, infinite=False)
+        if hasattr(it.dataset, "metainfo"):
+            metric.dataset_meta = dict(classes=it.dataset.metainfo["classes"])
+        n = 0
+        for batch in it.loader:
+            data = model.data_preprocessor(batch, False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = model.predict(data["inputs"], data["data_samples"])
+            torch.cuda.synchronize()
+            t += time.perf_counter() - t0
+            metric.process(None, out)
+            n += 1
+            if a.images and n >= a.images and a.data != "real":
+                break
+        res = dict(metric.evaluate(n))
+        res["ms_per_img"] = 1e3 * t / max(n, 1)
+        print(res)
+        return
     for i in range(a.images):
         img, lab = synth_image(1, tuple(a.size), seed=500 + i).cuda(), synth_label(1, tuple(a.size), seed=500 + i).cuda()
         torch.cuda.synchronize()

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--local_rank", "--local-rank", type=int, default=0)
     ap.add_argument("--max-iters", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--data", choices=["auto", "synthetic", "real"], default="auto",
+                    help="auto: read train_dataloader.dataset when its data_root exists, else the synthetic 19-class stream")
     a = ap.parse_args()
     if "LOCAL_RANK" not in os.environ:
         os.environ["LOCAL_RANK"] = str(a.local_rank)
@@ -46,7 +48,15 @@ def main():
         cfg["model"]["train_cfg"] = {}
     cfg["model"]["train_cfg"]["work_dir"] = cfg["work_dir"]           # tools/train.py:108-109
     cfg["model"]["train_cfg"]["log_config"] = cfg.get("log_config", dict(interval=50, img_interval=500))
-    runner = Runner.from_cfg(cfg)
+    synthetic = a.data == "synthetic"
+    if a.data == "auto":
+        ds = dict(cfg.get("train_dataloader", {}) or {}).get("dataset") or {}
+        src = ds.get("source", ds) if isinstance(ds, dict) else {}
+        root = src.get("data_root") if isinstance(src, dict) else None
+        synthetic = not (root and os.path.isdir(root))
+        if synthetic:
+            print(f"[train] data_root {root!r} not found: training on the synthetic stream (--data real to insist)")
+    runner = Runner.from_cfg(cfg, synthetic=synthetic)
     if a.resume:
         from vfmseg_amd.runner import find_latest_checkpoint
         ck = find_latest_checkpoint(cfg["work_dir"])

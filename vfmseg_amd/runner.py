@@ -77,19 +77,24 @@ class Runner:
         ctor = OPTIM_WRAPPER_CONSTRUCTORS.get(ow_cfg.get("constructor", "PEFTOptimWrapperConstructor")) or PEFTOptimWrapperConstructor
         ow = ctor(ow_cfg, ow_cfg.get("paramwise_cfg"))(model, cfg.get("param_scheduler"))
         parallel.attach(model, ow)
-        ds = (cfg.get("train_dataloader", {}) or {}).get("dataset")
+        dl = dict(cfg.get("train_dataloader", {}) or {})
+        ds = dl.get("dataset")
+        bs = dl.get("batch_size", 2)
+        loader = None
         if ds is not None and not synthetic:
-            raise NotImplementedError(
-                "train_dataloader.dataset is configured, but the dataset / augmentation chain (mmseg-side, SURVEY 8 row f4) is not "
-                "part of this build: run with synthetic=True (tools/train.py default) or feed Runner(loader=...) an iterator of "
-                "dict(inputs=uint8|float32 CHW images, data_samples=[SegDataSample]) - SegDataPreProcessor takes both")
-        if ds is not None and rank == 0:
+            # the reference's input pipeline (configs/dg/datasets/*.py -> DGDataset + rare class sampling over a CityscapesDataset
+            # folder tree, mmseg transform chain, InfiniteSampler): vfmseg_amd.datasets.  Fails loudly when the data are not there.
+            from .datasets import DataLoaderIter
+            shuffle = dict(dl.get("sampler", {}) or {}).get("shuffle", True)
+            loader = DataLoaderIter(ds, bs, dl.get("num_workers", 0), shuffle, seed, rank, world, infinite=True)
+        elif ds is not None and rank == 0:
             import warnings
             warnings.warn(f"train_dataloader.dataset ({ds.get('type', '?') if isinstance(ds, dict) else type(ds).__name__}) is NOT read: "
-                          "this build trains on the synthetic 19-class stream (no datasets offline; SURVEY 8 row f4)")
-        bs = cfg.get("train_dataloader", {}).get("batch_size", 2)
-        size = tuple(cfg.get("crop_size", cfg["model"].get("data_preprocessor", {}).get("size", (1024, 1024))))
-        loader = SyntheticLoader(bs, size, rank, world, seed)
+                          "synthetic=True trains on the synthetic 19-class stream (pass synthetic=False / tools/train.py --real-data "
+                          "to read it through vfmseg_amd.datasets)")
+        if loader is None:
+            size = tuple(cfg.get("crop_size", cfg["model"].get("data_preprocessor", {}).get("size", (1024, 1024))))
+            loader = SyntheticLoader(bs, size, rank, world, seed)
         work_dir = cfg.get("work_dir", "./work_dirs/run")
         return cfg_cls(cfg, model, ow, loader, work_dir, rank, world)
 
@@ -134,7 +139,7 @@ class Runner:
             out = self.model.train_step(data, self.ow)
             self.iter += 1
             if self.iter % log_interval == 0 or self.iter == max_iters:
-                rec = {k: float(v) for k, v in out.items() if v is not None}  # one sync per log interval
+                rec = {k: float(v.detach() if torch.is_tensor(v) else v) for k, v in out.items() if v is not None}  # one sync per log interval
                 rec.update(iter=self.iter, lr=self.ow.get_lr(), time=(time.time() - t0) / log_interval,
                            memory=torch.cuda.max_memory_allocated() // (1 << 20))
                 t0 = time.time()

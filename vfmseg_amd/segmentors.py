@@ -93,7 +93,7 @@ class SegDataPreProcessor(nn.Module):
                 h, w = im.shape[-2:]
                 gt = getattr(s_, "gt_sem_seg", None)
                 g = None if gt is None else (gt if torch.is_tensor(gt) else gt.data)
-                if g is not None and tuple(g.shape[-2:]) != (hp, wp):
+                if training and g is not None and tuple(g.shape[-2:]) != (hp, wp):   # (test mode: stack_batch pads the images only)
                     pad = torch.full(tuple(g.shape[:-2]) + (hp, wp), self.seg_pad_val, dtype=g.dtype, device=g.device)
                     pad[..., :g.shape[-2], :g.shape[-1]] = g
                     s_.gt_sem_seg = PixelData(pad)
