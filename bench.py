@@ -58,7 +58,7 @@ class KernelTimer:
     the measurement hook of vfmseg_amd.ops: every `every`-th launch is bracketed by an event pair (sampling keeps the event cost off
     the step time; a prime period cycles through every launch site over the steps).  Sums are kept per (kind, region)."""
 
-    def __init__(self, every=7):
+    def __init__(self, every=31):
         self.recs = []
         self.on = False
         self.calls = 0
@@ -231,8 +231,8 @@ def main():
     real_stdout = _reserve_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=2, help="samples per GPU (reference: 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
