@@ -321,7 +321,10 @@ static int g_fold_tail = 1;  // run the tail rows as extra blocks of the tile ke
 // per shape (+2.6 % images/s).  The big-tile kernels win on long-K / light-epilogue shapes (4096^3: 1.26 PF vs 1.0) and stay
 // selectable per call (vfm_tune gemm_cfg 30..33).
 static int g_use_pp = 40;
-static int g_deep_tail_k = 0;  // K from which one-tile-per-CU launches WITH tail blocks take the seven-chunk ring (0 = never)
+static int g_deep_tail_k = 0;  // K from which one-tile-per-CU launches WITH tail rows take the seven-chunk ring, the tail rows riding
+                               // inside the regular blocks (gemm_w4.hip CLSIN); 0 = never (five-chunk ring + tail blocks).  Measured:
+                               // with cold operands 62.8 -> 53.9 us at K = 4096 (19.8 -> 22.2 at K = 1024), inside the train step
+                               // (operands warm in L2 / Infinity Cache) 127.1 -> 124.6 images/s with K >= 2048: off
 extern "C" int vfm_tune(const char* key, int value) {
   if (key && strcmp(key, "gemm_cfg") == 0) {
     g_force_cfg = value;

@@ -42,7 +42,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 // P = prefetch depth: the ring has NCH = 2P + 1 chunk slots (P = 2: the five-chunk ring described above; chunk 2v+2P-1 .. 2v+2P+1
 // are issued during iteration v, and the wait before the last k-step leaves 2P-3 whole chunks in flight).  P = 4 (nine slots, 144 KiB
 // for 128 x 128 tiles) is for launches with at most one tile per CU, where the LDS of the second block would lie idle.
-template <bool VEC, int MI, int NI, int WM_W, int WN_W, int P = 2, int DBG = 0>
+// CLSIN (8-wave 128 x 128 forms): the tail rows of M (<= 32: the [cls] rows of the token-major layout) are not extra blocks of the
+// launch but ride inside ONE regular block per tile column: that block's waves issue one more MFMA per k-step - the tail rows'
+// A fragment (straight from global memory, a K-tile ahead) against the B fragment they hold anyway.  Tail blocks cannot share
+// a CU with a deep ring (they would reserve its whole LDS and wait for a free CU: measured 46 -> 51 us); this way the
+// one-tile-per-CU shapes (N = 1024: 96 launches per train step) get the seven-chunk ring.  The 8 blocks concerned do 3 MFMAs
+// per k-step instead of 2, inside a loop that is bound by the operand stream, not by the matrix pipe.
+template <bool VEC, int MI, int NI, int WM_W, int WN_W, int P = 2, int DBG = 0, bool CLSIN = false>
 __global__ void __launch_bounds__(WM_W* WN_W * 64)
     k_gemm_w4(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, long M, long N, long K, long stride_a,
               long stride_b, long stride_c, int tiles_m, int tiles_n, EpiParams e, SkinnyTail sk) {
@@ -54,7 +60,7 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   static_assert(PPC >= 2 && PPC % 2 == 0, "a wave moves whole halves of a chunk");
   constexpr int NMF = MI * NI, NRD = MI + NI, NOPS = NRD + PPS;  // per k-step: MFMAs, fragment reads, memory ops
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if constexpr (WAVES == 8 && NCH * CH >= 65536) {  // the tail rows of M run as extra blocks at the end of the grid
+  if constexpr (WAVES == 8 && NCH * CH >= 65536 && !CLSIN) {  // the tail rows of M run as extra blocks at the end of the grid
     if (sk.nblk > 0 && (int)blockIdx.x >= tiles_m * tiles_n) {
       skinny_tile(sk.A, sk.lda, B, ldb, sk.M, N, K, (long)((int)blockIdx.x - tiles_m * tiles_n) * 32, sk.e, 0, smem);
       return;
@@ -129,9 +135,49 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   const int nk = (int)(K / 64);  // >= P (checked by the dispatcher)
   bf16x8 fa[2][MI], fb[2][NI];   // [buffer][block]
 
+  // ---- tail rows inside the block (CLSIN): this block owns them for its 128 columns when tm == tn % tiles_m.
+  // Their A fragments go through LDS like everything else (a ring of eight 1-KiB slots behind the chunk ring: eight rows x one
+  // 128-B K-tile row, same XOR swizzle), fetched by LDS-DMA four K-tiles ahead.  (Plain global loads into registers made the
+  // compiler put an s_waitcnt vmcnt(0) at the loop head - its counter state is unknown across the back edge -, which drains the
+  // whole chunk ring every K-tile: 49 -> 75 us.)  Every wave issues the same piece (identical bytes to the same slot), so that
+  // all waves keep the same vmcnt arithmetic.
+  constexpr int CLS_SLOTS = 8, CLS_D = 4;
+  bool cls_blk = false;
+  f32x16 acc_cls;
+  bf16x8 fc[2];            // tail-row fragments, double-buffered per k-step like fa / fb
+  unsigned cls_soff = 0;   // per-lane source offset inside a K-tile row block
+  int rc[4] = {0, 0, 0, 0};
+  char* cls_base = smem + NCH * CH;
+  if constexpr (CLSIN) {
+    static_assert(MI == 2 && NI == 1 && WAVES == 8, "CLSIN is written for the 64 x 32 wave tiles of the 8-wave 128 x 128 form");
+    cls_blk = sk.nblk > 0 && tm == tn % tiles_m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_cls[r] = 0.f;
+    {
+      const int r = lane >> 3;                       // staged row 0..7 (rows beyond the tail repeat its last row)
+      long am = r;
+      if (am > sk.M - 1) am = sk.M - 1;
+      cls_soff = (unsigned)((am * sk.lda + (((lane & 7) ^ ((r >> 1) & 7)) << 3)) * 2);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const int rr = fr & 7;                         // accumulator rows 8.. are never stored: any staged row will do
+      rc[s2] = rr * 128 + (((2 * s2 + fh) ^ ((rr >> 1) & 7)) << 4);
+    }
+  }
+  auto main_loop = [&](auto CLSc) __attribute__((always_inline)) {
+  constexpr bool CLS = decltype(CLSc)::value;
+  auto cls_dma = [&](int u) __attribute__((always_inline)) {   // K-tile u (clamped to the last one) -> slot u % CLS_SLOTS
+    const int nkt = (int)(K / 64);
+    const int uu = u < nkt ? u : nkt - 1;
+    const unsigned long long bv = (unsigned long long)sk.A + (unsigned long long)uu * 128;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)bv), hi = __builtin_amdgcn_readfirstlane((unsigned)(bv >> 32));
+    const char* base = (const char*)(((unsigned long long)hi << 32) | lo);
+    glds16(base + cls_soff, cls_base + (u % CLS_SLOTS) * 1024);
+  };
   // one k-step: NMF MFMAs on buffer CUR; spread between them the fragment reads of the next k-step (READ: k-step rs of the
   // chunks at slots pb / pa) and PPS DMA pieces (ISSUE: half H of chunk type CH of K-tile u into slot dpos)
-  auto kstep = [&](auto CURc, auto READc, auto ISSUEc, auto CHc, auto Hc, int pb_slot, int pa_slot, auto RSc, int u, int dpos) {
+  auto kstep = [&](auto CURc, auto READc, auto ISSUEc, auto CHc, auto Hc, int pb_slot, int pa_slot, auto RSc, int u, int dpos, int cls_off = 0) {
     constexpr int cur = decltype(CURc)::value, nxt = cur ^ 1, ch = decltype(CHc)::value, j0 = decltype(Hc)::value * PPS;
     constexpr int rs = decltype(RSc)::value;
     constexpr bool READ = decltype(READc)::value, ISSUE = decltype(ISSUEc)::value;
@@ -156,6 +202,11 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
       });
       __builtin_amdgcn_sched_barrier(0);
     });
+    if constexpr (CLS) {  // the tail rows' MFMA of this k-step against the wave's own B fragment; next k-step's tail fragment
+      acc_cls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc[cur], fb[cur][0], acc_cls, 0, 0, 0);
+      if constexpr (READ) fc[nxt] = *reinterpret_cast<const bf16x8*>(cls_base + cls_off + rc[rs]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
   auto wrap = [](int p) { return p >= NCH ? p - NCH : p; };
   // X: 0 steady (v <= nk-P-1); X = j+1 for the last P K-tiles v = nk-P+j (j = 0: only the second half of the last chunk is left
@@ -165,20 +216,30 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
     constexpr bool LAST = X == P;
     const int q1 = wrap(q + 1), q2 = wrap(q + 2), q3 = wrap(q + 3);
     const int d0 = wrap(q + 2 * P - 1), d1 = wrap(q + 2 * P);
-    kstep(IC<0>{}, IC<true>{}, IC<(X <= 1)>{}, IC<1>{}, IC<1>{}, q, q1, IC<1>{}, v + P - 1, d0);
-    kstep(IC<1>{}, IC<true>{}, IC<(X == 0)>{}, IC<0>{}, IC<0>{}, q, q1, IC<2>{}, v + P, d1);
-    kstep(IC<0>{}, IC<true>{}, IC<(X == 0)>{}, IC<0>{}, IC<1>{}, q, q1, IC<3>{}, v + P, d1);
+    if constexpr (CLS && !LAST) cls_dma(v + CLS_D);   // (one piece, BEFORE this iteration's chunk pieces: see the vmcnt window below)
+    const int co = CLS ? (v % CLS_SLOTS) * 1024 : 0, co1 = CLS ? ((v + 1) % CLS_SLOTS) * 1024 : 0;
+    kstep(IC<0>{}, IC<true>{}, IC<(X <= 1)>{}, IC<1>{}, IC<1>{}, q, q1, IC<1>{}, v + P - 1, d0, co);
+    kstep(IC<1>{}, IC<true>{}, IC<(X == 0)>{}, IC<0>{}, IC<0>{}, q, q1, IC<2>{}, v + P, d1, co);
+    kstep(IC<0>{}, IC<true>{}, IC<(X == 0)>{}, IC<0>{}, IC<1>{}, q, q1, IC<3>{}, v + P, d1, co);
     if constexpr (!LAST) {
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
       constexpr int live = X == 0 ? 2 * P - 3 : (2 * P - 4 - 2 * (X - 1) > 0 ? 2 * P - 4 - 2 * (X - 1) : 0);  // whole chunks in flight
-      wait_vmcnt<live * PPC>();
+      // CLS: the tail-row piece of this iteration sits between the chunk pieces; when the window of pieces that may stay in
+      // flight reaches back past it, it is part of the window (else it is older than the window and completes with it)
+      constexpr int after = X == 0 ? 3 * PPS : (X == 1 ? PPS : 0);   // chunk pieces issued behind the tail-row piece in this iteration
+      constexpr int extra = (CLS && live * PPC > after) ? 1 : 0;
+      wait_vmcnt<live * PPC + extra>();
       __builtin_amdgcn_s_barrier();
     }
     __builtin_amdgcn_sched_barrier(0);
-    kstep(IC<1>{}, IC<!LAST>{}, IC<(X == 0)>{}, IC<1>{}, IC<0>{}, q2, q3, IC<0>{}, v + P, q);
+    kstep(IC<1>{}, IC<!LAST>{}, IC<(X == 0)>{}, IC<1>{}, IC<0>{}, q2, q3, IC<0>{}, v + P, q, co1);
   };
 
   // ---- prologue: chunks 0 .. 2P-2 and the first half of chunk 2P-1 in flight; K-tile 0 landed; fragments of (0, s0)
+  if constexpr (CLS) {   // tail-row pieces of K-tiles 0 .. CLS_D-1 (older than every chunk piece: landed with K-tile 0)
+#pragma unroll
+    for (int u0 = 0; u0 < CLS_D; ++u0) cls_dma(u0);
+  }
   static_for<2 * P - 1>([&](auto Cc) {
     constexpr int c = decltype(Cc)::value;
     dma_half(IC<(c & 1)>{}, IC<0>{}, c >> 1, c), dma_half(IC<(c & 1)>{}, IC<1>{}, c >> 1, c);
@@ -191,6 +252,7 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   for (int i = 0; i < MI; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + CH + ra[0] + i * 4096);
 #pragma unroll
   for (int j = 0; j < NI; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(smem + rb[0] + j * 4096);
+  if constexpr (CLS) fc[0] = *reinterpret_cast<const bf16x8*>(cls_base + rc[0]);
   __builtin_amdgcn_sched_barrier(0);
 
   int v = 0, q = 0;
@@ -204,6 +266,13 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
     q = wrap(q + 2);
   });
   __builtin_amdgcn_sched_barrier(0);
+  };  // main_loop
+  if constexpr (CLSIN) {
+    if (cls_blk) main_loop(IC<true>{});   // (two copies of the loop: a branch inside it would break the hand-placed schedule)
+    else main_loop(IC<false>{});
+  } else {
+    main_loop(IC<false>{});
+  }
 
   // ---- epilogue (accumulators -> per-wave fp32 LDS image -> 16-byte rows), one 64-row half of the wave tile at a time
   const long zoff = z * stride_c;
@@ -229,25 +298,36 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
     if constexpr (VEC) epi_wave_tile<2, NI, 2>(e, zoff, acc[h], img, lane, mw + h * 64, nw, M, N);
     else epi_scalar<2, NI, 2>(e, zoff, acc[h], img, lane, mw + h * 64, nw, M, N);
   });
+  if constexpr (CLSIN) {
+    // tail rows: accumulator register r of lane (fr, fh) is row (r & 3) + 8 (r >> 2) + 4 fh, column nw + fr; all eight waves
+    // computed them (no branch in the loop), the wm == 0 waves store
+    if (cls_blk && wm == 0 && nw + fr < N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long row = (r & 3) + 8 * (r >> 2) + 4 * fh;
+        if (row < sk.M) epi_store(sk.e, 0, row, nw + fr, acc_cls[r]);
+      }
+    }
+  }
 }
 
 extern int g_pp_dbg;
-template <bool VEC, int MI, int NI, int WM_W, int WN_W, int P, int DBG>
+template <bool VEC, int MI, int NI, int WM_W, int WN_W, int P, int DBG, bool CLSIN = false>
 static bool launch_w4_t(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail) {
   constexpr int T = WM_W * MI * 32, WAVES = WM_W * WN_W;
-  constexpr int RING = (2 * P + 1) * T * 128, EPI = WAVES * 64 * (NI * 32 + 4) * 4, SMEM = RING > EPI ? RING : EPI;
+  constexpr int RING = (2 * P + 1) * T * 128 + (CLSIN ? 8 * 1024 : 0), EPI = WAVES * 64 * (NI * 32 + 4) * 4, SMEM = RING > EPI ? RING : EPI;
   const int tiles_m = cdiv(d->M, T), tiles_n = cdiv(d->N, T);
   const long batch = d->batch > 0 ? d->batch : 1;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_gemm_w4<VEC, MI, NI, WM_W, WN_W, P, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipFuncSetAttribute((const void*)k_gemm_w4<VEC, MI, NI, WM_W, WN_W, P, DBG, CLSIN>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr = true;
   }
   SkinnyTail sk;
   sk.nblk = 0;
-  const bool fold = tail && batch == 1 && WAVES == 8 && RING >= 65536;
+  const bool fold = tail && batch == 1 && WAVES == 8 && RING >= 65536 && (!CLSIN || (tail->M <= 8 && tail->sa_k == 1));
   if (fold) sk.A = (const bf16_t*)tail->A, sk.lda = tail->sa_m, sk.M = tail->M, sk.nblk = cdiv(tail->N, 32), sk.e = make_epi(tail);
-  hipLaunchKernelGGL((k_gemm_w4<VEC, MI, NI, WM_W, WN_W, P, DBG>), dim3(tiles_m * tiles_n + sk.nblk, (unsigned)batch), dim3(WAVES * 64), SMEM, s,
+  hipLaunchKernelGGL((k_gemm_w4<VEC, MI, NI, WM_W, WN_W, P, DBG, CLSIN>), dim3(tiles_m * tiles_n + (CLSIN ? 0 : sk.nblk), (unsigned)batch), dim3(WAVES * 64), SMEM, s,
                      (const bf16_t*)d->A, d->sa_m, (const bf16_t*)d->B, d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c,
                      tiles_m, tiles_n, make_epi(d), sk);
   return fold || !tail;
@@ -265,8 +345,16 @@ bool vfm_gemm_launch_w4(const vfm_gemm_desc* d, hipStream_t s, bool vec, const v
     if (g_pp_dbg == 4) return launch_w4_t<true, 4, 2, 2, 4, 2, 4>(d, s, tail);
     return g_pp_dbg == 1 ? launch_w4_t<true, 4, 2, 2, 4, 2, 1>(d, s, tail) : launch_w4_t<true, 4, 2, 2, 4, 2, 0>(d, s, tail);
   }
-  if (form == 5) return vec ? launch_w4_t<true, 2, 1, 2, 4, 4, 0>(d, s, tail) : launch_w4_t<false, 2, 1, 2, 4, 4, 0>(d, s, tail);
-  if (form == 3) return vec ? launch_w4_t<true, 2, 1, 2, 4, 3, 0>(d, s, tail) : launch_w4_t<false, 2, 1, 2, 4, 3, 0>(d, s, tail);
+  // deep rings (one block per CU): tail rows ride inside the regular blocks (CLSIN)
+  const bool clsin = tail && (d->batch <= 1) && tail->M <= 8 && tail->sa_k == 1;
+  if (form == 5) {
+    if (clsin) return vec ? launch_w4_t<true, 2, 1, 2, 4, 4, 0, true>(d, s, tail) : launch_w4_t<false, 2, 1, 2, 4, 4, 0, true>(d, s, tail);
+    return vec ? launch_w4_t<true, 2, 1, 2, 4, 4, 0>(d, s, tail) : launch_w4_t<false, 2, 1, 2, 4, 4, 0>(d, s, tail);
+  }
+  if (form == 3) {
+    if (clsin) return vec ? launch_w4_t<true, 2, 1, 2, 4, 3, 0, true>(d, s, tail) : launch_w4_t<false, 2, 1, 2, 4, 3, 0, true>(d, s, tail);
+    return vec ? launch_w4_t<true, 2, 1, 2, 4, 3, 0>(d, s, tail) : launch_w4_t<false, 2, 1, 2, 4, 3, 0>(d, s, tail);
+  }
   if (!vec) return launch_w4_t<false, 2, 1, 2, 4, 2, 0>(d, s, tail);
   if (g_pp_dbg == 1) return launch_w4_t<true, 2, 1, 2, 4, 2, 1>(d, s, tail);   // diagnostic: no epilogue => the MFMAs are dead code too:
                                                                                // what is left is the operand stream (DMA + barriers)
