@@ -51,6 +51,8 @@ int vfm_strided_copy(const void* src, int src_dt, void* dst, int dst_dt, long n0
 typedef struct vfm_copy_job {
   const float* src; void* dst; long dst_dt; long accumulate;   /* accumulate != 0: dst (fp32) += src */
   long n[4], s[4], d[4];
+  long nsum, sum_stride;   /* nsum > 1: the value copied is the sum of nsum source slices sum_stride elements apart (the
+                            * partial results of a reduction cut into nsum batch entries); 0 / 1: a plain copy */
 } vfm_copy_job;
 int vfm_strided_copy_batch(const vfm_copy_job* table_dev, int njobs, long max_elems, void* stream);
 /* y = a*x + b*y elementwise over n fp32 values (gradient accumulation, residual adds) */

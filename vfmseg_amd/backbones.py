@@ -606,24 +606,38 @@ class DinoEngine:
         ws = P.setdefault("wg_ws", {})
         key = (lo, hi, M)
         w = ws.get(key)
+        # dA has only D / 128 output tiles per layer (its 64 rows are one tile row): n * 8 = 96 blocks for 256 CUs.  The token
+        # reduction is therefore cut into `ksp` equal row ranges that run as batch entries of their own (each layer's rows are
+        # contiguous, so range c of layer l is entry ksp * l + c of ONE strided batch) and meet in the scatter-accumulate below.
+        ksp = 4 if (M % 4 == 0 and n * (D // 128) * 4 <= 512) else (2 if (M % 2 == 0 and n * (D // 128) * 2 <= 512) else 1)
+        if os.environ.get("VFMSEG_LORA_WGRAD_KSPLIT", "1") == "0":
+            ksp = 1
         if w is None:
             w = ws[key] = dict(outB=torch.empty(n, R_PAD, 3 * D, dtype=torch.float32, device=dev),
-                               outA=torch.empty(n, R_PAD, D, dtype=torch.float32, device=dev), table=None, sig=None)
+                               outA=torch.empty(n * ksp, R_PAD, D, dtype=torch.float32, device=dev), table=None, sig=None)
         A1all, XDall = ctx["A1all"], ctx["XDall"]
         q0 = v.blocks[lo].attn.qkv
         ops.gemm_tn_batched(A1all[lo:hi, :, D:D + R_PAD], DQKVall[lo:hi], w["outB"], M)                       # dB^T = T^T dqkv
         Y = XDall[lo:hi] if XDall is not None else A1all[lo:hi, :, :D]
-        ops.gemm_tn_batched(DA1all[lo:hi, :, D:D + R_PAD], Y, w["outA"], M, alpha=q0.scaling)                 # dA = s dT^T drop(LN x)
+        dT = DA1all[lo:hi, :, D:D + R_PAD]
+        if ksp > 1:
+            mk = M // ksp
+            dT = dT.as_strided((n * ksp, mk, R_PAD), (mk * dT.stride(1), dT.stride(1), 1), dT.storage_offset())
+            Y = Y.as_strided((n * ksp, mk, D), (mk * Y.stride(1), Y.stride(1), 1), Y.storage_offset())
+            ops.gemm_tn_batched(dT, Y, w["outA"], mk, alpha=q0.scaling)                                       # dA = s dT^T drop(LN x)
+        else:
+            ops.gemm_tn_batched(dT, Y, w["outA"], M, alpha=q0.scaling)
         tg = []
         for l in range(lo, hi):
             q = v.blocks[l].attn.qkv
             tg.append((direct_grad_target(q.lora_A["default"].weight), direct_grad_target(q.lora_B["default"].weight), q.r))
-        sig = tuple((a.data_ptr(), b.data_ptr()) for a, b, _ in tg)
+        sig = tuple((a.data_ptr(), b.data_ptr()) for a, b, _ in tg) + (ksp,)
         if w["table"] is None or w["sig"] != sig:
             jobs = []
             for i, (tA, tB, r) in enumerate(tg):
                 jobs.append((w["outB"][i], tB, (3 * D, r), (1, 3 * D), (r, 1), True))     # B.grad[n, rr] += outB[rr, n]
-                jobs.append((w["outA"][i], tA, (r, D), (D, 1), (D, 1), True))             # A.grad[rr, k] += outA[rr, k]
+                # A.grad[rr, k] += sum over the ksp token ranges of outA[rr, k] (ONE job: jobs of a table run concurrently)
+                jobs.append((w["outA"][i * ksp], tA, (r, D), (D, 1), (D, 1), True, ksp, R_PAD * D))
             w["table"], w["sig"] = ops.CopyBatch(jobs), sig
         w["table"].run()
 

@@ -252,7 +252,9 @@ __global__ void __launch_bounds__(256) k_strided_copy_batch(const vfm_copy_job* 
     const unsigned i3 = r % n3; r /= n3;
     const unsigned i2 = r % n2; r /= n2;
     const unsigned i1 = r % n1; r /= n1;
-    const float v = t.src[(long)r * t.s[0] + (long)i1 * t.s[1] + (long)i2 * t.s[2] + (long)i3 * t.s[3]];
+    const float* sp = t.src + ((long)r * t.s[0] + (long)i1 * t.s[1] + (long)i2 * t.s[2] + (long)i3 * t.s[3]);
+    float v = sp[0];
+    for (long c = 1; c < t.nsum; ++c) v += sp[c * t.sum_stride];   // partial results of one reduction, summed in a fixed order
     const long o = (long)r * t.d[0] + (long)i1 * t.d[1] + (long)i2 * t.d[2] + (long)i3 * t.d[3];
     if (t.accumulate) ((float*)t.dst)[o] += v;
     else st_any(t.dst, o, (int)t.dst_dt, v);

@@ -96,8 +96,10 @@ def strided_copy(src, dst, shape, sstr, dstr, accumulate=False):
 
 
 class CopyBatch:
-    """Device table for vfm_strided_copy_batch: jobs = [(src fp32 tensor, dst tensor, shape, src strides, dst strides)], each
-    up to 4-D; run() performs all of them in one launch.  The tensors are kept alive by the table."""
+    """Device table for vfm_strided_copy_batch: jobs = [(src fp32 tensor, dst tensor, shape, src strides, dst strides[, accumulate
+    [, nsum, sum_stride]])], each up to 4-D; run() performs all of them in one launch.  The tensors are kept alive by the table.
+    Jobs of one table run concurrently: two jobs must not accumulate into the same destination - sum the partials of one
+    reduction with nsum / sum_stride instead."""
 
     def __init__(self, jobs):
         import struct
@@ -106,10 +108,11 @@ class CopyBatch:
         for job in jobs:
             src, dst, shape, sstr, dstr = job[:5]
             acc = int(bool(job[5])) if len(job) > 5 else 0    # optional 6th item: accumulate into an fp32 dst
+            nsum, sstride = (int(job[6]), int(job[7])) if len(job) > 7 else (1, 0)
             assert src.dtype == torch.float32 and src.is_cuda and dst.is_cuda and (not acc or dst.dtype == torch.float32)
             k = 4 - len(shape)
             n, s_, d_ = [1] * k + list(shape), [0] * k + list(sstr), [0] * k + list(dstr)
-            buf += struct.pack("2Q14q", src.data_ptr(), dst.data_ptr(), L.dt_of(dst), acc, *n, *s_, *d_)
+            buf += struct.pack("2Q16q", src.data_ptr(), dst.data_ptr(), L.dt_of(dst), acc, *n, *s_, *d_, nsum, sstride)
             self.keep += [src, dst]
             e = 1
             for v in shape:
