@@ -57,7 +57,7 @@ def main():
         fl = 2.0 * M * N * K
         ref = (a.float() @ b.float().t())
         res_line = []
-        cfgs = [int(x) for x in os.environ.get("CFGS", "8,12,15,16,17,24").split(",")]
+        cfgs = [int(x) for x in os.environ.get("CFGS", "-1,34,33,17").split(",")]
         for cfg in cfgs:
             ops.tune("gemm_cfg", cfg)
             try:
