@@ -614,6 +614,37 @@ def test_upsample_ce(h, H):
     assert relerr(dl, lr.grad) < 2e-5
 
 
+@pytest.mark.parametrize("h,H,C,mode", [(32, 128, 19, "all_ignored"), (32, 512, 19, "all_ignored"), (16, 64, 19, "none_ignored"), (16, 256, 19, "none_ignored"),
+                                        (32, 128, 7, "band"), (16, 256, 21, "band")])
+def test_upsample_ce_edge_cases(h, H, C, mode):
+    # every pixel ignored (loss 0, zero gradient, accuracy denominators empty), none ignored, and class counts other than 19
+    # (the tiled kernels are instantiated for 19 classes; anything else takes the generic kernels) at the x4 / x16 scale factors
+    B = 2
+    lg = rnd(B, h, h, C, seed=154, scale=2.0)
+    lab = torch.randint(0, C, (B, H, H), generator=torch.Generator().manual_seed(155))
+    if mode == "all_ignored":
+        lab[:] = 255
+    elif mode == "band":
+        lab[:, 3:11] = 255
+    lr = lg.clone().requires_grad_(True)
+    up = F.interpolate(lr.permute(0, 3, 1, 2), size=(H, H), mode="bilinear", align_corners=False)
+    loss_ref = F.cross_entropy(up, lab, reduction="none", ignore_index=255).mean()
+    loss_ref.backward()
+    valid = lab != 255
+    hits_ref = ((up.argmax(1) == lab) & valid).sum().item()
+    loss, counts, dl = ops.upsample_ce(lg.to(DEV), lab.to(DEV))
+    assert abs(loss.item() - loss_ref.item()) < 1e-5 * max(1, abs(loss_ref.item()))
+    assert counts.tolist() == [hits_ref, int(valid.sum())]
+    if mode == "all_ignored":
+        assert float(dl.abs().max()) == 0.0 and loss.item() == 0.0
+    else:
+        assert relerr(dl, lr.grad) < 2e-5
+    loss2, acc2, _ = ops.upsample_ce_loss_acc(lg.to(DEV), lab.to(DEV))   # the training form: accuracy = 100 * hits / (valid + eps)
+    assert abs(loss2.item() - loss_ref.item()) < 1e-5 * max(1, abs(loss_ref.item()))
+    eps = torch.finfo(torch.float32).eps
+    assert abs(acc2.item() - 100.0 * hits_ref / (int(valid.sum()) + eps)) < 1e-3
+
+
 def test_inference_helpers():
     B, C, H, W = 1, 19, 96, 128
     lg = rnd(B, C, H, W, seed=56, scale=2.0)
