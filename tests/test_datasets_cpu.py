@@ -138,3 +138,19 @@ def test_infinite_sampler_shards_one_stream(tmp_path):
     assert len(batch["inputs"]) == 2 and batch["inputs"][0].dtype == torch.uint8 and len(batch["data_samples"]) == 2 and it.i == 1
     with pytest.raises(FileNotFoundError):
         DATASETS.build(dict(type="CityscapesDataset", data_root=os.path.join(root, "nope"), data_prefix=dict(img_path="x", seg_map_path="y")))
+
+
+def test_load_annotations_reduce_zero_label_and_label_map(tmp_path):
+    from PIL import Image
+    lab = np.array([[0, 1, 2, 255], [3, 0, 254, 7]], np.uint8)
+    fn = str(tmp_path / "l.png")
+    Image.fromarray(lab).save(fn)
+    r = D.LoadAnnotations(reduce_zero_label=True)(dict(seg_map_path=fn, seg_fields=[]))
+    # mmseg: 0 -> 255 (ignored), every other id shifts down by one, 255 stays 255 (254 + 1 - 1 ... the 254 -> 255 rule)
+    assert r["gt_seg_map"].tolist() == [[255, 0, 1, 255], [2, 255, 253, 6]] and r["seg_fields"] == ["gt_seg_map"]
+    r = D.LoadAnnotations()(dict(seg_map_path=fn, seg_fields=[], label_map={7: 0, 3: 255}))
+    assert r["gt_seg_map"].tolist() == [[0, 1, 2, 255], [255, 0, 254, 0]]
+    packed = D.PackSegInputs()(dict(img=np.zeros((2, 4, 3), np.uint8), gt_seg_map=r["gt_seg_map"], img_path="x.png", ori_shape=(2, 4),
+                                    img_shape=(2, 4), flip=False))
+    assert tuple(packed["inputs"].shape) == (3, 2, 4) and packed["data_samples"].metainfo["img_path"] == "x.png"
+    assert packed["data_samples"].gt_sem_seg.data.dtype == torch.int64

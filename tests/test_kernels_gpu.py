@@ -645,6 +645,27 @@ def test_upsample_ce_edge_cases(h, H, C, mode):
     assert abs(acc2.item() - 100.0 * hits_ref / (int(valid.sum()) + eps)) < 1e-3
 
 
+def test_copy_batch_sums_partials():
+    # one launch, several jobs: plain strided copy into bf16, accumulate into fp32, and a job whose value is the sum of four source
+    # slices (the token-range partials of a reduction; jobs of a table run concurrently, so partials must not be separate jobs)
+    g = torch.Generator().manual_seed(70)
+    a = torch.randn(6, 10, generator=g).to(DEV)
+    d1 = torch.zeros(10, 6, dtype=torch.bfloat16, device=DEV)
+    parts = torch.randn(4, 5, 7, generator=g).to(DEV)
+    d2 = torch.ones(5, 7, device=DEV)
+    b = torch.randn(3, 4, generator=g).to(DEV)
+    d3 = torch.full((3, 4), 2.0, device=DEV)
+    tab = ops.CopyBatch([(a, d1, (6, 10), (10, 1), (1, 6)),                       # transpose into bf16
+                         (parts[0], d2, (5, 7), (7, 1), (7, 1), True, 4, 35),      # d2 += parts.sum(0)
+                         (b, d3, (3, 4), (4, 1), (4, 1), True)])                   # d3 += b
+    tab.run()
+    assert torch.equal(d1.float().cpu(), a.t().bfloat16().float().cpu())
+    assert relerr(d2, 1.0 + parts.sum(0)) < 1e-6
+    assert relerr(d3, 2.0 + b) < 1e-7
+    tab.run()                                                                     # tables are reusable: accumulates again
+    assert relerr(d2, 1.0 + 2 * parts.sum(0)) < 1e-6
+
+
 def test_inference_helpers():
     B, C, H, W = 1, 19, 96, 128
     lg = rnd(B, C, H, W, seed=56, scale=2.0)
