@@ -408,8 +408,11 @@ static bool aligned_ok(const vfm_attn_desc* d, bool bwd) {
   return r;
 }
 
-// 2-wave blocks when the 4-wave grid would not even give every CU one block
-static bool short_grid(const vfm_attn_desc* d, int n) { return (long)cdiv(n, 128) * d->B * d->H < 256; }
+// 2-wave blocks (64 stationary positions) when the 4-wave grid would give the CUs at most ~1.5 blocks: half-size blocks then
+// balance better (2049 tokens x 16 heads, the coarse eval pass: 272 blocks of 128 = two for 16 CUs and one for the rest, against
+// 528 of 64 = two or three of half the size everywhere; three fit a CU).  vfm_tune("attn_short_grid").
+int g_attn_short_grid = 256;   // (384 measured neutral on the eval leg: 16.6 ms/img either way)
+static bool short_grid(const vfm_attn_desc* d, int n) { return (long)cdiv(n, 128) * d->B * d->H < g_attn_short_grid; }
 
 int g_attn_xcd = 1;       // vfm_tune("attn_xcd"): 0 = plain (block, pair) order (A/B of the XCD-local order)
 int g_attn_fwd64 = 0;     // vfm_tune("attn_fwd64"): 1 = use the experimental 64-queries-per-wave forward (attention_fwd64.hip) where it fits

@@ -335,6 +335,11 @@ extern "C" int vfm_tune(const char* key, int value) {
     g_pp_dbg = value;
     return VFM_OK;
   }
+  if (key && strcmp(key, "attn_short_grid") == 0) {
+    extern int g_attn_short_grid;
+    g_attn_short_grid = value;
+    return VFM_OK;
+  }
   if (key && strcmp(key, "attn_xcd") == 0) {
     extern int g_attn_xcd;
     g_attn_xcd = value;
