@@ -414,7 +414,11 @@ int vfm_gemm_bf16_impl(const vfm_gemm_desc* d0, hipStream_t s) {
   // more row tile of the same launch - cheaper than a launch of its own
   // (a few tiles over the 512 resident slots still beat a second launch: the coarse 512 x 1024 inference pass, M = 2049, N = 1024,
   // has 33 x 16 tiles and paid 10 us per GEMM for its one [cls] row)
-  const bool rows64 = d0->N > 32 && d0->K >= 512 && (long)cdiv(d0->M, 128) * cdiv(d0->N, 128) <= 160 &&
+  // (... except where the ping-pong kernel with the tail folded in as skinny blocks is faster still: half a wave of 128 x 128 tiles,
+  // N >= 512, K >= 1024 - the rule in gemm_main)
+  const long t128m = (long)((d0->M - tail) / 128) * cdiv(d0->N, 128);
+  const bool pp_coarse = !(g_use_pp & 64) && tail > 0 && t128m >= 96 && t128m <= 160 && d0->N >= 512 && d0->K >= 1024 && d0->batch <= 1;
+  const bool rows64 = !pp_coarse && d0->N > 32 && d0->K >= 512 && (long)cdiv(d0->M, 128) * cdiv(d0->N, 128) <= 160 &&
                       (long)cdiv(d0->M, 64) * cdiv(d0->N, 64) <= 544;
   if (g_split_tail && !(rows64 && (g_split_tail & 2)) && d0->M > 512 && tail > 0 && tail <= 32 && (d0->batch <= 1)) {
     vfm_gemm_desc dm = *d0, dt = *d0;
@@ -463,7 +467,16 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
     const long nbatch = d->batch > 0 ? d->batch : 1;  // batched launches (SAM's per-window products) fill the chip with their batch
     const long t128 = (long)cdiv(d->M, 128) * cdiv(d->N, 128) * (g_batch_tiles ? nbatch : 1);
     const long t256 = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
+    const bool span31 = (d->M + 128) * d->sa_m < (1l << 31) && (d->N + 128) * d->sb_n < (1l << 31);
+    const bool span33 = (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31);
     if (d->N <= 32) cfg = 10;                                        // 64x64 tiles: many rows, few columns
+    else if (!(g_use_pp & 64) && tail && t128 >= 96 && t128 <= 160 && d->N >= 512 && d->K >= 1024 && span31 && nbatch == 1)
+      cfg = 31;  // half a wave of 128x128 tiles over a long K in a backbone GEMM (tail rows present: the coarse eval pass, 2049 tokens x
+                 // 1024 columns): the ping-pong kernel beats the 64x64 tiles by 10-20 % (tools/scratch/_coarse_gemm.py: 15.9 / 36.3 us
+                 // against 17.5 / 45.8 at K = 1024 / 4096).  The decoder's 2048-token GEMMs of the train step (no tail) keep the
+                 // 64x64 tiles: 125.3 vs 124.9 images/s
+    else if (!(g_use_pp & 64) && d->N >= 1024 && d->N < 2048 && t256 >= 128 && t256 <= 160 && d->K >= 2048 && span33 && nbatch == 1)
+      cfg = 33;  // ~150 tiles of 256x256 over a long K (the nine refine windows' fc2: 9225 x 1024 x 4096): 94.9 against 104.5 us
     else if (t128 <= 160 && d->K >= 512 && (long)cdiv(d->M, 64) * cdiv(d->N, 64) <= 544)
       cfg = 10;  // few tiles, long K (LoRA T GEMM 4096x64x1024, decoder projections): 64x64 tiles with the 4-stage ring
     else if (t128 <= 160) cfg = 18;                                  // small problems: 64x128 tiles fill more CUs
