@@ -11,7 +11,10 @@ def t(f, n=50):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for (M, N, K) in [(2049, 1024, 1024), (2049, 1024, 4096), (2049, 4096, 1024), (2049, 3072, 1024), (9225, 1024, 1024), (9225, 1024, 4096)]:
+SHAPES = [(2049, 1024, 1024), (2049, 1024, 4096), (2049, 4096, 1024), (2049, 3072, 1024), (9225, 1024, 1024), (9225, 1024, 4096)]
+if len(sys.argv) > 1 and sys.argv[1] == "sam":
+    SHAPES = [(9216, 1280, 1280), (9216, 1280, 5120), (9216, 5120, 1280), (9216, 3840, 1280), (9225, 4096, 1024), (9225, 3072, 1024)]
+for (M, N, K) in SHAPES:
     A = torch.randn(M, K, device="cuda").bfloat16(); B = torch.randn(N, K, device="cuda").bfloat16()
     C = torch.empty(M, N, device="cuda"); R = torch.randn(M, N, device="cuda"); bias = torch.randn(N, device="cuda")
     out = []

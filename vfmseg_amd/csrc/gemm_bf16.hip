@@ -475,8 +475,13 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
                  // 1024 columns): the ping-pong kernel beats the 64x64 tiles by 10-20 % (tools/scratch/_coarse_gemm.py: 15.9 / 36.3 us
                  // against 17.5 / 45.8 at K = 1024 / 4096).  The decoder's 2048-token GEMMs of the train step (no tail) keep the
                  // 64x64 tiles: 125.3 vs 124.9 images/s
-    else if (!(g_use_pp & 64) && d->N >= 1024 && d->N < 2048 && t256 >= 128 && t256 <= 160 && d->K >= 2048 && span33 && nbatch == 1)
-      cfg = 33;  // ~150 tiles of 256x256 over a long K (the nine refine windows' fc2: 9225 x 1024 x 4096): 94.9 against 104.5 us
+    else if (!(g_use_pp & 64) && d->N >= 1024 && d->N < 2048 && t256 >= 128 && t256 <= 200 && span33 && nbatch == 1 &&
+             (d->K >= 2048 || (t256 >= 170 && d->K >= 1024)))
+      cfg = 33;  // 130-200 tiles of 256x256 (eval: nine 1024-token windows at once - DINOv2 fc2 [9225 x 1024 x 4096] 104.5 -> 94.9 us,
+                 // SAM-H proj / fc2 [9216 x 1280 x 1280 / 5120] 51.6 -> 46.9 / 142.5 -> 118.0 us): 576-720 tiles of 128x128 are 1.1-1.4
+                 // rounds of the 512 resident slots
+    else if (!(g_use_pp & 64) && d->N >= 4096 && t256 >= 700 && t256 < 768 && d->K >= 1024 && span33 && nbatch == 1)
+      cfg = 33;  // SAM-H fc1 over nine windows [9216 x 5120 x 1280]: 189.4 -> 160.5 us
     else if (t128 <= 160 && d->K >= 512 && (long)cdiv(d->M, 64) * cdiv(d->N, 64) <= 544)
       cfg = 10;  // few tiles, long K (LoRA T GEMM 4096x64x1024, decoder projections): 64x64 tiles with the 4-stage ring
     else if (t128 <= 160) cfg = 18;                                  // small problems: 64x128 tiles fill more CUs
