@@ -16,12 +16,16 @@
 //   one barrier per tile.  Window tokens outside the image are real keys whose k / v equal the projection bias (window_partition
 //   pads the NORMALISED input with zeros); queries outside the image are computed and dropped (window_unpartition).
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 #define SF_D 80
+#ifndef SF_EXP
+#define SF_EXP 0   // timing experiments (tools/scratch/_sam_flash_exp.sh): 1 no restaging, 2 no exp, 3 no P V, 4 no Q K, 5 prologue only
+#endif
 #define SF_LOG2E 1.4426950408889634f
 #define SF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
@@ -36,7 +40,7 @@ struct SamFlashP {
 
 template <int S>
 struct SamFlashCfg {
-  static constexpr int NW = S == 14 ? 7 : 4;          // waves per block: 224 (>= 196) or 128 queries
+  static constexpr int NW = 4;                         // waves per block: 128 queries (two query blocks per 14 x 14 window)
   static constexpr int NT = NW * 64;
   static constexpr int NWIN = S * S;                   // tokens per window
   static constexpr int QBLK = (NWIN + NW * 32 - 1) / (NW * 32);
@@ -48,8 +52,10 @@ struct SamFlashCfg {
   static constexpr int TS = 176;                       // bytes per row of the table image
   static constexpr int TILE = 64 * (KS + VS);
   static constexpr int NTILES = (NWIN + 63) / 64;
-  static constexpr int TH_BYTES = NW * 2 * JP * 32 * 4;  // per-wave T_h^T / T_w^T images [JP][32 queries] fp32
-  static constexpr int SMEM = 2 * TILE + TH_BYTES;
+  static constexpr int TIMG = 2 * JP * TS;             // the two table images, parked at the END of stage 1 during the prologue
+  static constexpr int TH_BYTES = NW * 2 * JP * 32 * 2;  // per-wave T_h^T / T_w^T images [JP][32 queries] bf16, from byte 0
+  static constexpr int SMEM = 2 * TILE + 4 * SF_D;     // both prologue images alias the K/V ring (two blocks per CU) + the bias image
+  static_assert(TH_BYTES + TIMG <= 2 * TILE, "prologue images overlap");
 };
 
 __device__ __forceinline__ int sf_acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -67,14 +73,23 @@ __device__ __forceinline__ uint32_t sf_pack2(float a, float b) {
 }
 
 template <int S>
-__global__ void __launch_bounds__(SamFlashCfg<S>::NT) k_sam_flash_fwd(SamFlashP p) {
+__global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlashP p) {
   using C = SamFlashCfg<S>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, h = lane >> 5;
-  // block -> (image, window, head, query block)
+  // block -> (image, window, head, query block).  Workgroups go round-robin to the eight XCDs by linear id and each XCD has its own
+  // L2: all H * QBLK blocks of one window (the same K / V rows; neighbouring heads share cache lines of the 160-byte segments) are
+  // given ids congruent mod 8, so that a window's keys are fetched through ONE L2.  The last (windows % 8) windows keep the plain order.
   int bid = blockIdx.x;
+  {
+    const int inner = p.H * C::QBLK, ngroups = p.nimg * p.nws * p.nws, full = ngroups & ~7;
+    if (bid < full * inner) {
+      const int xcd = bid & 7, idx = bid >> 3;
+      bid = ((idx / inner) * 8 + xcd) * inner + idx % inner;
+    }
+  }
   const int qb = bid % C::QBLK; bid /= C::QBLK;
   const int head = bid % p.H; bid /= p.H;
   const int wx = bid % p.nws; bid /= p.nws;
@@ -87,25 +102,32 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT) k_sam_flash_fwd(SamFlashP 
     inside = gy < G && gx < G;
     return ((long)img * G + gy) * G + gx;
   };
-  // one 16-byte piece (8 columns from column c8) of section sec (0 q, 1 k, 2 v) of window token t
+  // one 16-byte piece (8 columns from column c8) of section sec (0 q, 1 k, 2 v) of window token t.  A token outside the image has
+  // k / v = the projection bias, read from the block's packed image in LDS (a global load there would put a full-latency
+  // s_waitcnt vmcnt(0) into every staging step of an edge window); a query outside the image is dropped, any value will do.
+  const char* bimg = smem + 2 * C::TILE;            // [2 sections][80 columns] bf16
   auto load_piece = [&](int sec, int t, int c8) -> uint4 {
     uint4 v = make_uint4(0, 0, 0, 0);
     if (t < C::NWIN) {
       bool inside;
       const long row = tok_row(t, inside);
-      const int col = sec * Cq + head * SF_D + c8;
-      if (inside) {
-        v = *reinterpret_cast<const uint4*>(p.qkv + row * p.ld + col);
-      } else if (p.bias) {
-        const float4 a = *reinterpret_cast<const float4*>(p.bias + col), b = *reinterpret_cast<const float4*>(p.bias + col + 4);
-        v = make_uint4(sf_pack2(a.x, a.y), sf_pack2(a.z, a.w), sf_pack2(b.x, b.y), sf_pack2(b.z, b.w));
-      }
+      if (inside) v = *reinterpret_cast<const uint4*>(p.qkv + row * p.ld + sec * Cq + head * SF_D + c8);
+      else if (sec > 0) v = *reinterpret_cast<const uint4*>(bimg + (sec - 1) * (2 * SF_D) + c8 * 2);
     }
     return v;
   };
-
-  // ---- prologue 1: the table images (aliased with K/V stage 1) and this wave's query fragments
-  char* timg = smem + C::TILE;                       // [2][JP rows][176 B]
+  if (tid < 20) {
+    const int sec = 1 + tid / 10, c8 = (tid % 10) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (p.bias) {
+      const float* b = p.bias + sec * Cq + head * SF_D + c8;
+      const float4 a = *reinterpret_cast<const float4*>(b), c = *reinterpret_cast<const float4*>(b + 4);
+      v = make_uint4(sf_pack2(a.x, a.y), sf_pack2(a.z, a.w), sf_pack2(c.x, c.y), sf_pack2(c.z, c.w));
+    }
+    *reinterpret_cast<uint4*>(smem + 2 * C::TILE + (sec - 1) * (2 * SF_D) + c8 * 2) = v;
+  }
+  // ---- prologue 1: the table images (aliased with the end of K/V stage 1) and this wave's query fragments
+  char* timg = smem + 2 * C::TILE - C::TIMG;             // [2][JP rows][176 B]
   for (int pc = tid; pc < 2 * C::JP * 10; pc += C::NT) {
     const int which = pc / (C::JP * 10), rem = pc - which * (C::JP * 10), row = rem / 10, c = rem - row * 10;
     const bf16_t* src = which ? p.tbl_w : p.tbl_h;
@@ -122,7 +144,9 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT) k_sam_flash_fwd(SamFlashP 
   }
   __syncthreads();
   // ---- prologue 2: T^T[j, q] = tbl[j, :] . q  (rows j = relative index), both axes, into the wave-private images
-  float* th = reinterpret_cast<float*>(smem + 2 * C::TILE) + wave * (2 * C::JP * 32);
+  // (stored as bf16 of T / scale, the value the query operand carries; aliased with the start of the K/V ring)
+  __bf16* th = reinterpret_cast<__bf16*>(smem) + wave * (2 * C::JP * 32);
+  const float inv = 1.0f / p.scale;
 #pragma unroll
   for (int which = 0; which < 2; ++which)
 #pragma unroll
@@ -134,32 +158,31 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT) k_sam_flash_fwd(SamFlashP 
         acc = SF_MFMA(a, qa[kk], acc);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) th[(which * C::JP + jb * 32 + sf_acc_row(r, h)) * 32 + fr] = acc[r];
+      for (int r = 0; r < 16; ++r) th[(which * C::JP + jb * 32 + sf_acc_row(r, h)) * 32 + fr] = (__bf16)(acc[r] * inv);
     }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
   {  // gather Bh[q, kh] / scale, Bw[q, kw] / scale into the extension k-steps of the query operand
     const int qh = qc / S, qw = qc - qh * S;
-    const float inv = 1.0f / p.scale;
 #pragma unroll
     for (int which = 0; which < 2; ++which)
 #pragma unroll
       for (int ks = 0; ks < C::SP / 16; ++ks) {
-        float v[8];
+        bf16x8 u;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int kx = 16 * ks + 8 * h + e;        // key coordinate along this axis
           const int j = (which ? qw : qh) - kx + S - 1;
-          v[e] = kx < S ? th[(which * C::JP + j) * 32 + fr] * inv : 0.f;
+          u[e] = kx < S ? th[(which * C::JP + j) * 32 + fr] : (__bf16)0.f;
         }
-        const uint4 u = make_uint4(sf_pack2(v[0], v[1]), sf_pack2(v[2], v[3]), sf_pack2(v[4], v[5]), sf_pack2(v[6], v[7]));
-        qa[5 + which * (C::SP / 16) + ks] = *reinterpret_cast<const bf16x8*>(&u);
+        qa[5 + which * (C::SP / 16) + ks] = u;
       }
   }
-  __syncthreads();  // everyone is done with the table image: stage 1 of the K/V ring may be overwritten
+  __syncthreads();  // everyone is done with the prologue images: the K/V ring may be overwritten
 
   // ---- K/V tile staging: 64 keys x (10 K pieces + 10 V pieces + the one-hot columns), global -> registers -> LDS
-  constexpr int PK = 64 * 10, POH = 64 * (2 * C::SP / 8), PTOT = 2 * PK + POH, PPT = (PTOT + C::NT - 1) / C::NT;
+  // (the one-hot pieces come from the key index alone: commit() writes them without a staging register)
+  constexpr int PK = 64 * 10, POH = 64 * (2 * C::SP / 8), PPT = (2 * PK + C::NT - 1) / C::NT, PPO = (POH + C::NT - 1) / C::NT;
   uint4 stg[PPT];
   auto fetch = [&](int t) {
 #pragma unroll
@@ -169,23 +192,11 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT) k_sam_flash_fwd(SamFlashP 
       if (pc < 2 * PK) {
         const int sec = pc / PK, rem = pc - sec * PK, row = rem / 10, c = rem - row * 10;
         v = load_piece(1 + sec, t * 64 + row, c * 8);
-      } else if (pc < PTOT) {
-        const int rem = pc - 2 * PK, row = rem / (2 * C::SP / 8), c = rem - row * (2 * C::SP / 8);
-        const int key = t * 64 + row;
-        if (key < C::NWIN) {
-          const int kh = key / S, kw = key - kh * S;
-          const int want = (c < C::SP / 8 ? kh : kw + C::SP) - 8 * c;   // position of the 1 inside this piece, if 0..7
-          if (want >= 0 && want < 8) {   // bf16 1.0 at element `want` of the piece
-            const uint32_t val = (want & 1) ? 0x3F800000u : 0x00003F80u;
-            const int wi = want >> 1;
-            v = make_uint4(wi == 0 ? val : 0u, wi == 1 ? val : 0u, wi == 2 ? val : 0u, wi == 3 ? val : 0u);
-          }
-        }
       }
       stg[i] = v;
     }
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](int buf, int t) {
     char* kt = smem + buf * C::TILE;
     char* vt = kt + 64 * C::KS;
 #pragma unroll
@@ -197,9 +208,25 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT) k_sam_flash_fwd(SamFlashP 
       } else if (pc < 2 * PK) {
         const int rem = pc - PK, row = rem / 10, c = rem - row * 10;
         *reinterpret_cast<uint4*>(vt + row * C::VS + c * 16) = stg[i];
-      } else if (pc < PTOT) {
-        const int rem = pc - 2 * PK, row = rem / (2 * C::SP / 8), c = rem - row * (2 * C::SP / 8);
-        *reinterpret_cast<uint4*>(kt + row * C::KS + 160 + c * 16) = stg[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PPO; ++i) {
+      const int rem = tid + i * C::NT;
+      if (rem < POH) {
+        const int row = rem / (2 * C::SP / 8), c = rem - row * (2 * C::SP / 8);
+        const int key = t * 64 + row;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (key < C::NWIN) {
+          const int kh = key / S, kw = key - kh * S;
+          const int want = (c < C::SP / 8 ? kh : kw + C::SP) - 8 * c;   // position of the 1 inside this piece, if 0..7
+          if (want >= 0 && want < 8) {   // bf16 1.0 at element `want` of the piece
+            const uint32_t val = (want & 1) ? 0x3F800000u : 0x00003F80u;
+            const int wi = want >> 1;
+            v = make_uint4(wi == 0 ? val : 0u, wi == 1 ? val : 0u, wi == 2 ? val : 0u, wi == 3 ? val : 0u);
+          }
+        }
+        *reinterpret_cast<uint4*>(kt + row * C::KS + 160 + c * 16) = v;
       }
     }
   };
@@ -209,37 +236,38 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT) k_sam_flash_fwd(SamFlashP 
     *reinterpret_cast<uint4*>(smem + buf * C::TILE + 64 * C::KS + row * C::VS + 160 + c * 16) = make_uint4(0, 0, 0, 0);
   }
   fetch(0);
-  commit(0);
+  commit(0, 0);
   __syncthreads();
 
   const float c = p.scale * SF_LOG2E;
   f32x16 oacc[3] = {sf_zero(), sf_zero(), sf_zero()};
   float m = -INFINITY, l = 0.f;
-#pragma unroll 1
-  for (int t = 0; t < C::NTILES; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < C::NTILES) fetch(t + 1);            // global loads of the next tile fly during this tile's products
-    const char* kt = smem + buf * C::TILE;
-    const char* vt = kt + 64 * C::KS;
-    f32x16 sacc[2] = {sf_zero(), sf_zero()};
+  const bool active = (C::NWIN % (C::NW * 32) == 0) || q0 < C::NWIN;   // wave-uniform
+  // One tile of 64 keys for this wave: NKB 32-key blocks enter the score product, the last of them feeds NSL 16-key steps of P V.
+  // (A 14 x 14 window has 196 = 3 * 64 + 4 keys: its last tile is one block and one step.)
+  auto tile = [&](auto nkb_c, auto nsl_c, int t, const char* kt, const char* vt) __attribute__((always_inline)) {
+    constexpr int NKB = decltype(nkb_c)::value, NSL = decltype(nsl_c)::value;
+    f32x16 sacc[NKB];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < NKB; ++kb) {
+      sacc[kb] = sf_zero();
 #pragma unroll
-      for (int kk = 0; kk < C::KSTEPS; ++kk) {
+      for (int kk = 0; kk < (SF_EXP == 4 ? 1 : C::KSTEPS); ++kk) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(kt + (kb * 32 + fr) * C::KS + (2 * kk + h) * 16);
         sacc[kb] = SF_MFMA(a, qa[kk], sacc[kb]);
       }
+    }
     if ((C::NWIN % 64 != 0) && t == C::NTILES - 1) {  // ragged last tile: keys beyond the window do not exist
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (t * 64 + kb * 32 + sf_acc_row(r, h) >= C::NWIN) sacc[kb][r] = -INFINITY;
     }
-    // ---- online softmax over this lane's 32 keys of the tile (the other 32 live in lane ^ 32)
+    // ---- online softmax over this lane's keys of the tile (the others live in lane ^ 32)
     float m4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) m4[r & 3] = fmaxf(m4[r & 3], sacc[kb][r]);
     float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
@@ -250,10 +278,10 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT) k_sam_flash_fwd(SamFlashP 
     const float mnc = mn * c;
     float rs4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -mnc));
+        const float pv = SF_EXP == 2 ? fmaf(sacc[kb][r], c, -mnc) : __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -mnc));
         sacc[kb][r] = pv;
         rs4[r & 3] += pv;
       }
@@ -267,9 +295,9 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT) k_sam_flash_fwd(SamFlashP 
     }
     // ---- O^T[col, query] += V^T[col x key] P^T[key x query]
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < (SF_EXP == 3 ? 0 : NKB); ++kb)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < (kb == NKB - 1 ? NSL : 2); ++s) {
         bf16x8 pb;
 #pragma unroll
         for (int e = 0; e < 8; ++e) pb[e] = (__bf16)sacc[kb][8 * s + e];
@@ -288,7 +316,22 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT) k_sam_flash_fwd(SamFlashP 
           oacc[j] = SF_MFMA(u.v, pb, oacc[j]);
         }
       }
-    if (t + 1 < C::NTILES) commit(buf ^ 1);         // stage buf^1 was last read during tile t-1: every wave passed that barrier
+  };
+  constexpr int LASTK = C::NWIN - 64 * (C::NTILES - 1);     // keys of the last tile
+  constexpr int NKB_LAST = (LASTK + 31) / 32, NSL_LAST = ((LASTK - 1) % 32 + 16) / 16;
+#pragma unroll 1
+  for (int t = 0; t < C::NTILES; ++t) {
+    const int buf = t & 1;
+    if (SF_EXP != 1 && t + 1 < C::NTILES) fetch(t + 1);            // global loads of the next tile fly during this tile's products
+    const char* kt = smem + buf * C::TILE;
+    const char* vt = kt + 64 * C::KS;
+    if (SF_EXP != 5 && active) {                                   // a wave past the window's last query only helps with the tile staging
+      if ((NKB_LAST < 2 || NSL_LAST < 2) && t == C::NTILES - 1)
+        tile(std::integral_constant<int, NKB_LAST>{}, std::integral_constant<int, NSL_LAST>{}, t, kt, vt);
+      else
+        tile(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, t, kt, vt);
+    }
+    if (SF_EXP != 1 && t + 1 < C::NTILES) commit(buf ^ 1, t + 1);        // stage buf^1 was last read during tile t-1: every wave passed that barrier
     __syncthreads();
   }
   // ---- epilogue: lane = query, registers = output columns sf_acc_row(r, h) + 32 j (columns >= 80 are padding)
