@@ -236,6 +236,18 @@ int vfm_sam_attn_bwd_merge(const void* dqa, const void* dkT, const void* dvT, in
  * tbl[j] = rel_pos(re-interpolated)[j] = Rh[qh, kh] for qh - kh + S - 1 = j, rows >= 2S-1 zero.  No score matrix in memory. */
 int vfm_sam_attn_flash_fwd(const void* qkv, long ld, const float* bias, const void* tbl_h, const void* tbl_w, void* out, long ldo,
                            int nimg, int G, int S, int H, int d, float scale, void* stream);
+/* Training form of the same launch: also writes, per (image, window, head) and window token (row pitch NWINP = 256 for S = 14,
+ * 1024 for S = 32; vfm_sam_attn_flash_stat_rows gives the row count), lse = log2-sum-exp of the scaled scores (fp32) and
+ * qext = the bias columns [Bh / scale | Bw / scale] of the query operand (bf16 [rows, 2*SP]). */
+int vfm_sam_attn_flash_fwd_train(const void* qkv, long ld, const float* bias, const void* tbl_h, const void* tbl_w, void* out, long ldo,
+                                 int nimg, int G, int S, int H, int d, float scale, float* lse, void* qext, void* stream);
+long vfm_sam_attn_flash_stat_rows(int nimg, int G, int S, int H);
+/* Backward of the above with frozen tables (autograd of sam_vit.py:273-298, 392-430): out / dout [nimg*G*G, H*d] bf16 (same
+ * pitch ldo), lse / qext from the training forward, dsum = fp32 scratch [rows] -> dqkv [nimg*G*G, 3*H*d] bf16, every element
+ * written (gradients of padded window tokens are dropped, as window_unpartition / F.pad do).  Two launches, no score matrix. */
+int vfm_sam_attn_flash_bwd(const void* qkv, long ld, const float* bias, const void* tbl_h, const void* tbl_w, const void* out,
+                           const void* dout, long ldo, const float* lse, const void* qext, float* dsum, void* dqkv, long ldg,
+                           int nimg, int G, int S, int H, int d, float scale, void* stream);
 
 /* ---- ViT input / output ------------------------------------------------------------------------ */
 /* im2col of non-overlapping PxP patches (patch_embed.py:65-77): img fp32 NCHW [B,3,H,W] (crop window y0,x0,

@@ -19,7 +19,7 @@ from vfmseg_amd import ops  # noqa: E402
 def _ref(qkv, bias, rel_h, rel_w, nimg, G, S, H, d):
     """fp64: [nimg*G*G, 3*H*d] -> [nimg*G*G, H*d]"""
     C = H * d
-    x = qkv.double().view(nimg, G, G, 3 * C)
+    x = (qkv if qkv.dtype == torch.float64 else qkv.double()).view(nimg, G, G, 3 * C)
     if S < G:
         pad = (S - G % S) % S
         Gp = G + pad
@@ -66,6 +66,40 @@ def test_sam_flash_forward_matches_reference_math(S, G, nimg, L):
     e = rel_err(out.float().cpu(), ref)
     print(f"[sam flash S={S}] rel err {e:.2e}")
     assert e < 2e-2, e     # bf16 P and bf16 bias columns; the materialised path has the same operand precision
+
+
+@pytest.mark.parametrize("S,G,nimg,L", [(14, 32, 2, 27), (32, 32, 2, 127), (14, 32, 9, 27)])
+def test_sam_flash_backward_matches_autograd(S, G, nimg, L):
+    """vfm_sam_attn_flash_fwd_train + vfm_sam_attn_flash_bwd (csrc/sam_flash_bwd.hip) against float64 autograd of the same
+    restatement: d(qkv) for random d(out), including the path through the decomposed rel-pos bias (frozen tables) and the windows
+    with padded tokens (their k / v gradients are dropped, their queries have no output)."""
+    H, d = 16, 80
+    g = torch.Generator().manual_seed(100 + S + nimg)
+    qkv = (torch.randn(nimg * G * G, 3 * H * d, generator=g) * 1.5).bfloat16()
+    bias = torch.randn(3 * H * d, generator=g) * 0.5
+    rel_h, rel_w = torch.randn(L, d, generator=g) * 0.3, torch.randn(L, d, generator=g) * 0.3
+    dout = (torch.randn(nimg * G * G, H * d, generator=g)).bfloat16()
+    JP = 32 if S == 14 else 64
+    th, tw = _tables(rel_h, S, JP), _tables(rel_w, S, JP)
+    out = torch.full((nimg * G * G, H * d), float("nan"), dtype=torch.bfloat16, device="cuda")
+    lse, qext = ops.sam_attn_flash_stats(nimg, G, S, H, "cuda")
+    ops.sam_attn_flash_fwd_train(qkv.cuda(), bias.cuda(), th, tw, out, lse, qext, nimg, G, S, H, d, d ** -0.5)
+    out2 = torch.empty_like(out)
+    ops.sam_attn_flash_fwd(qkv.cuda(), bias.cuda(), th, tw, out2, nimg, G, S, H, d, d ** -0.5)
+    assert torch.equal(out, out2)                       # the training launch computes the same output
+    dqkv = torch.full((nimg * G * G, 3 * H * d), float("nan"), dtype=torch.bfloat16, device="cuda")
+    for rep in range(2):
+        ops.sam_attn_flash_bwd(qkv.cuda(), bias.cuda(), th, tw, out, dout.cuda(), lse, qext, dqkv, nimg, G, S, H, d, d ** -0.5)
+    assert torch.isfinite(dqkv.float()).all()           # every element written
+    x = qkv.double().requires_grad_(True)
+    ref = _ref(x, bias, rel_h, rel_w, nimg, G, S, H, d)
+    ref.backward(dout.double())
+    C = H * d
+    got = dqkv.float().cpu()
+    for name, sl in (("dq", slice(0, C)), ("dk", slice(C, 2 * C)), ("dv", slice(2 * C, 3 * C))):
+        e = rel_err(got[:, sl], x.grad[:, sl])
+        print(f"[sam flash bwd S={S} nimg={nimg}] {name} rel err {e:.2e}")
+        assert e < 3e-2, (name, e)
 
 
 def test_sam_engine_flash_equals_materialised_path():

@@ -15,62 +15,7 @@
 //   K / V tiles of 64 keys are staged global -> registers -> LDS (rows are 160 B: no whole-line LDS-DMA shape), double buffered,
 //   one barrier per tile.  Window tokens outside the image are real keys whose k / v equal the projection bias (window_partition
 //   pads the NORMALISED input with zeros); queries outside the image are computed and dropped (window_unpartition).
-#include "common.h"
-#include <type_traits>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-#define SF_D 80
-#ifndef SF_EXP
-#define SF_EXP 0   // timing experiments (tools/scratch/_sam_flash_exp.sh): 1 no restaging, 2 no exp, 3 no P V, 4 no Q K, 5 prologue only
-#endif
-#define SF_LOG2E 1.4426950408889634f
-#define SF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
-
-struct SamFlashP {
-  const bf16_t* qkv; long ld;        // token-major [nimg*G*G, 3*H*80]
-  const float* bias;                 // [3*H*80] projection bias (qkv of the padded window tokens), may be null
-  const bf16_t* tbl_h; const bf16_t* tbl_w;  // [JP, 80] relative-index tables (rows >= 2S-1 zero)
-  bf16_t* out; long ldo;             // token-major [nimg*G*G, H*80]
-  int nimg, G, H, nws;               // nws windows per side (1 for global)
-  float scale;
-};
-
-template <int S>
-struct SamFlashCfg {
-  static constexpr int NW = 4;                         // waves per block: 128 queries (two query blocks per 14 x 14 window)
-  static constexpr int NT = NW * 64;
-  static constexpr int NWIN = S * S;                   // tokens per window
-  static constexpr int QBLK = (NWIN + NW * 32 - 1) / (NW * 32);
-  static constexpr int SP = S <= 16 ? 16 : 32;         // one-hot columns per axis
-  static constexpr int JP = 2 * SP;                    // padded rows of the relative-index tables (>= 2S-1)
-  static constexpr int KSTEPS = (SF_D + 2 * SP) / 16;  // 7 / 9 k-steps of the extended score product
-  static constexpr int KS = S == 14 ? 240 : 304;       // bytes per row of the K tile (160 + 4 SP, padded so that 16 rows hit 16 slots)
-  static constexpr int VS = 192;                       // bytes per row of the V tile (96 columns, 80..95 zero)
-  static constexpr int TS = 176;                       // bytes per row of the table image
-  static constexpr int TILE = 64 * (KS + VS);
-  static constexpr int NTILES = (NWIN + 63) / 64;
-  static constexpr int TIMG = 2 * JP * TS;             // the two table images, parked at the END of stage 1 during the prologue
-  static constexpr int TH_BYTES = NW * 2 * JP * 32 * 2;  // per-wave T_h^T / T_w^T images [JP][32 queries] bf16, from byte 0
-  static constexpr int SMEM = 2 * TILE + 4 * SF_D;     // both prologue images alias the K/V ring (two blocks per CU) + the bias image
-  static_assert(TH_BYTES + TIMG <= 2 * TILE, "prologue images overlap");
-};
-
-__device__ __forceinline__ int sf_acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-__device__ __forceinline__ f32x16 sf_zero() {
-  f32x16 z;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) z[i] = 0.f;
-  return z;
-}
-__device__ __forceinline__ uint32_t sf_pack2(float a, float b) {
-  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  const b2 v = __builtin_convertvector(f2{a, b}, b2);
-  return *reinterpret_cast<const uint32_t*>(&v);
-}
+#include "sam_flash_dev.h"
 
 template <int S>
 __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlashP p) {
@@ -177,6 +122,12 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
         }
         qa[5 + which * (C::SP / 16) + ks] = u;
       }
+  }
+  const long stat_row = ((((long)img * p.nws + wy) * p.nws + wx) * p.H + head) * C::NWINP + qi;
+  if (p.qext && qi < C::NWIN) {   // training: the backward reuses the bias columns instead of repeating the table products
+#pragma unroll
+    for (int e = 0; e < 2 * C::SP / 16; ++e)
+      *reinterpret_cast<bf16x8*>(p.qext + stat_row * (2 * C::SP) + 16 * e + 8 * h) = qa[5 + e];
   }
   __syncthreads();  // everyone is done with the prologue images: the K/V ring may be overwritten
 
@@ -337,6 +288,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
   // ---- epilogue: lane = query, registers = output columns sf_acc_row(r, h) + 32 j (columns >= 80 are padding)
   l += __shfl_xor(l, 32, 64);
   const float mult = 1.f / l;
+  if (p.lse && qi < C::NWIN && h == 0) p.lse[stat_row] = m * c + __builtin_amdgcn_logf(l);   // log2 domain: P = exp2(c s - lse)
   bool inside = false;
   const long row = tok_row(qc, inside);
   if (qi < C::NWIN && inside) {
@@ -366,8 +318,8 @@ static int launch_sam_flash(const SamFlashP& p, hipStream_t s) {
   return 0;
 }
 
-extern "C" int vfm_sam_attn_flash_fwd(const void* qkv, long ld, const float* bias, const void* tbl_h, const void* tbl_w, void* out,
-                                      long ldo, int nimg, int G, int S, int H, int d, float scale, void* stream) {
+static int sam_flash_fwd_impl(const void* qkv, long ld, const float* bias, const void* tbl_h, const void* tbl_w, void* out, long ldo, int nimg,
+                              int G, int S, int H, int d, float scale, float* lse, void* qext, void* stream) {
   VFM_CHECK(qkv && tbl_h && tbl_w && out, VFM_E_INVAL, "vfm_sam_attn_flash_fwd: null pointer");
   VFM_CHECK(d == SF_D, VFM_E_UNSUPPORTED, "vfm_sam_attn_flash_fwd: head dim %d (only 80 = SAM ViT-H)", d);
   VFM_CHECK((S == 14 && G > 0) || (S == 32 && G == 32), VFM_E_UNSUPPORTED,
@@ -379,8 +331,20 @@ extern "C" int vfm_sam_attn_flash_fwd(const void* qkv, long ld, const float* bia
   SamFlashP p;
   p.qkv = (const bf16_t*)qkv, p.ld = ld, p.bias = bias, p.tbl_h = (const bf16_t*)tbl_h, p.tbl_w = (const bf16_t*)tbl_w;
   p.out = (bf16_t*)out, p.ldo = ldo, p.nimg = nimg, p.G = G, p.H = H, p.nws = S == 32 ? 1 : (G + S - 1) / S, p.scale = scale;
+  p.lse = lse, p.qext = (bf16_t*)qext;
   if (S == 14) launch_sam_flash<14>(p, (hipStream_t)stream);
   else launch_sam_flash<32>(p, (hipStream_t)stream);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
+}
+
+extern "C" int vfm_sam_attn_flash_fwd(const void* qkv, long ld, const float* bias, const void* tbl_h, const void* tbl_w, void* out,
+                                      long ldo, int nimg, int G, int S, int H, int d, float scale, void* stream) {
+  return sam_flash_fwd_impl(qkv, ld, bias, tbl_h, tbl_w, out, ldo, nimg, G, S, H, d, scale, nullptr, nullptr, stream);
+}
+
+extern "C" int vfm_sam_attn_flash_fwd_train(const void* qkv, long ld, const float* bias, const void* tbl_h, const void* tbl_w, void* out,
+                                            long ldo, int nimg, int G, int S, int H, int d, float scale, float* lse, void* qext, void* stream) {
+  VFM_CHECK(lse && qext && ((uintptr_t)qext & 15) == 0, VFM_E_INVAL, "vfm_sam_attn_flash_fwd_train: lse / qext");
+  return sam_flash_fwd_impl(qkv, ld, bias, tbl_h, tbl_w, out, ldo, nimg, G, S, H, d, scale, lse, qext, stream);
 }

@@ -1,0 +1,564 @@
+// Flash-style SAM attention backward for gfx950 (head dim 80, windowed 14 x 14 and global 32 x 32, decomposed relative-position
+// bias with FROZEN tables): d(attention output) -> d(qkv), straight from / to the token-major matrices, no score matrix in memory.
+// Reference: the autograd of rein/models/backbones/sam_vit.py:273-298 (Attention.forward), :301-356 (window partition /
+// unpartition: padded window tokens are keys whose gradient is dropped, padded queries have no output), :392-430
+// (add_decomposed_rel_pos).  Replaces, for bf16 training, the materialised form of sam.hip (prep -> dP GEMM -> softmax backward ->
+// three batched GEMMs -> prep again -> dQaug GEMM -> merge).
+//
+//   s[q, k] = scale q.k + Bh[q, kh] + Bw[q, kw],  Bh[q, kh] = q . tbl_h[qh - kh + S - 1];  p = softmax_k(s);  o = p v
+//   dv = p^T do;  dp = do v^T;  ds = p * (dp - D), D[q] = do[q] . o[q];
+//   dk = scale ds^T q;  dq = scale ds k + sum_kh dBh[q, kh] tbl_h[qh - kh + S - 1] + (same for w),  dBh[q, kh] = sum_{k in row kh} ds[q, k]
+//
+// The training forward (sam_flash.hip, vfm_sam_attn_flash_fwd_train) leaves lse[q] (log2 domain) and the query operand's bias columns
+// qext[q] = [Bh[q, :] / scale | Bw[q, :] / scale] (bf16, the values its score product used).  Two kernels, both shaped like the forward:
+// * k_sam_flash_dq: a wave owns 32 queries on the MFMA lane index and walks the key tiles [k | onehot(kh) | onehot(kw)] + v:
+//   s^T and dp^T by row fragments, dQext^T += Kext^T ds^T by transposing LDS reads.  Rows 80.. of dQext^T ARE dBh^T / dBw^T (the
+//   one-hot columns sum ds over a key row / column); they go through a wave-private LDS image into one more small MFMA product
+//   with the table images.  Also writes D[q] for the second kernel.
+// * k_sam_flash_dkv: a wave owns 32 keys on the lane index (operand [k | onehot] and v in registers) and walks the query tiles
+//   [q | qext] + do (+ lse, D): s and dp by row fragments (rows = queries), dV^T += dO^T p, dK^T += Q^T ds by transposing reads.
+#include "sam_flash_dev.h"
+
+struct SamFlashBwdP {
+  const bf16_t* qkv; long ld;
+  const float* bias;
+  const bf16_t* tbl_h; const bf16_t* tbl_w;
+  const bf16_t* out; const bf16_t* dout; long ldo;   // token-major [nimg*G*G, H*80]
+  const float* lse; const bf16_t* qext;              // from the training forward
+  float* dsum;                                        // [nwh, NWINP] scratch: D[q]
+  bf16_t* dqkv; long ldg;                             // token-major [nimg*G*G, 3*H*80]
+  int nimg, G, H, nws;
+  float scale;
+};
+
+template <int S>
+struct SfBlock {   // block -> (image, window, head, sub-block) with the forward's XCD-aware order, and the window geometry
+  using C = SamFlashCfg<S>;
+  int sub, head, wx, wy, img, G, H;
+  __device__ SfBlock(int bid, int nimg, int nws, int H_, int G_) : G(G_), H(H_) {
+    const int inner = H_ * C::QBLK, ngroups = nimg * nws * nws, full = ngroups & ~7;
+    if (bid < full * inner) {
+      const int xcd = bid & 7, idx = bid >> 3;
+      bid = ((idx / inner) * 8 + xcd) * inner + idx % inner;
+    }
+    sub = bid % C::QBLK; bid /= C::QBLK;
+    head = bid % H_; bid /= H_;
+    wx = bid % nws; bid /= nws;
+    wy = bid % nws;
+    img = bid / nws;
+  }
+  __device__ long wh(int nws) const { return (((long)img * nws + wy) * nws + wx) * H + head; }
+  __device__ long tok_row(int t, bool& inside) const {
+    const int ty = t / S, tx = t - ty * S;
+    const int gy = wy * S + ty, gx = wx * S + tx;
+    inside = gy < G && gx < G;
+    return ((long)img * G + gy) * G + gx;
+  }
+};
+
+__device__ __forceinline__ float sf_dot8(uint4 a, uint4 b) {
+  const uint32_t* x = reinterpret_cast<const uint32_t*>(&a);
+  const uint32_t* y = reinterpret_cast<const uint32_t*>(&b);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    s += __uint_as_float(x[i] << 16) * __uint_as_float(y[i] << 16);
+    s += __uint_as_float(x[i] & 0xFFFF0000u) * __uint_as_float(y[i] & 0xFFFF0000u);
+  }
+  return s;
+}
+
+// A operand (rows = stored columns 32 j .., k = stored rows of 16-row step `r16`) by transposing LDS reads, as the forward's P V product
+__device__ __forceinline__ bf16x8 sf_tr_frag(const char* base, int stride, int r16, int j, int lane) {
+  const int g = lane >> 4, i = lane & 15, q4 = i >> 2, pp = i & 3, hh = g >> 1;
+  const int chunk = 4 * j + 2 * (g & 1) + (pp >> 1);
+  const int r0 = r16 + 4 * hh + q4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(base + r0 * stride + chunk * 16 + ((pp & 1) << 3)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(base + (r0 + 8) * stride + chunk * 16 + ((pp & 1) << 3)));
+  union { struct { s16x4 a, b; } st; bf16x8 v; } u;
+  u.st.a = lo;
+  u.st.b = hi;
+  return u.v;
+}
+
+// ============================================================ dq (+ D)
+template <int S>
+__global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlashBwdP p) {
+  using C = SamFlashCfg<S>;
+  constexpr int NJ = (SF_D + 2 * C::SP + 31) / 32;   // 32-row blocks of dQext^T: 4 (112 rows) / 5 (144 rows)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, h = lane >> 5;
+  const SfBlock<S> B(blockIdx.x, p.nimg, p.nws, p.H, p.G);
+  const int head = B.head, Cq = p.H * SF_D;
+  const long wh = B.wh(p.nws);
+
+  // bias image of the padded keys (k, v), as the forward
+  char* bimg = smem + 2 * C::TILE;
+  if (tid < 20) {
+    const int sec = 1 + tid / 10, c8 = (tid % 10) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (p.bias) {
+      const float* b = p.bias + sec * Cq + head * SF_D + c8;
+      const float4 a = *reinterpret_cast<const float4*>(b), c = *reinterpret_cast<const float4*>(b + 4);
+      v = make_uint4(sf_pack2(a.x, a.y), sf_pack2(a.z, a.w), sf_pack2(c.x, c.y), sf_pack2(c.z, c.w));
+    }
+    *reinterpret_cast<uint4*>(bimg + (sec - 1) * (2 * SF_D) + c8 * 2) = v;
+  }
+  auto load_piece = [&](int sec, int t, int c8) __attribute__((always_inline)) -> uint4 {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (t < C::NWIN) {
+      bool inside;
+      const long row = B.tok_row(t, inside);
+      if (inside) v = *reinterpret_cast<const uint4*>(p.qkv + row * p.ld + sec * Cq + head * SF_D + c8);
+      else if (sec > 0) v = *reinterpret_cast<const uint4*>(bimg + (sec - 1) * (2 * SF_D) + c8 * 2);
+    }
+    return v;
+  };
+
+  // ---- this lane's query: operand [q | qext], dO fragments, D = dO . O, lse
+  const int q0 = B.sub * (C::NW * 32) + wave * 32;
+  const int qi = q0 + fr;
+  const int qc = qi < C::NWIN ? qi : C::NWIN - 1;
+  const long stat = wh * C::NWINP + qc;
+  bool q_inside;
+  const long q_row = B.tok_row(qc, q_inside);
+  bf16x8 qa[C::KSTEPS], da[5];
+  float dsum = 0.f;
+#pragma unroll
+  for (int kk = 0; kk < 5; ++kk) {
+    uint4 vq = make_uint4(0, 0, 0, 0), vd = vq, vo = vq;
+    if (q_inside) {
+      vq = *reinterpret_cast<const uint4*>(p.qkv + q_row * p.ld + head * SF_D + 16 * kk + 8 * h);
+      vd = *reinterpret_cast<const uint4*>(p.dout + q_row * p.ldo + head * SF_D + 16 * kk + 8 * h);
+      vo = *reinterpret_cast<const uint4*>(p.out + q_row * p.ldo + head * SF_D + 16 * kk + 8 * h);
+    }
+    qa[kk] = *reinterpret_cast<const bf16x8*>(&vq);
+    da[kk] = *reinterpret_cast<const bf16x8*>(&vd);
+    dsum += sf_dot8(vd, vo);
+  }
+#pragma unroll
+  for (int e = 0; e < 2 * C::SP / 16; ++e) qa[5 + e] = *reinterpret_cast<const bf16x8*>(p.qext + stat * (2 * C::SP) + 16 * e + 8 * h);
+  dsum += __shfl_xor(dsum, 32, 64);
+  if (qi < C::NWIN && h == 0) p.dsum[stat] = dsum;
+  const float L = p.lse[stat];
+  __syncthreads();   // bias image
+
+  // ---- K/V tile staging, as the forward
+  constexpr int PK = 64 * 10, POH = 64 * (2 * C::SP / 8), PPT = (2 * PK + C::NT - 1) / C::NT, PPO = (POH + C::NT - 1) / C::NT;
+  uint4 stg[PPT];
+  auto fetch = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int pc = tid + i * C::NT;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (pc < 2 * PK) {
+        const int sec = pc / PK, rem = pc - sec * PK, row = rem / 10, c = rem - row * 10;
+        v = load_piece(1 + sec, t * 64 + row, c * 8);
+      }
+      stg[i] = v;
+    }
+  };
+  auto commit = [&](int buf, int t) __attribute__((always_inline)) {
+    char* kt = smem + buf * C::TILE;
+    char* vt = kt + 64 * C::KS;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int pc = tid + i * C::NT;
+      if (pc < PK) {
+        const int row = pc / 10, c = pc - row * 10;
+        *reinterpret_cast<uint4*>(kt + row * C::KS + c * 16) = stg[i];
+      } else if (pc < 2 * PK) {
+        const int rem = pc - PK, row = rem / 10, c = rem - row * 10;
+        *reinterpret_cast<uint4*>(vt + row * C::VS + c * 16) = stg[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PPO; ++i) {
+      const int rem = tid + i * C::NT;
+      if (rem < POH) {
+        const int row = rem / (2 * C::SP / 8), c = rem - row * (2 * C::SP / 8);
+        const int key = t * 64 + row;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (key < C::NWIN) {
+          const int kh = key / S, kw = key - kh * S;
+          const int want = (c < C::SP / 8 ? kh : kw + C::SP) - 8 * c;
+          if (want >= 0 && want < 8) {
+            const uint32_t val = (want & 1) ? 0x3F800000u : 0x00003F80u;
+            const int wi = want >> 1;
+            v = make_uint4(wi == 0 ? val : 0u, wi == 1 ? val : 0u, wi == 2 ? val : 0u, wi == 3 ? val : 0u);
+          }
+        }
+        *reinterpret_cast<uint4*>(kt + row * C::KS + 160 + c * 16) = v;
+      }
+    }
+  };
+  // the pad bytes of the K rows (beyond 160 + 4 SP) are read by the transposing loads of the last row block: keep them finite
+  for (int i = tid; i < 2 * 64; i += C::NT) {
+    char* row = smem + (i >> 6) * C::TILE + (i & 63) * C::KS;
+    for (int b = 160 + 4 * C::SP; b < C::KS; b += 16) *reinterpret_cast<uint4*>(row + b) = make_uint4(0, 0, 0, 0);
+  }
+  fetch(0);
+  commit(0, 0);
+  __syncthreads();
+
+  const float c = p.scale * SF_LOG2E;
+  f32x16 dq[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) dq[j] = sf_zero();
+  const bool active = (C::NWIN % (C::NW * 32) == 0) || q0 < C::NWIN;
+  constexpr int LASTK = C::NWIN - 64 * (C::NTILES - 1);
+  constexpr int NKB_LAST = (LASTK + 31) / 32;
+#pragma unroll 1
+  for (int t = 0; t < C::NTILES; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < C::NTILES) {   // (staged before the products, not around them: the staging registers are dead during the tile)
+      fetch(t + 1);
+      commit(buf ^ 1, t + 1);   // stage buf^1 was last read during tile t-1: every wave passed that barrier
+    }
+    const char* kt = smem + buf * C::TILE;
+    const char* vt = kt + 64 * C::KS;
+    if (active) {
+      const int nkb = t == C::NTILES - 1 ? NKB_LAST : 2;
+#pragma unroll 1
+      for (int kb = 0; kb < nkb; ++kb) {
+        f32x16 sacc = sf_zero(), dp = sf_zero();
+#pragma unroll
+        for (int kk = 0; kk < C::KSTEPS; ++kk) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(kt + (kb * 32 + fr) * C::KS + (2 * kk + h) * 16);
+          sacc = SF_MFMA(a, qa[kk], sacc);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(vt + (kb * 32 + fr) * C::VS + (2 * kk + h) * 16);
+          dp = SF_MFMA(a, da[kk], dp);
+        }
+        const int key0 = t * 64 + kb * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float pv = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -L));
+          if ((C::NWIN % 64 != 0) && key0 + sf_acc_row(r, h) >= C::NWIN) pv = 0.f;   // keys beyond the window do not exist
+          sacc[r] = pv * (dp[r] - dsum);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 pb;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pb[e] = (__bf16)sacc[8 * s + e];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) dq[j] = SF_MFMA(sf_tr_frag(kt, C::KS, kb * 32 + 16 * s, j, lane), pb, dq[j]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: rows 80.. of dQext^T = dBh^T / dBw^T -> wave-private image [2][SP][32 queries] fp32; table images -> LDS
+  float* db = reinterpret_cast<float*>(smem) + wave * (2 * C::SP * 32);
+  char* timg = smem + 2 * C::TILE - C::TIMG;
+  static_assert(C::NW * 2 * C::SP * 32 * 4 + C::TIMG <= 2 * C::TILE, "epilogue images overlap");
+#pragma unroll
+  for (int j = 2; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int e0 = 32 * j + (r & 3) + 8 * (r >> 2) - SF_D;   // + 4 h: the bias column of this register
+      if (e0 >= 0 && e0 < 2 * C::SP) db[(e0 + 4 * h) * 32 + fr] = dq[j][r];
+    }
+  for (int pc = tid; pc < 2 * C::JP * 10; pc += C::NT) {
+    const int which = pc / (C::JP * 10), rem = pc - which * (C::JP * 10), row = rem / 10, cc = rem - row * 10;
+    const bf16_t* src = which ? p.tbl_w : p.tbl_h;
+    *reinterpret_cast<uint4*>(timg + (which * C::JP + row) * C::TS + cc * 16) = *reinterpret_cast<const uint4*>(src + row * SF_D + cc * 8);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[j][r] *= p.scale;
+  {
+    const int qh = qc / S, qw = qc - qh * S;
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+#pragma unroll
+      for (int js = 0; js < C::JP / 16; ++js) {
+        bf16x8 pb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int jj = 16 * js + 4 * h + (e & 3) + 8 * (e >> 2);       // the k index the transposing read pairs with element e
+          const int kx = (which ? qw : qh) - jj + S - 1;                 // key coordinate whose bias used table row jj
+          pb[e] = (kx >= 0 && kx < S) ? (__bf16)db[(which * C::SP + kx) * 32 + fr] : (__bf16)0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) dq[j] = SF_MFMA(sf_tr_frag(timg + which * C::JP * C::TS, C::TS, 16 * js, j, lane), pb, dq[j]);
+      }
+  }
+  if (qi < C::NWIN && q_inside) {
+    bf16_t* o = p.dqkv + q_row * p.ldg + head * SF_D;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int col = 32 * j + 8 * rq + 4 * h;
+        if (col < SF_D)
+          *reinterpret_cast<uint2*>(o + col) = make_uint2(sf_pack2(dq[j][4 * rq], dq[j][4 * rq + 1]), sf_pack2(dq[j][4 * rq + 2], dq[j][4 * rq + 3]));
+      }
+  }
+}
+
+// ============================================================ dk, dv
+template <int S>
+struct SamFlashDkvCfg {
+  using C = SamFlashCfg<S>;
+  static constexpr int TILE = 64 * (C::KS + C::VS) + 512;   // [q | qext] rows, dO rows, lse[64], D[64]
+  static constexpr int SMEM = 2 * TILE;
+};
+
+template <int S>
+__global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlashBwdP p) {
+  using C = SamFlashCfg<S>;
+  using CB = SamFlashDkvCfg<S>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 31, h = lane >> 5;
+  const SfBlock<S> B(blockIdx.x, p.nimg, p.nws, p.H, p.G);
+  const int head = B.head, Cq = p.H * SF_D;
+  const long wh = B.wh(p.nws);
+
+  // ---- this lane's key: operands [k | onehot(kh) | onehot(kw)] and v
+  const int k0 = B.sub * (C::NW * 32) + wave * 32;
+  const int ki = k0 + fr;
+  const int kc = ki < C::NWIN ? ki : C::NWIN - 1;
+  bool k_inside;
+  const long k_row = B.tok_row(kc, k_inside);
+  bf16x8 kq[C::KSTEPS], vb[5];
+#pragma unroll
+  for (int kk = 0; kk < 5; ++kk) {
+    uint4 vk = make_uint4(0, 0, 0, 0), vv = vk;
+    const int c8 = 16 * kk + 8 * h;
+    if (k_inside) {
+      vk = *reinterpret_cast<const uint4*>(p.qkv + k_row * p.ld + Cq + head * SF_D + c8);
+      vv = *reinterpret_cast<const uint4*>(p.qkv + k_row * p.ld + 2 * Cq + head * SF_D + c8);
+    } else if (p.bias) {
+      const float* b = p.bias + Cq + head * SF_D + c8;
+      const float4 a0 = *reinterpret_cast<const float4*>(b), a1 = *reinterpret_cast<const float4*>(b + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(b + Cq), b1 = *reinterpret_cast<const float4*>(b + Cq + 4);
+      vk = make_uint4(sf_pack2(a0.x, a0.y), sf_pack2(a0.z, a0.w), sf_pack2(a1.x, a1.y), sf_pack2(a1.z, a1.w));
+      vv = make_uint4(sf_pack2(b0.x, b0.y), sf_pack2(b0.z, b0.w), sf_pack2(b1.x, b1.y), sf_pack2(b1.z, b1.w));
+    }
+    kq[kk] = *reinterpret_cast<const bf16x8*>(&vk);
+    vb[kk] = *reinterpret_cast<const bf16x8*>(&vv);
+  }
+  {
+    const int kh = kc / S, kw = kc - kh * S;
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+#pragma unroll
+      for (int ks = 0; ks < C::SP / 16; ++ks) {
+        bf16x8 u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u[e] = (16 * ks + 8 * h + e == (which ? kw : kh)) ? (__bf16)1.0f : (__bf16)0.f;
+        kq[5 + which * (C::SP / 16) + ks] = u;
+      }
+  }
+
+  // ---- query tile staging: 64 queries x (10 q pieces + the qext pieces + 10 dO pieces) + lse / D, global -> registers -> LDS
+  constexpr int PQ = 64 * 10, PE = 64 * (2 * C::SP / 8), PPT = (2 * PQ + C::NT - 1) / C::NT, PPE = (PE + C::NT - 1) / C::NT;
+  uint4 stg[PPT], stge[PPE], stgs;
+  auto fetch = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int pc = tid + i * C::NT;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (pc < 2 * PQ) {
+        const int sec = pc / PQ, rem = pc - sec * PQ, row = rem / 10, cc = rem - row * 10;
+        const int tq = t * 64 + row;
+        if (tq < C::NWIN) {
+          bool inside;
+          const long grow = B.tok_row(tq, inside);
+          if (inside)   // a padded query has no output: q does not matter and dO = 0
+            v = sec == 0 ? *reinterpret_cast<const uint4*>(p.qkv + grow * p.ld + head * SF_D + cc * 8)
+                         : *reinterpret_cast<const uint4*>(p.dout + grow * p.ldo + head * SF_D + cc * 8);
+        }
+      }
+      stg[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < PPE; ++i) {
+      const int rem = tid + i * C::NT;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (rem < PE) {
+        const int row = rem / (2 * C::SP / 8), cc = rem - row * (2 * C::SP / 8);
+        const int tq = t * 64 + row;
+        if (tq < C::NWIN) v = *reinterpret_cast<const uint4*>(p.qext + (wh * C::NWINP + tq) * (2 * C::SP) + cc * 8);
+      }
+      stge[i] = v;
+    }
+    {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (tid < 32) {   // pieces 0..15: lse (rows beyond the window: +inf, so p = 0), 16..31: D (0 there)
+        const int which = tid >> 4, q4 = t * 64 + 4 * (tid & 15);
+        const float* src = (which ? p.dsum : p.lse) + wh * C::NWINP + q4;
+        const float fill = which ? 0.f : INFINITY;
+        float f[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = q4 + e < C::NWIN ? src[e] : fill;
+        v = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+      }
+      stgs = v;
+    }
+  };
+  auto commit = [&](int buf) __attribute__((always_inline)) {
+    char* qt = smem + buf * CB::TILE;
+    char* dt = qt + 64 * C::KS;
+    char* st = dt + 64 * C::VS;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int pc = tid + i * C::NT;
+      if (pc < PQ) {
+        const int row = pc / 10, cc = pc - row * 10;
+        *reinterpret_cast<uint4*>(qt + row * C::KS + cc * 16) = stg[i];
+      } else if (pc < 2 * PQ) {
+        const int rem = pc - PQ, row = rem / 10, cc = rem - row * 10;
+        *reinterpret_cast<uint4*>(dt + row * C::VS + cc * 16) = stg[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PPE; ++i) {
+      const int rem = tid + i * C::NT;
+      if (rem < PE) {
+        const int row = rem / (2 * C::SP / 8), cc = rem - row * (2 * C::SP / 8);
+        *reinterpret_cast<uint4*>(qt + row * C::KS + 160 + cc * 16) = stge[i];
+      }
+    }
+    if (tid < 32) *reinterpret_cast<uint4*>(st + tid * 16) = stgs;
+  };
+  // pad bytes that the transposing reads of column block 2 touch (q rows beyond 160 + 4 SP, dO rows beyond 160): keep them finite
+  for (int i = tid; i < 2 * 64; i += C::NT) {
+    char* qrow = smem + (i >> 6) * CB::TILE + (i & 63) * C::KS;
+    char* drow = smem + (i >> 6) * CB::TILE + 64 * C::KS + (i & 63) * C::VS;
+    for (int b = 160 + 4 * C::SP; b < C::KS; b += 16) *reinterpret_cast<uint4*>(qrow + b) = make_uint4(0, 0, 0, 0);
+    for (int b = 160; b < C::VS; b += 16) *reinterpret_cast<uint4*>(drow + b) = make_uint4(0, 0, 0, 0);
+  }
+  fetch(0);
+  commit(0);
+  __syncthreads();
+
+  const float c = p.scale * SF_LOG2E;
+  f32x16 dk[3] = {sf_zero(), sf_zero(), sf_zero()}, dv[3] = {sf_zero(), sf_zero(), sf_zero()};
+  const bool active = (C::NWIN % (C::NW * 32) == 0) || k0 < C::NWIN;
+  constexpr int LASTQ = C::NWIN - 64 * (C::NTILES - 1);
+  constexpr int NQB_LAST = (LASTQ + 31) / 32;
+#pragma unroll 1
+  for (int t = 0; t < C::NTILES; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < C::NTILES) {
+      fetch(t + 1);
+      commit(buf ^ 1);
+    }
+    const char* qt = smem + buf * CB::TILE;
+    const char* dt = qt + 64 * C::KS;
+    const char* st = dt + 64 * C::VS;
+    if (active) {
+      const int nqb = t == C::NTILES - 1 ? NQB_LAST : 2;
+#pragma unroll 1
+      for (int qb = 0; qb < nqb; ++qb) {
+        f32x16 sacc = sf_zero(), dp = sf_zero();   // rows = queries of this 32-block, lanes = keys
+#pragma unroll
+        for (int kk = 0; kk < C::KSTEPS; ++kk) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(qt + (qb * 32 + fr) * C::KS + (2 * kk + h) * 16);
+          sacc = SF_MFMA(a, kq[kk], sacc);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(dt + (qb * 32 + fr) * C::VS + (2 * kk + h) * 16);
+          dp = SF_MFMA(a, vb[kk], dp);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {   // registers 4 i .. 4 i + 3 = query rows 8 i + 4 h + 0..3 of the block
+          const float4 Lr = *reinterpret_cast<const float4*>(st + (qb * 32 + 8 * i + 4 * h) * 4);
+          const float4 Dr = *reinterpret_cast<const float4*>(st + 256 + (qb * 32 + 8 * i + 4 * h) * 4);
+          const float lr[4] = {Lr.x, Lr.y, Lr.z, Lr.w}, dr[4] = {Dr.x, Dr.y, Dr.z, Dr.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[4 * i + e], c, -lr[e]));
+            sacc[4 * i + e] = pv;
+            dp[4 * i + e] = pv * (dp[4 * i + e] - dr[e]);
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 pp_, ps_;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pp_[e] = (__bf16)sacc[8 * s + e], ps_[e] = (__bf16)dp[8 * s + e];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            dv[j] = SF_MFMA(sf_tr_frag(dt, C::VS, qb * 32 + 16 * s, j, lane), pp_, dv[j]);
+            dk[j] = SF_MFMA(sf_tr_frag(qt, C::KS, qb * 32 + 16 * s, j, lane), ps_, dk[j]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (ki < C::NWIN && k_inside) {
+    bf16_t* ok = p.dqkv + k_row * p.ldg + Cq + head * SF_D;
+    bf16_t* ov = ok + Cq;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int col = 32 * j + 8 * rq + 4 * h;
+        if (col < SF_D) {
+          *reinterpret_cast<uint2*>(ok + col) = make_uint2(sf_pack2(dk[j][4 * rq] * p.scale, dk[j][4 * rq + 1] * p.scale),
+                                                           sf_pack2(dk[j][4 * rq + 2] * p.scale, dk[j][4 * rq + 3] * p.scale));
+          *reinterpret_cast<uint2*>(ov + col) = make_uint2(sf_pack2(dv[j][4 * rq], dv[j][4 * rq + 1]), sf_pack2(dv[j][4 * rq + 2], dv[j][4 * rq + 3]));
+        }
+      }
+  }
+}
+
+template <int S>
+static void launch_sam_flash_bwd(const SamFlashBwdP& p, hipStream_t s) {
+  using C = SamFlashCfg<S>;
+  using CB = SamFlashDkvCfg<S>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k_sam_flash_dq<S>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+    (void)hipFuncSetAttribute((const void*)k_sam_flash_dkv<S>, hipFuncAttributeMaxDynamicSharedMemorySize, CB::SMEM);
+    attr = true;
+  }
+  const long blocks = (long)p.nimg * p.nws * p.nws * p.H * C::QBLK;
+  hipLaunchKernelGGL(k_sam_flash_dq<S>, dim3((unsigned)blocks), dim3(C::NT), C::SMEM, s, p);    // writes D, which dkv reads
+  hipLaunchKernelGGL(k_sam_flash_dkv<S>, dim3((unsigned)blocks), dim3(C::NT), CB::SMEM, s, p);
+}
+
+extern "C" long vfm_sam_attn_flash_stat_rows(int nimg, int G, int S, int H) {
+  const int nws = S == 32 ? 1 : (G + S - 1) / S;
+  return (long)nimg * nws * nws * H * (S == 14 ? SamFlashCfg<14>::NWINP : SamFlashCfg<32>::NWINP);
+}
+
+extern "C" int vfm_sam_attn_flash_bwd(const void* qkv, long ld, const float* bias, const void* tbl_h, const void* tbl_w, const void* out,
+                                      const void* dout, long ldo, const float* lse, const void* qext, float* dsum, void* dqkv, long ldg,
+                                      int nimg, int G, int S, int H, int d, float scale, void* stream) {
+  VFM_CHECK(qkv && tbl_h && tbl_w && out && dout && lse && qext && dsum && dqkv, VFM_E_INVAL, "vfm_sam_attn_flash_bwd: null pointer");
+  VFM_CHECK(d == SF_D, VFM_E_UNSUPPORTED, "vfm_sam_attn_flash_bwd: head dim %d (only 80 = SAM ViT-H)", d);
+  VFM_CHECK((S == 14 && G > 0) || (S == 32 && G == 32), VFM_E_UNSUPPORTED,
+            "vfm_sam_attn_flash_bwd: window %d on a %d-token grid (14 x 14 windows or 32 x 32 global)", S, G);
+  VFM_CHECK(ld % 8 == 0 && ldo % 8 == 0 && ldg % 4 == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)dout & 15) == 0 &&
+                ((uintptr_t)dqkv & 7) == 0 && ((uintptr_t)qext & 15) == 0 && ((uintptr_t)lse & 15) == 0 && ((uintptr_t)dsum & 15) == 0 &&
+                (!bias || ((uintptr_t)bias & 15) == 0) && ((uintptr_t)tbl_h & 15) == 0 && ((uintptr_t)tbl_w & 15) == 0,
+            VFM_E_ALIGN, "vfm_sam_attn_flash_bwd: alignment");
+  if (nimg <= 0) return VFM_OK;
+  SamFlashBwdP p;
+  p.qkv = (const bf16_t*)qkv, p.ld = ld, p.bias = bias, p.tbl_h = (const bf16_t*)tbl_h, p.tbl_w = (const bf16_t*)tbl_w;
+  p.out = (const bf16_t*)out, p.dout = (const bf16_t*)dout, p.ldo = ldo, p.lse = lse, p.qext = (const bf16_t*)qext, p.dsum = dsum;
+  p.dqkv = (bf16_t*)dqkv, p.ldg = ldg, p.nimg = nimg, p.G = G, p.H = H, p.nws = S == 32 ? 1 : (G + S - 1) / S, p.scale = scale;
+  if (S == 14) launch_sam_flash_bwd<14>(p, (hipStream_t)stream);
+  else launch_sam_flash_bwd<32>(p, (hipStream_t)stream);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}

@@ -92,6 +92,8 @@ SIGNATURES = {
     "vfm_softmax_rows_bwd": [vp, vp, cl, vp, ci, cl, cl, ci, ci, ci, ci, vp],
     "vfm_sam_attn_bwd_merge": [vp, vp, vp, ci, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp],
     "vfm_sam_attn_flash_fwd": [vp, cl, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, cf, vp],
+    "vfm_sam_attn_flash_fwd_train": [vp, cl, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, cf, vp, vp, vp],
+    "vfm_sam_attn_flash_bwd": [vp, cl, vp, vp, vp, vp, vp, cl, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, cf, vp],
     "vfm_patchify": [vp, cl, cl, cl, ci, ci, ci, ci, ci, vp, ci, cl, ci, vp],
     "vfm_assemble_tokens": [vp, vp, vp, vp, ci, ci, ci, vp],
     "vfm_resize_bilinear": [vp, ci, ci, ci, ci, ci, ci, cl, vp, ci, ci, cl, ci, ci, ci, ci, ci, ci, vp],

@@ -572,6 +572,34 @@ def sam_attn_flash_fwd(qkv, bias, tbl_h, tbl_w, out, nimg, G, S, H, d, scale):
     return out
 
 
+def sam_attn_flash_stats(nimg, G, S, H, dev):
+    """Buffers the training forward leaves for the backward: lse [rows] fp32, qext [rows, 2*SP] bf16 (rows = window-heads x 256 / 1024)."""
+    nws = 1 if S == 32 else (G + S - 1) // S
+    rows = nimg * nws * nws * H * (256 if S == 14 else 1024)
+    return (torch.empty(rows, dtype=torch.float32, device=dev), torch.empty(rows, 2 * (16 if S == 14 else 32), dtype=torch.bfloat16, device=dev))
+
+
+def sam_attn_flash_fwd_train(qkv, bias, tbl_h, tbl_w, out, lse, qext, nimg, G, S, H, d, scale):
+    """sam_attn_flash_fwd that also writes the per-query log2-sum-exp and the bias columns of the query operand."""
+    lib = L.load()
+    assert qkv.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and tbl_h.dtype == torch.bfloat16 and tbl_h.is_contiguous()
+    assert lse.dtype == torch.float32 and qext.dtype == torch.bfloat16 and qext.is_contiguous()
+    L.check(lib.vfm_sam_attn_flash_fwd_train(L.ptr(qkv), _ld(qkv), L.ptr(bias), L.ptr(tbl_h), L.ptr(tbl_w), L.ptr(out), _ld(out), nimg, G, S, H, d,
+                                             float(scale), L.ptr(lse), L.ptr(qext), L.stream()), "vfm_sam_attn_flash_fwd_train")
+    return out
+
+
+def sam_attn_flash_bwd(qkv, bias, tbl_h, tbl_w, out, dout, lse, qext, dqkv, nimg, G, S, H, d, scale):
+    """d(out) [M, H*d] -> dqkv [M, 3*H*d] (bf16, every element written) in two launches (csrc/sam_flash_bwd.hip)."""
+    lib = L.load()
+    assert all(t.dtype == torch.bfloat16 for t in (qkv, out, dout, dqkv, qext)) and _ld(out) == _ld(dout)
+    dsum = torch.empty_like(lse)
+    L.check(lib.vfm_sam_attn_flash_bwd(L.ptr(qkv), _ld(qkv), L.ptr(bias), L.ptr(tbl_h), L.ptr(tbl_w), L.ptr(out), L.ptr(dout), _ld(out), L.ptr(lse),
+                                       L.ptr(qext), L.ptr(dsum), L.ptr(dqkv), _ld(dqkv), nimg, G, S, H, d, float(scale), L.stream()),
+            "vfm_sam_attn_flash_bwd")
+    return dqkv
+
+
 def sam_attn_prep(qkv, bias, rh, rw, q_aug, k_aug, v_win, nimg, G, S, H, d, scale):
     lib = L.load()
     L.check(lib.vfm_sam_attn_prep(L.ptr(qkv), L.dt_of(qkv), _ld(qkv), L.ptr(bias), L.ptr(rh), L.ptr(rw), L.ptr(q_aug),

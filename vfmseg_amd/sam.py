@@ -171,12 +171,17 @@ class SamEngine:
         """-> token-major attention output [nimg*G*G, H*d] (+ the probabilities [nb, NP, NP] when keep=True: rows / columns
         beyond the S*S window tokens are zero, so P can later serve in place as a [K, N] GEMM operand)"""
         S = Lp["S"]
-        if (not keep and cd == torch.bfloat16 and d == 80 and (S == 14 or (S == 32 and G == 32))
+        if (cd == torch.bfloat16 and d == 80 and (S == 14 or (S == 32 and G == 32))
                 and os.environ.get("VFMSEG_SAM_FLASH", "1") != "0"):
-            # inference: one flash-style launch, no score matrix (csrc/sam_flash.hip)
+            # one flash-style launch, no score matrix (csrc/sam_flash.hip); training keeps lse + the bias columns for sam_flash_bwd.hip
             ao = torch.empty(nimg * G * G, H * d, dtype=cd, device=dev)
-            ops.sam_attn_flash_fwd(qkv, Lp["qkv_b"], Lp["tbl_h"], Lp["tbl_w"], ao, nimg, G, S, H, d, d ** -0.5)
-            return ao
+            if keep and os.environ.get("VFMSEG_SAM_FLASH_BWD", "1") != "0":
+                lse, qext = ops.sam_attn_flash_stats(nimg, G, S, H, dev)
+                ops.sam_attn_flash_fwd_train(qkv, Lp["qkv_b"], Lp["tbl_h"], Lp["tbl_w"], ao, lse, qext, nimg, G, S, H, d, d ** -0.5)
+                return ao, dict(ao=ao, lse=lse, qext=qext)
+            if not keep:
+                ops.sam_attn_flash_fwd(qkv, Lp["qkv_b"], Lp["tbl_h"], Lp["tbl_w"], ao, nimg, G, S, H, d, d ** -0.5)
+                return ao
         nws = (G + S - 1) // S
         nb, Nw = nimg * nws * nws * H, S * S
         Dq, NP = _pad64(d + 2 * S), _pad64(Nw)
@@ -205,6 +210,10 @@ class SamEngine:
     def attention_bwd(self, dao, qkv, pr, Lp, nimg, G, H, d, cd, dev):
         """d(attention output) [M, H*d] -> dqkv [M, 3*H*d]; pr = the probabilities kept by attention(keep=True)."""
         S = Lp["S"]
+        if isinstance(pr, dict):   # flash training forward
+            dqkv = torch.empty(nimg * G * G, 3 * H * d, dtype=cd, device=dev)
+            return ops.sam_attn_flash_bwd(qkv, Lp["qkv_b"], Lp["tbl_h"], Lp["tbl_w"], pr["ao"], dao, pr["lse"], pr["qext"], dqkv,
+                                          nimg, G, S, H, d, d ** -0.5)
         nws = (G + S - 1) // S
         nb, Nw = nimg * nws * nws * H, S * S
         Dq, NP, dp = _pad64(d + 2 * S), _pad64(Nw), _pad64(d)
