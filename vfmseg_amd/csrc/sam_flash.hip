@@ -24,6 +24,14 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 31, h = lane >> 5;
+#if SF_EXP == 9   // phase clocks of wave 0 (s_memtime), summed over the blocks into p.lse[0..15] (tools/scratch/_sam_flash_exp.py)
+  unsigned long long sf_tprev = __builtin_amdgcn_s_memtime();
+  unsigned sf_tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define SF_T(k) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+                  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); sf_tacc[k] += (unsigned)(now_ - sf_tprev); sf_tprev = now_; }
+#else
+#define SF_T(k)
+#endif
   // block -> (image, window, head, query block).  Workgroups go round-robin to the eight XCDs by linear id and each XCD has its own
   // L2: all H * QBLK blocks of one window (the same K / V rows; neighbouring heads share cache lines of the 160-byte segments) are
   // given ids congruent mod 8, so that a window's keys are fetched through ONE L2.  The last (windows % 8) windows keep the plain order.
@@ -71,6 +79,11 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
     }
     *reinterpret_cast<uint4*>(smem + 2 * C::TILE + (sec - 1) * (2 * SF_D) + c8 * 2) = v;
   }
+  // ---- K/V tile staging (SfKvStager, sam_flash_dev.h)
+  const SfGeo geo{img, wy, wx, G};
+  SfKvStager<S> stager;
+  auto fetch = [&](int t) __attribute__((always_inline)) { stager.fetch(p.qkv, p.ld, Cq, head, bimg, geo, t, tid); };
+  auto commit = [&](int buf, int t) __attribute__((always_inline)) { stager.commit(smem, buf, t, tid); };
   // ---- prologue 1: the table images (aliased with the end of K/V stage 1) and this wave's query fragments
   char* timg = smem + 2 * C::TILE - C::TIMG;             // [2][JP rows][176 B]
   for (int pc = tid; pc < 2 * C::JP * 10; pc += C::NT) {
@@ -88,6 +101,8 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
     qa[kk] = *reinterpret_cast<const bf16x8*>(&v);
   }
   __syncthreads();
+  SF_T(0)
+  fetch(0);   // the first K/V tile flies during the table products and the gather (it needs the bias image: after the barrier)
   // ---- prologue 2: T^T[j, q] = tbl[j, :] . q  (rows j = relative index), both axes, into the wave-private images
   // (stored as bf16 of T / scale, the value the query operand carries; aliased with the start of the K/V ring)
   __bf16* th = reinterpret_cast<__bf16*>(smem) + wave * (2 * C::JP * 32);
@@ -129,66 +144,19 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
     for (int e = 0; e < 2 * C::SP / 16; ++e)
       *reinterpret_cast<bf16x8*>(p.qext + stat_row * (2 * C::SP) + 16 * e + 8 * h) = qa[5 + e];
   }
+  SF_T(1)
   __syncthreads();  // everyone is done with the prologue images: the K/V ring may be overwritten
+  SF_T(2)
 
-  // ---- K/V tile staging: 64 keys x (10 K pieces + 10 V pieces + the one-hot columns), global -> registers -> LDS
-  // (the one-hot pieces come from the key index alone: commit() writes them without a staging register)
-  constexpr int PK = 64 * 10, POH = 64 * (2 * C::SP / 8), PPT = (2 * PK + C::NT - 1) / C::NT, PPO = (POH + C::NT - 1) / C::NT;
-  uint4 stg[PPT];
-  auto fetch = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const int pc = tid + i * C::NT;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (pc < 2 * PK) {
-        const int sec = pc / PK, rem = pc - sec * PK, row = rem / 10, c = rem - row * 10;
-        v = load_piece(1 + sec, t * 64 + row, c * 8);
-      }
-      stg[i] = v;
-    }
-  };
-  auto commit = [&](int buf, int t) {
-    char* kt = smem + buf * C::TILE;
-    char* vt = kt + 64 * C::KS;
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const int pc = tid + i * C::NT;
-      if (pc < PK) {
-        const int row = pc / 10, c = pc - row * 10;
-        *reinterpret_cast<uint4*>(kt + row * C::KS + c * 16) = stg[i];
-      } else if (pc < 2 * PK) {
-        const int rem = pc - PK, row = rem / 10, c = rem - row * 10;
-        *reinterpret_cast<uint4*>(vt + row * C::VS + c * 16) = stg[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < PPO; ++i) {
-      const int rem = tid + i * C::NT;
-      if (rem < POH) {
-        const int row = rem / (2 * C::SP / 8), c = rem - row * (2 * C::SP / 8);
-        const int key = t * 64 + row;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (key < C::NWIN) {
-          const int kh = key / S, kw = key - kh * S;
-          const int want = (c < C::SP / 8 ? kh : kw + C::SP) - 8 * c;   // position of the 1 inside this piece, if 0..7
-          if (want >= 0 && want < 8) {   // bf16 1.0 at element `want` of the piece
-            const uint32_t val = (want & 1) ? 0x3F800000u : 0x00003F80u;
-            const int wi = want >> 1;
-            v = make_uint4(wi == 0 ? val : 0u, wi == 1 ? val : 0u, wi == 2 ? val : 0u, wi == 3 ? val : 0u);
-          }
-        }
-        *reinterpret_cast<uint4*>(kt + row * C::KS + 160 + c * 16) = v;
-      }
-    }
-  };
   // columns 80..95 of both V stages are never written by the loader: zero them once (the third 32-row block of O^T reads them)
   for (int i = tid; i < 2 * 64 * 2; i += C::NT) {
     const int buf = i / 128, rem = i - buf * 128, row = rem >> 1, c = rem & 1;
     *reinterpret_cast<uint4*>(smem + buf * C::TILE + 64 * C::KS + row * C::VS + 160 + c * 16) = make_uint4(0, 0, 0, 0);
   }
-  fetch(0);
   commit(0, 0);
+  SF_T(3)
   __syncthreads();
+  SF_T(4)
 
   const float c = p.scale * SF_LOG2E;
   f32x16 oacc[3] = {sf_zero(), sf_zero(), sf_zero()};
@@ -198,15 +166,34 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
   // (A 14 x 14 window has 196 = 3 * 64 + 4 keys: its last tile is one block and one step.)
   auto tile = [&](auto nkb_c, auto nsl_c, int t, const char* kt, const char* vt) __attribute__((always_inline)) {
     constexpr int NKB = decltype(nkb_c)::value, NSL = decltype(nsl_c)::value;
+    // S^T = Kext Q^T: the row fragments are read four MFMAs ahead of their use and the two 32-key chains alternate (the compiler's own
+    // order keeps two reads in flight and waits before every pair of MFMAs: ~1.5k cycles of exposed LDS latency per tile at 2 waves per SIMD)
     f32x16 sacc[NKB];
+    constexpr int NQK = NKB * (SF_EXP == 4 ? 1 : C::KSTEPS), DEP = 4;
+    auto kfrag = [&](int i) __attribute__((always_inline)) -> bf16x8 {
+      const int kb = i % NKB, kk = i / NKB;
+      return *reinterpret_cast<const bf16x8*>(kt + (kb * 32 + fr) * C::KS + (2 * kk + h) * 16);
+    };
+    bf16x8 fk[DEP];
 #pragma unroll
-    for (int kb = 0; kb < NKB; ++kb) {
-      sacc[kb] = sf_zero();
+    for (int i = 0; i < DEP && i < NQK; ++i) fk[i] = kfrag(i);
+    __builtin_amdgcn_sched_group_barrier(0x100, DEP < NQK ? DEP : NQK, 0);
 #pragma unroll
-      for (int kk = 0; kk < (SF_EXP == 4 ? 1 : C::KSTEPS); ++kk) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(kt + (kb * 32 + fr) * C::KS + (2 * kk + h) * 16);
-        sacc[kb] = SF_MFMA(a, qa[kk], sacc[kb]);
-      }
+    for (int i = 0; i < NQK; ++i) {
+      const int kb = i % NKB, kk = i / NKB;
+      sacc[kb] = SF_MFMA(fk[i % DEP], qa[kk], kk == 0 ? sf_zero() : sacc[kb]);
+      if (i + DEP < NQK) fk[i % DEP] = kfrag(i + DEP);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // (pins the order: one MFMA, then the read four steps ahead)
+      if (i + DEP < NQK) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    SF_T(5)
+    // the V^T fragments of the first P V step do not depend on the softmax: read them now
+    constexpr int NST = (SF_EXP == 3 ? 0 : (NKB - 1) * 2 + NSL);
+    auto vfrag = [&](int n, int j) __attribute__((always_inline)) -> bf16x8 { return sf_tr_frag(vt, C::VS, (n >> 1) * 32 + 16 * (n & 1), j, lane); };
+    bf16x8 vf[2][3];
+    if (NST > 0) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) vf[0][j] = vfrag(0, j);
     }
     if ((C::NWIN % 64 != 0) && t == C::NTILES - 1) {  // ragged last tile: keys beyond the window do not exist
 #pragma unroll
@@ -244,65 +231,58 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[j][r] *= alpha;
     }
-    // ---- O^T[col, query] += V^T[col x key] P^T[key x query]
+    SF_T(6)
+    // ---- O^T[col, query] += V^T[col x key] P^T[key x query], step n = 16 keys; the fragments of step n + 1 are read before the MFMAs of step n
 #pragma unroll
-    for (int kb = 0; kb < (SF_EXP == 3 ? 0 : NKB); ++kb)
+    for (int n = 0; n < NST; ++n) {
+      if (n + 1 < NST) {
 #pragma unroll
-      for (int s = 0; s < (kb == NKB - 1 ? NSL : 2); ++s) {
-        bf16x8 pb;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pb[e] = (__bf16)sacc[kb][8 * s + e];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int g = lane >> 4, i = lane & 15, q4 = i >> 2, pp = i & 3, hh = g >> 1;
-          const int chunk = 4 * j + 2 * (g & 1) + (pp >> 1);
-          const int r0 = kb * 32 + 16 * s + 4 * hh + q4;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(vt + r0 * C::VS + chunk * 16 + ((pp & 1) << 3)));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(vt + (r0 + 8) * C::VS + chunk * 16 + ((pp & 1) << 3)));
-          union { struct { s16x4 a, b; } st; bf16x8 v; } u;
-          u.st.a = lo;
-          u.st.b = hi;
-          oacc[j] = SF_MFMA(u.v, pb, oacc[j]);
-        }
+        for (int j = 0; j < 3; ++j) vf[(n + 1) & 1][j] = vfrag(n + 1, j);
       }
+      bf16x8 pb;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pb[e] = (__bf16)sacc[n >> 1][8 * (n & 1) + e];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) oacc[j] = SF_MFMA(vf[n & 1][j], pb, oacc[j]);
+    }
   };
   constexpr int LASTK = C::NWIN - 64 * (C::NTILES - 1);     // keys of the last tile
   constexpr int NKB_LAST = (LASTK + 31) / 32, NSL_LAST = ((LASTK - 1) % 32 + 16) / 16;
 #pragma unroll 1
   for (int t = 0; t < C::NTILES; ++t) {
     const int buf = t & 1;
+    SF_T(10)
     if (SF_EXP != 1 && t + 1 < C::NTILES) fetch(t + 1);            // global loads of the next tile fly during this tile's products
     const char* kt = smem + buf * C::TILE;
     const char* vt = kt + 64 * C::KS;
+    SF_T(5)
     if (SF_EXP != 5 && active) {                                   // a wave past the window's last query only helps with the tile staging
       if ((NKB_LAST < 2 || NSL_LAST < 2) && t == C::NTILES - 1)
         tile(std::integral_constant<int, NKB_LAST>{}, std::integral_constant<int, NSL_LAST>{}, t, kt, vt);
       else
         tile(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, t, kt, vt);
     }
+    SF_T(7)
     if (SF_EXP != 1 && t + 1 < C::NTILES) commit(buf ^ 1, t + 1);        // stage buf^1 was last read during tile t-1: every wave passed that barrier
+    SF_T(8)
     __syncthreads();
+    SF_T(9)
   }
+#if SF_EXP == 9
+  SF_T(11)
+  if (wave == 0 && lane == 0 && p.lse) {
+    for (int k = 0; k < 12; ++k) p.lse[blockIdx.x * 16 + k] = (float)sf_tacc[k];
+  }
+  return;
+#endif
   // ---- epilogue: lane = query, registers = output columns sf_acc_row(r, h) + 32 j (columns >= 80 are padding)
   l += __shfl_xor(l, 32, 64);
   const float mult = 1.f / l;
   if (p.lse && qi < C::NWIN && h == 0) p.lse[stat_row] = m * c + __builtin_amdgcn_logf(l);   // log2 domain: P = exp2(c s - lse)
   bool inside = false;
   const long row = tok_row(qc, inside);
-  if (qi < C::NWIN && inside) {
-    bf16_t* o = p.out + row * p.ldo + head * SF_D;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int col = 32 * j + 8 * rq + 4 * h;     // four consecutive columns: registers 4 rq .. 4 rq + 3
-        if (col < SF_D)
-          *reinterpret_cast<uint2*>(o + col) = make_uint2(sf_pack2(oacc[j][4 * rq] * mult, oacc[j][4 * rq + 1] * mult),
-                                                          sf_pack2(oacc[j][4 * rq + 2] * mult, oacc[j][4 * rq + 3] * mult));
-      }
-  }
+  if (SF_EXP != 7)   // (the loop's last barrier has passed: the K/V ring is free for the wave-private output images)
+    sf_store_rows(smem + wave * SF_OIMG, oacc, mult, (qi < C::NWIN && inside) ? (int)row : -1, p.out + head * SF_D, p.ldo, lane);
 }
 
 template <int S>
@@ -324,7 +304,7 @@ static int sam_flash_fwd_impl(const void* qkv, long ld, const float* bias, const
   VFM_CHECK(d == SF_D, VFM_E_UNSUPPORTED, "vfm_sam_attn_flash_fwd: head dim %d (only 80 = SAM ViT-H)", d);
   VFM_CHECK((S == 14 && G > 0) || (S == 32 && G == 32), VFM_E_UNSUPPORTED,
             "vfm_sam_attn_flash_fwd: window %d on a %d-token grid (14 x 14 windows or 32 x 32 global)", S, G);
-  VFM_CHECK(ld % 8 == 0 && ldo % 4 == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 7) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
+  VFM_CHECK(ld % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
                 ((uintptr_t)tbl_h & 15) == 0 && ((uintptr_t)tbl_w & 15) == 0,
             VFM_E_ALIGN, "vfm_sam_attn_flash_fwd: alignment");
   if (nimg <= 0) return VFM_OK;

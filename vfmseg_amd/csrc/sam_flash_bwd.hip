@@ -68,21 +68,6 @@ __device__ __forceinline__ float sf_dot8(uint4 a, uint4 b) {
   return s;
 }
 
-// A operand (rows = stored columns 32 j .., k = stored rows of 16-row step `r16`) by transposing LDS reads, as the forward's P V product
-__device__ __forceinline__ bf16x8 sf_tr_frag(const char* base, int stride, int r16, int j, int lane) {
-  const int g = lane >> 4, i = lane & 15, q4 = i >> 2, pp = i & 3, hh = g >> 1;
-  const int chunk = 4 * j + 2 * (g & 1) + (pp >> 1);
-  const int r0 = r16 + 4 * hh + q4;
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4*)(base + r0 * stride + chunk * 16 + ((pp & 1) << 3)));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4*)(base + (r0 + 8) * stride + chunk * 16 + ((pp & 1) << 3)));
-  union { struct { s16x4 a, b; } st; bf16x8 v; } u;
-  u.st.a = lo;
-  u.st.b = hi;
-  return u.v;
-}
-
 // ============================================================ dq (+ D)
 template <int S>
 __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlashBwdP p) {
@@ -119,6 +104,19 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
     return v;
   };
 
+  __syncthreads();   // bias image
+
+  // ---- K/V tile staging, as the forward (SfKvStager, sam_flash_dev.h)
+  const SfGeo geo{B.img, B.wy, B.wx, B.G};
+  SfKvStager<S> stager;
+  auto fetch = [&](int t) __attribute__((always_inline)) { stager.fetch(p.qkv, p.ld, Cq, head, bimg, geo, t, tid); };
+  auto commit = [&](int buf, int t) __attribute__((always_inline)) { stager.commit(smem, buf, t, tid); };
+  // the pad bytes of the K rows (beyond 160 + 4 SP) are read by the transposing loads of the last row block: keep them finite
+  for (int i = tid; i < 2 * 64; i += C::NT) {
+    char* row = smem + (i >> 6) * C::TILE + (i & 63) * C::KS;
+    for (int b = 160 + 4 * C::SP; b < C::KS; b += 16) *reinterpret_cast<uint4*>(row + b) = make_uint4(0, 0, 0, 0);
+  }
+  fetch(0);   // in flight together with the query's own loads below
   // ---- this lane's query: operand [q | qext], dO fragments, D = dO . O, lse
   const int q0 = B.sub * (C::NW * 32) + wave * 32;
   const int qi = q0 + fr;
@@ -145,63 +143,6 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
   dsum += __shfl_xor(dsum, 32, 64);
   if (qi < C::NWIN && h == 0) p.dsum[stat] = dsum;
   const float L = p.lse[stat];
-  __syncthreads();   // bias image
-
-  // ---- K/V tile staging, as the forward
-  constexpr int PK = 64 * 10, POH = 64 * (2 * C::SP / 8), PPT = (2 * PK + C::NT - 1) / C::NT, PPO = (POH + C::NT - 1) / C::NT;
-  uint4 stg[PPT];
-  auto fetch = [&](int t) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const int pc = tid + i * C::NT;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (pc < 2 * PK) {
-        const int sec = pc / PK, rem = pc - sec * PK, row = rem / 10, c = rem - row * 10;
-        v = load_piece(1 + sec, t * 64 + row, c * 8);
-      }
-      stg[i] = v;
-    }
-  };
-  auto commit = [&](int buf, int t) __attribute__((always_inline)) {
-    char* kt = smem + buf * C::TILE;
-    char* vt = kt + 64 * C::KS;
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const int pc = tid + i * C::NT;
-      if (pc < PK) {
-        const int row = pc / 10, c = pc - row * 10;
-        *reinterpret_cast<uint4*>(kt + row * C::KS + c * 16) = stg[i];
-      } else if (pc < 2 * PK) {
-        const int rem = pc - PK, row = rem / 10, c = rem - row * 10;
-        *reinterpret_cast<uint4*>(vt + row * C::VS + c * 16) = stg[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < PPO; ++i) {
-      const int rem = tid + i * C::NT;
-      if (rem < POH) {
-        const int row = rem / (2 * C::SP / 8), c = rem - row * (2 * C::SP / 8);
-        const int key = t * 64 + row;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (key < C::NWIN) {
-          const int kh = key / S, kw = key - kh * S;
-          const int want = (c < C::SP / 8 ? kh : kw + C::SP) - 8 * c;
-          if (want >= 0 && want < 8) {
-            const uint32_t val = (want & 1) ? 0x3F800000u : 0x00003F80u;
-            const int wi = want >> 1;
-            v = make_uint4(wi == 0 ? val : 0u, wi == 1 ? val : 0u, wi == 2 ? val : 0u, wi == 3 ? val : 0u);
-          }
-        }
-        *reinterpret_cast<uint4*>(kt + row * C::KS + 160 + c * 16) = v;
-      }
-    }
-  };
-  // the pad bytes of the K rows (beyond 160 + 4 SP) are read by the transposing loads of the last row block: keep them finite
-  for (int i = tid; i < 2 * 64; i += C::NT) {
-    char* row = smem + (i >> 6) * C::TILE + (i & 63) * C::KS;
-    for (int b = 160 + 4 * C::SP; b < C::KS; b += 16) *reinterpret_cast<uint4*>(row + b) = make_uint4(0, 0, 0, 0);
-  }
-  fetch(0);
   commit(0, 0);
   __syncthreads();
 
@@ -294,17 +235,11 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
         for (int j = 0; j < 3; ++j) dq[j] = SF_MFMA(sf_tr_frag(timg + which * C::JP * C::TS, C::TS, 16 * js, j, lane), pb, dq[j]);
       }
   }
-  if (qi < C::NWIN && q_inside) {
-    bf16_t* o = p.dqkv + q_row * p.ldg + head * SF_D;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int col = 32 * j + 8 * rq + 4 * h;
-        if (col < SF_D)
-          *reinterpret_cast<uint2*>(o + col) = make_uint2(sf_pack2(dq[j][4 * rq], dq[j][4 * rq + 1]), sf_pack2(dq[j][4 * rq + 2], dq[j][4 * rq + 3]));
-      }
-  }
+  // output image: behind the dB images (S = 14) or over this wave's own dB image (S = 32, read above); never over the table images
+  constexpr int IMG0 = S == 14 ? C::NW * 2 * C::SP * 32 * 4 : 0, IMGSZ = S == 14 ? SF_OIMG : 2 * C::SP * 32 * 4;
+  static_assert(IMGSZ >= SF_OIMG && IMG0 + C::NW * IMGSZ <= 2 * C::TILE - C::TIMG, "output images overlap the table images");
+  sf_store_rows(smem + IMG0 + wave * IMGSZ, reinterpret_cast<const f32x16(&)[3]>(dq[0]), 1.0f, (qi < C::NWIN && q_inside) ? (int)q_row : -1,
+                p.dqkv + head * SF_D, p.ldg, lane);
 }
 
 // ============================================================ dk, dv
@@ -327,13 +262,78 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlas
   const int head = B.head, Cq = p.H * SF_D;
   const long wh = B.wh(p.nws);
 
+  // ---- query tile staging: 64 queries x ([q | qext] rows, dO rows) + lse / D, global -> registers -> LDS; thread (row = tid >> 2,
+  // quarter = tid & 3) owns the pieces {quarter, quarter + 4, quarter + 8 (< 10)} of its query row in q and dO and one or two qext pieces
+  constexpr int NE = 2 * C::SP / 32;   // qext pieces per thread
+  const int srow = tid >> 2, sq = tid & 3;
+  const SfGeo geo{B.img, B.wy, B.wx, B.G};
+  uint4 stq[3], std_[3], stge[NE], stgs;
+  auto fetch = [&](int t) __attribute__((always_inline)) {
+    const int tq = t * 64 + srow;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) stq[i] = std_[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) stge[i] = make_uint4(0, 0, 0, 0);
+    if (tq < C::NWIN) {
+      bool inside;
+      const long grow = geo.tok_row<S>(tq, inside);
+      if (inside) {   // a padded query has no output: q does not matter and dO = 0
+        const bf16_t* sq_ = p.qkv + grow * p.ld + head * SF_D + sq * 8;
+        const bf16_t* sd_ = p.dout + grow * p.ldo + head * SF_D + sq * 8;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          if (i < 2 || sq < 2) {
+            stq[i] = *reinterpret_cast<const uint4*>(sq_ + 32 * i);
+            std_[i] = *reinterpret_cast<const uint4*>(sd_ + 32 * i);
+          }
+      }
+      const bf16_t* se_ = p.qext + (wh * C::NWINP + tq) * (2 * C::SP) + sq * 8;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) stge[i] = *reinterpret_cast<const uint4*>(se_ + 32 * i);
+    }
+    {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (tid < 32) {   // pieces 0..15: lse (rows beyond the window: +inf, so p = 0), 16..31: D (0 there)
+        const int which = tid >> 4, q4 = t * 64 + 4 * (tid & 15);
+        const float* src = (which ? p.dsum : p.lse) + wh * C::NWINP + q4;
+        const float fill = which ? 0.f : INFINITY;
+        float f[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[e] = q4 + e < C::NWIN ? src[e] : fill;
+        v = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+      }
+      stgs = v;
+    }
+  };
+  auto commit = [&](int buf) __attribute__((always_inline)) {
+    char* qt = smem + buf * CB::TILE + srow * C::KS + sq * 16;
+    char* dt = smem + buf * CB::TILE + 64 * C::KS + srow * C::VS + sq * 16;
+    char* st = smem + buf * CB::TILE + 64 * (C::KS + C::VS);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < 2 || sq < 2) {
+        *reinterpret_cast<uint4*>(qt + 64 * i) = stq[i];
+        *reinterpret_cast<uint4*>(dt + 64 * i) = std_[i];
+      }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) *reinterpret_cast<uint4*>(qt + 160 + 64 * i) = stge[i];
+    if (tid < 32) *reinterpret_cast<uint4*>(st + tid * 16) = stgs;
+  };
+  // pad bytes that the transposing reads of column block 2 touch (q rows beyond 160 + 4 SP, dO rows beyond 160): keep them finite
+  for (int i = tid; i < 2 * 64; i += C::NT) {
+    char* qrow = smem + (i >> 6) * CB::TILE + (i & 63) * C::KS;
+    char* drow = smem + (i >> 6) * CB::TILE + 64 * C::KS + (i & 63) * C::VS;
+    for (int b = 160 + 4 * C::SP; b < C::KS; b += 16) *reinterpret_cast<uint4*>(qrow + b) = make_uint4(0, 0, 0, 0);
+    for (int b = 160; b < C::VS; b += 16) *reinterpret_cast<uint4*>(drow + b) = make_uint4(0, 0, 0, 0);
+  }
+  fetch(0);   // in flight together with the key's own loads below
   // ---- this lane's key: operands [k | onehot(kh) | onehot(kw)] and v
   const int k0 = B.sub * (C::NW * 32) + wave * 32;
   const int ki = k0 + fr;
   const int kc = ki < C::NWIN ? ki : C::NWIN - 1;
   bool k_inside;
   const long k_row = B.tok_row(kc, k_inside);
-  bf16x8 kq[C::KSTEPS], vb[5];
+  bf16x8 kq[5], vb[5];
 #pragma unroll
   for (int kk = 0; kk < 5; ++kk) {
     uint4 vk = make_uint4(0, 0, 0, 0), vv = vk;
@@ -351,98 +351,26 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlas
     kq[kk] = *reinterpret_cast<const bf16x8*>(&vk);
     vb[kk] = *reinterpret_cast<const bf16x8*>(&vv);
   }
+  // the one-hot columns of the key operand are rebuilt from two integers per axis at each use (registers are the scarce resource here):
+  // dword d of k-step ks holds bf16 1.0 in its low / high half iff (coordinate - 8 h) >> 1 == 8 ks + d
+  int oh_idx[2];
+  uint32_t oh_val[2];
   {
     const int kh = kc / S, kw = kc - kh * S;
 #pragma unroll
-    for (int which = 0; which < 2; ++which)
-#pragma unroll
-      for (int ks = 0; ks < C::SP / 16; ++ks) {
-        bf16x8 u;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) u[e] = (16 * ks + 8 * h + e == (which ? kw : kh)) ? (__bf16)1.0f : (__bf16)0.f;
-        kq[5 + which * (C::SP / 16) + ks] = u;
-      }
+    for (int which = 0; which < 2; ++which) {
+      const int slot = (which ? kw : kh) - 8 * h;
+      oh_idx[which] = slot >> 1;
+      oh_val[which] = (slot & 1) ? 0x3F800000u : 0x00003F80u;
+    }
   }
-
-  // ---- query tile staging: 64 queries x (10 q pieces + the qext pieces + 10 dO pieces) + lse / D, global -> registers -> LDS
-  constexpr int PQ = 64 * 10, PE = 64 * (2 * C::SP / 8), PPT = (2 * PQ + C::NT - 1) / C::NT, PPE = (PE + C::NT - 1) / C::NT;
-  uint4 stg[PPT], stge[PPE], stgs;
-  auto fetch = [&](int t) __attribute__((always_inline)) {
+  auto onehot = [&](int which, int ks) __attribute__((always_inline)) -> bf16x8 {
+    uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const int pc = tid + i * C::NT;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (pc < 2 * PQ) {
-        const int sec = pc / PQ, rem = pc - sec * PQ, row = rem / 10, cc = rem - row * 10;
-        const int tq = t * 64 + row;
-        if (tq < C::NWIN) {
-          bool inside;
-          const long grow = B.tok_row(tq, inside);
-          if (inside)   // a padded query has no output: q does not matter and dO = 0
-            v = sec == 0 ? *reinterpret_cast<const uint4*>(p.qkv + grow * p.ld + head * SF_D + cc * 8)
-                         : *reinterpret_cast<const uint4*>(p.dout + grow * p.ldo + head * SF_D + cc * 8);
-        }
-      }
-      stg[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < PPE; ++i) {
-      const int rem = tid + i * C::NT;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (rem < PE) {
-        const int row = rem / (2 * C::SP / 8), cc = rem - row * (2 * C::SP / 8);
-        const int tq = t * 64 + row;
-        if (tq < C::NWIN) v = *reinterpret_cast<const uint4*>(p.qext + (wh * C::NWINP + tq) * (2 * C::SP) + cc * 8);
-      }
-      stge[i] = v;
-    }
-    {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (tid < 32) {   // pieces 0..15: lse (rows beyond the window: +inf, so p = 0), 16..31: D (0 there)
-        const int which = tid >> 4, q4 = t * 64 + 4 * (tid & 15);
-        const float* src = (which ? p.dsum : p.lse) + wh * C::NWINP + q4;
-        const float fill = which ? 0.f : INFINITY;
-        float f[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) f[e] = q4 + e < C::NWIN ? src[e] : fill;
-        v = make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
-      }
-      stgs = v;
-    }
+    for (int dd = 0; dd < 4; ++dd) w[dd] = oh_idx[which] == 8 * ks + dd ? oh_val[which] : 0u;
+    const uint4 u = make_uint4(w[0], w[1], w[2], w[3]);
+    return *reinterpret_cast<const bf16x8*>(&u);
   };
-  auto commit = [&](int buf) __attribute__((always_inline)) {
-    char* qt = smem + buf * CB::TILE;
-    char* dt = qt + 64 * C::KS;
-    char* st = dt + 64 * C::VS;
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const int pc = tid + i * C::NT;
-      if (pc < PQ) {
-        const int row = pc / 10, cc = pc - row * 10;
-        *reinterpret_cast<uint4*>(qt + row * C::KS + cc * 16) = stg[i];
-      } else if (pc < 2 * PQ) {
-        const int rem = pc - PQ, row = rem / 10, cc = rem - row * 10;
-        *reinterpret_cast<uint4*>(dt + row * C::VS + cc * 16) = stg[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < PPE; ++i) {
-      const int rem = tid + i * C::NT;
-      if (rem < PE) {
-        const int row = rem / (2 * C::SP / 8), cc = rem - row * (2 * C::SP / 8);
-        *reinterpret_cast<uint4*>(qt + row * C::KS + 160 + cc * 16) = stge[i];
-      }
-    }
-    if (tid < 32) *reinterpret_cast<uint4*>(st + tid * 16) = stgs;
-  };
-  // pad bytes that the transposing reads of column block 2 touch (q rows beyond 160 + 4 SP, dO rows beyond 160): keep them finite
-  for (int i = tid; i < 2 * 64; i += C::NT) {
-    char* qrow = smem + (i >> 6) * CB::TILE + (i & 63) * C::KS;
-    char* drow = smem + (i >> 6) * CB::TILE + 64 * C::KS + (i & 63) * C::VS;
-    for (int b = 160 + 4 * C::SP; b < C::KS; b += 16) *reinterpret_cast<uint4*>(qrow + b) = make_uint4(0, 0, 0, 0);
-    for (int b = 160; b < C::VS; b += 16) *reinterpret_cast<uint4*>(drow + b) = make_uint4(0, 0, 0, 0);
-  }
-  fetch(0);
   commit(0);
   __syncthreads();
 
@@ -469,7 +397,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlas
 #pragma unroll
         for (int kk = 0; kk < C::KSTEPS; ++kk) {
           const bf16x8 a = *reinterpret_cast<const bf16x8*>(qt + (qb * 32 + fr) * C::KS + (2 * kk + h) * 16);
-          sacc = SF_MFMA(a, kq[kk], sacc);
+          sacc = SF_MFMA(a, kk < 5 ? kq[kk] : onehot((kk - 5) / (C::SP / 16), (kk - 5) % (C::SP / 16)), sacc);
         }
 #pragma unroll
         for (int kk = 0; kk < 5; ++kk) {
@@ -504,21 +432,9 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlas
     __syncthreads();
   }
 
-  if (ki < C::NWIN && k_inside) {
-    bf16_t* ok = p.dqkv + k_row * p.ldg + Cq + head * SF_D;
-    bf16_t* ov = ok + Cq;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int col = 32 * j + 8 * rq + 4 * h;
-        if (col < SF_D) {
-          *reinterpret_cast<uint2*>(ok + col) = make_uint2(sf_pack2(dk[j][4 * rq] * p.scale, dk[j][4 * rq + 1] * p.scale),
-                                                           sf_pack2(dk[j][4 * rq + 2] * p.scale, dk[j][4 * rq + 3] * p.scale));
-          *reinterpret_cast<uint2*>(ov + col) = make_uint2(sf_pack2(dv[j][4 * rq], dv[j][4 * rq + 1]), sf_pack2(dv[j][4 * rq + 2], dv[j][4 * rq + 3]));
-        }
-      }
-  }
+  const int k_dst = (ki < C::NWIN && k_inside) ? (int)k_row : -1;
+  sf_store_rows(smem + wave * SF_OIMG, dk, p.scale, k_dst, p.dqkv + Cq + head * SF_D, p.ldg, lane);
+  sf_store_rows(smem + wave * SF_OIMG, dv, 1.0f, k_dst, p.dqkv + 2 * Cq + head * SF_D, p.ldg, lane);
 }
 
 template <int S>
@@ -548,8 +464,8 @@ extern "C" int vfm_sam_attn_flash_bwd(const void* qkv, long ld, const float* bia
   VFM_CHECK(d == SF_D, VFM_E_UNSUPPORTED, "vfm_sam_attn_flash_bwd: head dim %d (only 80 = SAM ViT-H)", d);
   VFM_CHECK((S == 14 && G > 0) || (S == 32 && G == 32), VFM_E_UNSUPPORTED,
             "vfm_sam_attn_flash_bwd: window %d on a %d-token grid (14 x 14 windows or 32 x 32 global)", S, G);
-  VFM_CHECK(ld % 8 == 0 && ldo % 8 == 0 && ldg % 4 == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)dout & 15) == 0 &&
-                ((uintptr_t)dqkv & 7) == 0 && ((uintptr_t)qext & 15) == 0 && ((uintptr_t)lse & 15) == 0 && ((uintptr_t)dsum & 15) == 0 &&
+  VFM_CHECK(ld % 8 == 0 && ldo % 8 == 0 && ldg % 8 == 0 && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)dout & 15) == 0 &&
+                ((uintptr_t)dqkv & 15) == 0 && ((uintptr_t)qext & 15) == 0 && ((uintptr_t)lse & 15) == 0 && ((uintptr_t)dsum & 15) == 0 &&
                 (!bias || ((uintptr_t)bias & 15) == 0) && ((uintptr_t)tbl_h & 15) == 0 && ((uintptr_t)tbl_w & 15) == 0,
             VFM_E_ALIGN, "vfm_sam_attn_flash_bwd: alignment");
   if (nimg <= 0) return VFM_OK;

@@ -60,3 +60,124 @@ __device__ __forceinline__ uint32_t sf_pack2(float a, float b) {
   return *reinterpret_cast<const uint32_t*>(&v);
 }
 
+
+// A operand (rows = stored columns 32 j .., k = stored rows of 16-row step `r16`) by transposing LDS reads, as the forward's P V product
+__device__ __forceinline__ bf16x8 sf_tr_frag(const char* base, int stride, int r16, int j, int lane) {
+  const int g = lane >> 4, i = lane & 15, q4 = i >> 2, pp = i & 3, hh = g >> 1;
+  const int chunk = 4 * j + 2 * (g & 1) + (pp >> 1);
+  const int r0 = r16 + 4 * hh + q4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(base + r0 * stride + chunk * 16 + ((pp & 1) << 3)));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(base + (r0 + 8) * stride + chunk * 16 + ((pp & 1) << 3)));
+  union { struct { s16x4 a, b; } st; bf16x8 v; } u;
+  u.st.a = lo;
+  u.st.b = hi;
+  return u.v;
+}
+
+// ---- window geometry and the K/V tile stager shared by the forward and the dq kernel
+struct SfGeo {
+  int img, wy, wx, G;
+  template <int S>
+  __device__ __forceinline__ long tok_row(int t, bool& inside) const {   // window token index -> row of the token-major matrices
+    const int ty = t / S, tx = t - ty * S;
+    const int gy = wy * S + ty, gx = wx * S + tx;
+    inside = gy < G && gx < G;
+    return ((long)img * G + gy) * G + gx;
+  }
+};
+
+// One K/V tile = 64 keys x ([k | onehot(kh) | onehot(kw)] rows of KS bytes, v rows of VS bytes), global -> registers -> LDS.
+// Thread (row = tid >> 2, quarter = tid & 3) of the 256-thread block owns the 16-byte pieces {quarter, quarter + 4, quarter + 8 (< 10)}
+// of ITS key row in k and in v: one token-row computation and one address per tile and thread, the pieces at immediate offsets
+// (a piece-major split costs ~30 VALU instructions of index arithmetic per piece, which made the staging ~60 % of the loop's VALU work).
+// A token outside the image has k / v = the projection bias, read from the block's packed image in LDS (bimg: [2][80] bf16).
+template <int S>
+struct SfKvStager {
+  using C = SamFlashCfg<S>;
+  static_assert(C::NT == 256, "row / quarter split of 256 threads");
+  uint4 k[3], v[3];
+  __device__ __forceinline__ void fetch(const bf16_t* qkv, long ld, int Cq, int head, const char* bimg, const SfGeo& g, int t, int tid) {
+    const int row = tid >> 2, sq = tid & 3, key = t * 64 + row;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) k[i] = v[i] = make_uint4(0, 0, 0, 0);
+    if (key < C::NWIN) {
+      bool inside;
+      const long tr = g.tok_row<S>(key, inside);
+      if (inside) {
+        const bf16_t* src = qkv + tr * ld + Cq + head * SF_D + sq * 8;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          if (i < 2 || sq < 2) {
+            k[i] = *reinterpret_cast<const uint4*>(src + 32 * i);
+            v[i] = *reinterpret_cast<const uint4*>(src + Cq + 32 * i);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          if (i < 2 || sq < 2) {
+            k[i] = *reinterpret_cast<const uint4*>(bimg + (sq + 4 * i) * 16);
+            v[i] = *reinterpret_cast<const uint4*>(bimg + 2 * SF_D + (sq + 4 * i) * 16);
+          }
+      }
+    }
+  }
+  __device__ __forceinline__ void commit(char* smem, int buf, int t, int tid) const {
+    const int row = tid >> 2, sq = tid & 3, key = t * 64 + row;
+    char* kt = smem + buf * C::TILE + row * C::KS + sq * 16;
+    char* vt = smem + buf * C::TILE + 64 * C::KS + row * C::VS + sq * 16;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < 2 || sq < 2) {
+        *reinterpret_cast<uint4*>(kt + 64 * i) = k[i];
+        *reinterpret_cast<uint4*>(vt + 64 * i) = v[i];
+      }
+    // the one-hot pieces (2 SP / 8 per row: one or two per thread) come from the key index alone
+    const int kh = key / S, kw = key - kh * S;
+#pragma unroll
+    for (int i = 0; i < 2 * C::SP / 32; ++i) {
+      const int c = sq + 4 * i;
+      uint4 o = make_uint4(0, 0, 0, 0);
+      const int want = (c < C::SP / 8 ? kh : kw + C::SP) - 8 * c;   // position of the 1 inside this piece, if 0..7
+      if (key < C::NWIN && want >= 0 && want < 8) {
+        const uint32_t val = (want & 1) ? 0x3F800000u : 0x00003F80u;
+        const int wi = want >> 1;
+        o = make_uint4(wi == 0 ? val : 0u, wi == 1 ? val : 0u, wi == 2 ? val : 0u, wi == 3 ? val : 0u);
+      }
+      *reinterpret_cast<uint4*>(kt - sq * 16 + 160 + c * 16) = o;
+    }
+  }
+};
+
+// ---- output rows through LDS.  The accumulators hold O^T (lane = row of the output, registers = columns): a direct store is one
+// 8-byte piece per lane at a row pitch of kilobytes - 64 partial cache lines per instruction, measured at 25 % of the forward's run
+// time.  Instead the wave writes its 32 x 80 block into a private LDS image (rows of SF_OROW bytes, the row's destination index in
+// the pad) and stores it back as 16-byte pieces, ten consecutive lanes per 160-byte row.
+#define SF_OROW 176
+#define SF_OIMG (32 * SF_OROW)
+__device__ __forceinline__ void sf_store_rows(char* img, const f32x16 (&acc)[3], float mult, int dst_row /* -1: no output */, bf16_t* dst,
+                                              long ld, int lane) {
+  const int fr = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int col = 32 * j + 8 * rq + 4 * h;     // four consecutive columns: registers 4 rq .. 4 rq + 3
+      if (col < SF_D)
+        *reinterpret_cast<uint2*>(img + fr * SF_OROW + col * 2) =
+            make_uint2(sf_pack2(acc[j][4 * rq] * mult, acc[j][4 * rq + 1] * mult), sf_pack2(acc[j][4 * rq + 2] * mult, acc[j][4 * rq + 3] * mult));
+    }
+  if (h == 0) *reinterpret_cast<int*>(img + fr * SF_OROW + 2 * SF_D) = dst_row;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int pc = lane + 64 * i, r = pc / 10, c = pc - r * 10;
+    const int rr = *reinterpret_cast<const int*>(img + r * SF_OROW + 2 * SF_D);
+    const uint4 v = *reinterpret_cast<const uint4*>(img + r * SF_OROW + c * 16);
+    if (rr >= 0) *reinterpret_cast<uint4*>(dst + (long)rr * ld + c * 8) = v;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();   // the image may be rewritten (dk then dv)
+}
