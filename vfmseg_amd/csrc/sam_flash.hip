@@ -69,40 +69,57 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
     }
     return v;
   };
-  if (tid < 20) {
-    const int sec = 1 + tid / 10, c8 = (tid % 10) * 8;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (p.bias) {
-      const float* b = p.bias + sec * Cq + head * SF_D + c8;
-      const float4 a = *reinterpret_cast<const float4*>(b), c = *reinterpret_cast<const float4*>(b + 4);
-      v = make_uint4(sf_pack2(a.x, a.y), sf_pack2(a.z, a.w), sf_pack2(c.x, c.y), sf_pack2(c.z, c.w));
-    }
-    *reinterpret_cast<uint4*>(smem + 2 * C::TILE + (sec - 1) * (2 * SF_D) + c8 * 2) = v;
-  }
   // ---- K/V tile staging (SfKvStager, sam_flash_dev.h)
   const SfGeo geo{img, wy, wx, G};
   SfKvStager<S> stager;
   auto fetch = [&](int t) __attribute__((always_inline)) { stager.fetch(p.qkv, p.ld, Cq, head, bimg, geo, t, tid); };
   auto commit = [&](int buf, int t) __attribute__((always_inline)) { stager.commit(smem, buf, t, tid); };
-  // ---- prologue 1: the table images (aliased with the end of K/V stage 1) and this wave's query fragments
+  // ---- prologue 1: the bias image, the table images (aliased with the end of K/V stage 1) and this wave's query fragments.  ALL their
+  // global loads are issued before the first one is consumed: one round trip (a runtime loop over the table pieces made it one per pass)
   char* timg = smem + 2 * C::TILE - C::TIMG;             // [2][JP rows][176 B]
-  for (int pc = tid; pc < 2 * C::JP * 10; pc += C::NT) {
-    const int which = pc / (C::JP * 10), rem = pc - which * (C::JP * 10), row = rem / 10, c = rem - row * 10;
-    const bf16_t* src = which ? p.tbl_w : p.tbl_h;
-    *reinterpret_cast<uint4*>(timg + (which * C::JP + row) * C::TS + c * 16) = *reinterpret_cast<const uint4*>(src + row * SF_D + c * 8);
-  }
   const int q0 = qb * (C::NW * 32) + wave * 32;
   const int qi = q0 + fr;                            // this lane's query (window token index)
   const int qc = qi < C::NWIN ? qi : C::NWIN - 1;    // clamped: surplus queries of the last wave are computed and dropped
   bf16x8 qa[C::KSTEPS];
+  {
+    constexpr int NTP = 2 * C::JP * 10, NTI = (NTP + C::NT - 1) / C::NT;
+    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+    const int bsec = 1 + tid / 10, bc8 = (tid % 10) * 8;
+    if (tid < 20 && p.bias) {
+      const float* b = p.bias + bsec * Cq + head * SF_D + bc8;
+      b0 = *reinterpret_cast<const float4*>(b), b1 = *reinterpret_cast<const float4*>(b + 4);
+    }
+    uint4 tp[NTI];
 #pragma unroll
-  for (int kk = 0; kk < 5; ++kk) {
-    const uint4 v = load_piece(0, qc, 16 * kk + 8 * h);
-    qa[kk] = *reinterpret_cast<const bf16x8*>(&v);
+    for (int i = 0; i < NTI; ++i) {
+      const int pc = tid + i * C::NT;
+      tp[i] = make_uint4(0, 0, 0, 0);
+      if (pc < NTP) {
+        const int which = pc / (C::JP * 10), rem = pc - which * (C::JP * 10);
+        tp[i] = *reinterpret_cast<const uint4*>((which ? p.tbl_w : p.tbl_h) + rem * 8);   // (row, piece) of a [JP, 80] table = piece rem of its flat array
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 5; ++kk) {
+      const uint4 v = load_piece(0, qc, 16 * kk + 8 * h);
+      qa[kk] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+    stager.fetch_first_global(p.qkv, p.ld, Cq, head, geo, tid);   // the first K/V tile (its tokens inside the image) flies with the prologue loads, the table products and the gather
+    if (tid < 20)
+      *reinterpret_cast<uint4*>(smem + 2 * C::TILE + (bsec - 1) * (2 * SF_D) + bc8 * 2) =
+          make_uint4(sf_pack2(b0.x, b0.y), sf_pack2(b0.z, b0.w), sf_pack2(b1.x, b1.y), sf_pack2(b1.z, b1.w));
+#pragma unroll
+    for (int i = 0; i < NTI; ++i) {
+      const int pc = tid + i * C::NT;
+      if (pc < NTP) {
+        const int which = pc / (C::JP * 10), rem = pc - which * (C::JP * 10), row = rem / 10, c = rem - row * 10;
+        *reinterpret_cast<uint4*>(timg + (which * C::JP + row) * C::TS + c * 16) = tp[i];
+      }
+    }
   }
   __syncthreads();
   SF_T(0)
-  fetch(0);   // the first K/V tile flies during the table products and the gather (it needs the bias image: after the barrier)
+  stager.fetch_first_bias(bimg, geo, tid);   // (its padded tokens: from the bias image, after the barrier)
   // ---- prologue 2: T^T[j, q] = tbl[j, :] . q  (rows j = relative index), both axes, into the wave-private images
   // (stored as bf16 of T / scale, the value the query operand carries; aliased with the start of the K/V ring)
   __bf16* th = reinterpret_cast<__bf16*>(smem) + wave * (2 * C::JP * 32);
@@ -148,10 +165,12 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
   __syncthreads();  // everyone is done with the prologue images: the K/V ring may be overwritten
   SF_T(2)
 
-  // columns 80..95 of both V stages are never written by the loader: zero them once (the third 32-row block of O^T reads them)
+  // columns 80..95 of both V stages are never written by the loader: set them once - column 80 to ONE, the rest to zero.  Row 80 of
+  // O^T = sum_k P[k, q] then IS the softmax denominator (of the bf16 probabilities the product uses, rescaled with the other rows):
+  // the 32 row-sum adds per tile and lane leave the VALU, which is what bounds this kernel.
   for (int i = tid; i < 2 * 64 * 2; i += C::NT) {
     const int buf = i / 128, rem = i - buf * 128, row = rem >> 1, c = rem & 1;
-    *reinterpret_cast<uint4*>(smem + buf * C::TILE + 64 * C::KS + row * C::VS + 160 + c * 16) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(smem + buf * C::TILE + 64 * C::KS + row * C::VS + 160 + c * 16) = make_uint4(c == 0 ? 0x00003F80u : 0u, 0, 0, 0);
   }
   commit(0, 0);
   SF_T(3)
@@ -160,7 +179,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
 
   const float c = p.scale * SF_LOG2E;
   f32x16 oacc[3] = {sf_zero(), sf_zero(), sf_zero()};
-  float m = -INFINITY, l = 0.f;
+  float m = -INFINITY;
   const bool active = (C::NWIN % (C::NW * 32) == 0) || q0 < C::NWIN;   // wave-uniform
   // One tile of 64 keys for this wave: NKB 32-key blocks enter the score product, the last of them feeds NSL 16-key steps of P V.
   // (A 14 x 14 window has 196 = 3 * 64 + 4 keys: its last tile is one block and one step.)
@@ -214,16 +233,13 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
     const float mn = need ? mx : m;
     const float alpha = need ? __builtin_amdgcn_exp2f((m - mn) * c) : 1.0f;
     const float mnc = mn * c;
-    float rs4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pv = SF_EXP == 2 ? fmaf(sacc[kb][r], c, -mnc) : __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -mnc));
         sacc[kb][r] = pv;
-        rs4[r & 3] += pv;
       }
-    l = l * alpha + ((rs4[0] + rs4[1]) + (rs4[2] + rs4[3]));
     m = mn;
     if (__ballot(alpha != 1.0f) != 0ull) {
 #pragma unroll
@@ -276,7 +292,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
   return;
 #endif
   // ---- epilogue: lane = query, registers = output columns sf_acc_row(r, h) + 32 j (columns >= 80 are padding)
-  l += __shfl_xor(l, 32, 64);
+  const float l = __shfl(oacc[2][8], fr, 64);   // row 80 of O^T = block 2, row 16: register 8 of the lower half-wave's lane
   const float mult = 1.f / l;
   if (p.lse && qi < C::NWIN && h == 0) p.lse[stat_row] = m * c + __builtin_amdgcn_logf(l);   // log2 domain: P = exp2(c s - lse)
   bool inside = false;

@@ -81,17 +81,13 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
   const int head = B.head, Cq = p.H * SF_D;
   const long wh = B.wh(p.nws);
 
-  // bias image of the padded keys (k, v), as the forward
+  // bias image of the padded keys (k, v), as the forward: loads first, the LDS write after the other prologue loads are in flight
   char* bimg = smem + 2 * C::TILE;
-  if (tid < 20) {
-    const int sec = 1 + tid / 10, c8 = (tid % 10) * 8;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (p.bias) {
-      const float* b = p.bias + sec * Cq + head * SF_D + c8;
-      const float4 a = *reinterpret_cast<const float4*>(b), c = *reinterpret_cast<const float4*>(b + 4);
-      v = make_uint4(sf_pack2(a.x, a.y), sf_pack2(a.z, a.w), sf_pack2(c.x, c.y), sf_pack2(c.z, c.w));
-    }
-    *reinterpret_cast<uint4*>(bimg + (sec - 1) * (2 * SF_D) + c8 * 2) = v;
+  float4 bias0 = make_float4(0.f, 0.f, 0.f, 0.f), bias1 = bias0;
+  const int bsec = 1 + tid / 10, bc8 = (tid % 10) * 8;
+  if (tid < 20 && p.bias) {
+    const float* b = p.bias + bsec * Cq + head * SF_D + bc8;
+    bias0 = *reinterpret_cast<const float4*>(b), bias1 = *reinterpret_cast<const float4*>(b + 4);
   }
   auto load_piece = [&](int sec, int t, int c8) __attribute__((always_inline)) -> uint4 {
     uint4 v = make_uint4(0, 0, 0, 0);
@@ -104,8 +100,6 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
     return v;
   };
 
-  __syncthreads();   // bias image
-
   // ---- K/V tile staging, as the forward (SfKvStager, sam_flash_dev.h)
   const SfGeo geo{B.img, B.wy, B.wx, B.G};
   SfKvStager<S> stager;
@@ -116,7 +110,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
     char* row = smem + (i >> 6) * C::TILE + (i & 63) * C::KS;
     for (int b = 160 + 4 * C::SP; b < C::KS; b += 16) *reinterpret_cast<uint4*>(row + b) = make_uint4(0, 0, 0, 0);
   }
-  fetch(0);   // in flight together with the query's own loads below
+  stager.fetch_first_global(p.qkv, p.ld, Cq, head, geo, tid);   // (tokens inside the image) in flight together with the query's own loads below
   // ---- this lane's query: operand [q | qext], dO fragments, D = dO . O, lse
   const int q0 = B.sub * (C::NW * 32) + wave * 32;
   const int qi = q0 + fr;
@@ -143,6 +137,11 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
   dsum += __shfl_xor(dsum, 32, 64);
   if (qi < C::NWIN && h == 0) p.dsum[stat] = dsum;
   const float L = p.lse[stat];
+  if (tid < 20)
+    *reinterpret_cast<uint4*>(bimg + (bsec - 1) * (2 * SF_D) + bc8 * 2) =
+        make_uint4(sf_pack2(bias0.x, bias0.y), sf_pack2(bias0.z, bias0.w), sf_pack2(bias1.x, bias1.y), sf_pack2(bias1.z, bias1.w));
+  __syncthreads();   // bias image
+  stager.fetch_first_bias(bimg, geo, tid);       // the padded tokens of the first tile
   commit(0, 0);
   __syncthreads();
 
@@ -208,10 +207,26 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
       const int e0 = 32 * j + (r & 3) + 8 * (r >> 2) - SF_D;   // + 4 h: the bias column of this register
       if (e0 >= 0 && e0 < 2 * C::SP) db[(e0 + 4 * h) * 32 + fr] = dq[j][r];
     }
-  for (int pc = tid; pc < 2 * C::JP * 10; pc += C::NT) {
-    const int which = pc / (C::JP * 10), rem = pc - which * (C::JP * 10), row = rem / 10, cc = rem - row * 10;
-    const bf16_t* src = which ? p.tbl_w : p.tbl_h;
-    *reinterpret_cast<uint4*>(timg + (which * C::JP + row) * C::TS + cc * 16) = *reinterpret_cast<const uint4*>(src + row * SF_D + cc * 8);
+  {   // (all the loads before the first LDS write: one round trip)
+    constexpr int NTP = 2 * C::JP * 10, NTI = (NTP + C::NT - 1) / C::NT;
+    uint4 tp[NTI];
+#pragma unroll
+    for (int i = 0; i < NTI; ++i) {
+      const int pc = tid + i * C::NT;
+      tp[i] = make_uint4(0, 0, 0, 0);
+      if (pc < NTP) {
+        const int which = pc / (C::JP * 10), rem = pc - which * (C::JP * 10);
+        tp[i] = *reinterpret_cast<const uint4*>((which ? p.tbl_w : p.tbl_h) + rem * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NTI; ++i) {
+      const int pc = tid + i * C::NT;
+      if (pc < NTP) {
+        const int which = pc / (C::JP * 10), rem = pc - which * (C::JP * 10), row = rem / 10, cc = rem - row * 10;
+        *reinterpret_cast<uint4*>(timg + (which * C::JP + row) * C::TS + cc * 16) = tp[i];
+      }
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -276,7 +291,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlas
     for (int i = 0; i < NE; ++i) stge[i] = make_uint4(0, 0, 0, 0);
     if (tq < C::NWIN) {
       bool inside;
-      const long grow = geo.tok_row<S>(tq, inside);
+      const long grow = B.tok_row(tq, inside);
       if (inside) {   // a padded query has no output: q does not matter and dO = 0
         const bf16_t* sq_ = p.qkv + grow * p.ld + head * SF_D + sq * 8;
         const bf16_t* sd_ = p.dout + grow * p.ldo + head * SF_D + sq * 8;

@@ -81,6 +81,10 @@ struct SfGeo {
   int img, wy, wx, G;
   template <int S>
   __device__ __forceinline__ long tok_row(int t, bool& inside) const {   // window token index -> row of the token-major matrices
+    if constexpr (S == 32) {   // global attention: the window IS the 32 x 32 grid (the launcher checks G == 32)
+      inside = true;
+      return (long)img * (S * S) + t;
+    }
     const int ty = t / S, tx = t - ty * S;
     const int gy = wy * S + ty, gx = wx * S + tx;
     inside = gy < G && gx < G;
@@ -98,30 +102,50 @@ struct SfKvStager {
   using C = SamFlashCfg<S>;
   static_assert(C::NT == 256, "row / quarter split of 256 threads");
   uint4 k[3], v[3];
+  // A key beyond the window (ragged last tile) is staged as a copy of the last one: its probability is forced to 0 by the kernels, all
+  // it has to be is finite - so there is no zero fill and no validity branch in the loop.
+  __device__ __forceinline__ long locate(const SfGeo& g, int t, int tid, bool& inside) const {
+    const int row = tid >> 2;
+    const int key = (C::NWIN % 64 == 0) ? t * 64 + row : min(t * 64 + row, C::NWIN - 1);
+    return g.tok_row<S>(key, inside);
+  }
+  __device__ __forceinline__ void load_global(const bf16_t* src, int Cq, int sq) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int off = i < 2 ? 32 * i : (min(sq + 8, 9) - sq) * 8;   // quarters 2, 3 own two pieces: their third register re-reads piece 9 (never committed)
+      k[i] = *reinterpret_cast<const uint4*>(src + off);
+      v[i] = *reinterpret_cast<const uint4*>(src + Cq + off);
+    }
+  }
+  __device__ __forceinline__ void load_bias(const char* bimg, int sq) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int c = i < 2 ? sq + 4 * i : min(sq + 8, 9);
+      k[i] = *reinterpret_cast<const uint4*>(bimg + c * 16);
+      v[i] = *reinterpret_cast<const uint4*>(bimg + 2 * SF_D + c * 16);
+    }
+  }
+  // whole tile: global loads for the tokens inside the image, the bias rows (LDS image) for the padded ones
   __device__ __forceinline__ void fetch(const bf16_t* qkv, long ld, int Cq, int head, const char* bimg, const SfGeo& g, int t, int tid) {
-    const int row = tid >> 2, sq = tid & 3, key = t * 64 + row;
+    bool inside;
+    const long tr = locate(g, t, tid, inside);
+    const int sq = tid & 3;
+    if (inside) load_global(qkv + tr * ld + Cq + head * SF_D + sq * 8, Cq, sq);
+    else load_bias(bimg, sq);
+  }
+  // the first tile in two parts: the global loads before the barrier that publishes the bias image, the bias rows after it
+  __device__ __forceinline__ void fetch_first_global(const bf16_t* qkv, long ld, int Cq, int head, const SfGeo& g, int tid) {
+    bool inside;
+    const long tr = locate(g, 0, tid, inside);
+    const int sq = tid & 3;
 #pragma unroll
     for (int i = 0; i < 3; ++i) k[i] = v[i] = make_uint4(0, 0, 0, 0);
-    if (key < C::NWIN) {
-      bool inside;
-      const long tr = g.tok_row<S>(key, inside);
-      if (inside) {
-        const bf16_t* src = qkv + tr * ld + Cq + head * SF_D + sq * 8;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-          if (i < 2 || sq < 2) {
-            k[i] = *reinterpret_cast<const uint4*>(src + 32 * i);
-            v[i] = *reinterpret_cast<const uint4*>(src + Cq + 32 * i);
-          }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-          if (i < 2 || sq < 2) {
-            k[i] = *reinterpret_cast<const uint4*>(bimg + (sq + 4 * i) * 16);
-            v[i] = *reinterpret_cast<const uint4*>(bimg + 2 * SF_D + (sq + 4 * i) * 16);
-          }
-      }
-    }
+    if (inside) load_global(qkv + tr * ld + Cq + head * SF_D + sq * 8, Cq, sq);
+  }
+  __device__ __forceinline__ void fetch_first_bias(const char* bimg, const SfGeo& g, int tid) {
+    bool inside;
+    (void)locate(g, 0, tid, inside);
+    if (!inside) load_bias(bimg, tid & 3);
   }
   __device__ __forceinline__ void commit(char* smem, int buf, int t, int tid) const {
     const int row = tid >> 2, sq = tid & 3, key = t * 64 + row;
@@ -140,7 +164,7 @@ struct SfKvStager {
       const int c = sq + 4 * i;
       uint4 o = make_uint4(0, 0, 0, 0);
       const int want = (c < C::SP / 8 ? kh : kw + C::SP) - 8 * c;   // position of the 1 inside this piece, if 0..7
-      if (key < C::NWIN && want >= 0 && want < 8) {
+      if (want >= 0 && want < 8) {   // (a key beyond the window gets some row's columns: it is masked anyway)
         const uint32_t val = (want & 1) ? 0x3F800000u : 0x00003F80u;
         const int wi = want >> 1;
         o = make_uint4(wi == 0 ? val : 0u, wi == 1 ? val : 0u, wi == 2 ? val : 0u, wi == 3 ? val : 0u);
