@@ -148,7 +148,7 @@ def eval_leg(device, timer, iters=5):
                 r["roofline"] = {"bound": "mfma", "achieved": round(blk["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                  "frac": round(blk["tflops"] / PEAK_BF16_TFLOPS, 4),
                                  "kernel": "backbone GEMM + flash-attention launches (sampled HIP events)" if fkey == "dinov2_ms" else
-                                           "backbone GEMM launches incl. the batched score / PV GEMMs of the SAM attention (sampled HIP events)",
+                                           "backbone GEMM + SAM flash-attention launches (sampled HIP events; attention FLOPs = q.k and p.v only)",
                                  "kernel_ms_per_img_est": round(blk["ms"] * timer.every / iters, 2),
                                  "all_gemm_tflops": None if allg is None else round(allg["tflops"], 1)}
         res[name] = r

@@ -567,8 +567,14 @@ def sam_attn_flash_fwd(qkv, bias, tbl_h, tbl_w, out, nimg, G, S, H, d, scale):
     """One-launch SAM attention forward (inference): qkv [M, 3*H*d] bf16 -> out [M, H*d] bf16."""
     lib = L.load()
     assert qkv.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and tbl_h.dtype == torch.bfloat16 and tbl_h.is_contiguous()
+    fin = None
+    if PROFILE is not None:   # algorithmic FLOPs: q.k and p.v over the S*S keys of every window token (bias products not counted)
+        nws = 1 if S == 32 else (G + S - 1) // S
+        fin = PROFILE("attn_fwd", 4.0 * nimg * nws * nws * H * (S * S) ** 2 * d, REGION[-1])
     L.check(lib.vfm_sam_attn_flash_fwd(L.ptr(qkv), _ld(qkv), L.ptr(bias), L.ptr(tbl_h), L.ptr(tbl_w), L.ptr(out), _ld(out), nimg, G, S, H, d,
                                        float(scale), L.stream()), "vfm_sam_attn_flash_fwd")
+    if fin is not None:
+        fin()
     return out
 
 
