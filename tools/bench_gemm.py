@@ -33,6 +33,17 @@ if os.environ.get("SHAPES") == "small":
     ]
 
 
+if os.environ.get("SHAPES") == "sam":   # SAM-H train step at bs 2 (4 images of 32 x 32 tokens), D = 1280
+    SHAPES = [
+        (4096, 1280, 1280, torch.float32, "sam proj"),
+        (4096, 1280, 5120, torch.float32, "sam fc2"),
+        (4096, 1280, 3840, torch.bfloat16, "sam qkv dgrad"),
+        (4096, 1280, 5120, torch.bfloat16, "sam fc1 dgrad"),
+        (4096, 5120, 1280, torch.bfloat16, "sam fc1"),
+        (4096, 3840, 1344, torch.bfloat16, "sam qkv+lora"),
+    ]
+
+
 def timeit(fn, iters=20):
     for _ in range(3):
         fn()

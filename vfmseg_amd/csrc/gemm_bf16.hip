@@ -482,6 +482,8 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
                  // rounds of the 512 resident slots
     else if (!(g_use_pp & 64) && d->N >= 4096 && t256 >= 700 && t256 < 768 && d->K >= 1024 && span33 && nbatch == 1)
       cfg = 33;  // SAM-H fc1 over nine windows [9216 x 5120 x 1280]: 189.4 -> 160.5 us
+    else if (!(g_use_pp & 64) && d->N >= 2048 && t256 >= 224 && t256 <= 256 && d->K >= 1024 && span33 && nbatch == 1 && !tail)
+      cfg = 33;  // one 256x256 tile on (almost) every CU - SAM-H qkv + LoRA in the train step [4096 x 3840 x 1344]: 866 -> 1016 TFLOP/s
     else if (t128 <= 160 && d->K >= 512 && (long)cdiv(d->M, 64) * cdiv(d->N, 64) <= 544)
       cfg = 10;  // few tiles, long K (LoRA T GEMM 4096x64x1024, decoder projections): 64x64 tiles with the 4-stage ring
     else if (t128 <= 160) cfg = 18;                                  // small problems: 64x128 tiles fill more CUs
