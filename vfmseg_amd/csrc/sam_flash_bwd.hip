@@ -155,10 +155,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
 #pragma unroll 1
   for (int t = 0; t < C::NTILES; ++t) {
     const int buf = t & 1;
-    if (t + 1 < C::NTILES) {   // (staged before the products, not around them: the staging registers are dead during the tile)
-      fetch(t + 1);
-      commit(buf ^ 1, t + 1);   // stage buf^1 was last read during tile t-1: every wave passed that barrier
-    }
+    if (t + 1 < C::NTILES) fetch(t + 1);   // global loads of the next tile fly during this tile's products
     const char* kt = smem + buf * C::TILE;
     const char* vt = kt + 64 * C::KS;
     if (active) {
@@ -176,13 +173,16 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
           const bf16x8 a = *reinterpret_cast<const bf16x8*>(vt + (kb * 32 + fr) * C::VS + (2 * kk + h) * 16);
           dp = SF_MFMA(a, da[kk], dp);
         }
-        const int key0 = t * 64 + kb * 32;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float pv = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -L));
-          if ((C::NWIN % 64 != 0) && key0 + sf_acc_row(r, h) >= C::NWIN) pv = 0.f;   // keys beyond the window do not exist
-          sacc[r] = pv * (dp[r] - dsum);
+        for (int r = 0; r < 16; ++r) sacc[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -L));
+        if ((C::NWIN % 64 != 0) && t == C::NTILES - 1) {   // ragged last tile: keys beyond the window do not exist
+          const int key0 = t * 64 + kb * 32;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (key0 + sf_acc_row(r, h) >= C::NWIN) sacc[r] = 0.f;
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] *= dp[r] - dsum;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           bf16x8 pb;
@@ -193,6 +193,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
         }
       }
     }
+    if (t + 1 < C::NTILES) commit(buf ^ 1, t + 1);   // stage buf^1 was last read during tile t-1: every wave passed that barrier
     __syncthreads();
   }
 
@@ -397,10 +398,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlas
 #pragma unroll 1
   for (int t = 0; t < C::NTILES; ++t) {
     const int buf = t & 1;
-    if (t + 1 < C::NTILES) {
-      fetch(t + 1);
-      commit(buf ^ 1);
-    }
+    if (t + 1 < C::NTILES) fetch(t + 1);
     const char* qt = smem + buf * CB::TILE;
     const char* dt = qt + 64 * C::KS;
     const char* st = dt + 64 * C::VS;
@@ -444,6 +442,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlas
         }
       }
     }
+    if (t + 1 < C::NTILES) commit(buf ^ 1);
     __syncthreads();
   }
 
