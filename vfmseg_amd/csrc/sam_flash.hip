@@ -15,6 +15,11 @@
 //   K / V tiles of 64 keys are staged global -> registers -> LDS (rows are 160 B: no whole-line LDS-DMA shape), double buffered,
 //   one barrier per tile.  Window tokens outside the image are real keys whose k / v equal the projection bias (window_partition
 //   pads the NORMALISED input with zeros); queries outside the image are computed and dropped (window_unpartition).
+// * What the profile asked for (profiles/r02_pmc_sam_flash.txt: the SIMD issue port, not the matrix pipe, is the busy resource): blocks of
+//   4 waves whose prologue images alias the K/V ring (two blocks per CU); one key row per staging thread (SfKvStager); the softmax
+//   denominator as row 80 of O^T through a ones column of V; output rows through LDS as 16-byte pieces; all prologue loads in one round
+//   trip.  SF_EXP (compile-time) keeps the ablations and phase clocks those numbers came from (tools/scratch/_sam_flash_exp.py).
+// * Training (vfm_sam_attn_flash_fwd_train) also writes lse (log2 domain) and the bias columns of the query operand for sam_flash_bwd.hip.
 #include "sam_flash_dev.h"
 
 template <int S>

@@ -89,16 +89,6 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
     const float* b = p.bias + bsec * Cq + head * SF_D + bc8;
     bias0 = *reinterpret_cast<const float4*>(b), bias1 = *reinterpret_cast<const float4*>(b + 4);
   }
-  auto load_piece = [&](int sec, int t, int c8) __attribute__((always_inline)) -> uint4 {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (t < C::NWIN) {
-      bool inside;
-      const long row = B.tok_row(t, inside);
-      if (inside) v = *reinterpret_cast<const uint4*>(p.qkv + row * p.ld + sec * Cq + head * SF_D + c8);
-      else if (sec > 0) v = *reinterpret_cast<const uint4*>(bimg + (sec - 1) * (2 * SF_D) + c8 * 2);
-    }
-    return v;
-  };
 
   // ---- K/V tile staging, as the forward (SfKvStager, sam_flash_dev.h)
   const SfGeo geo{B.img, B.wy, B.wx, B.G};
