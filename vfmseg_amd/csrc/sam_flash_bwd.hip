@@ -72,6 +72,7 @@ __device__ __forceinline__ float sf_dot8(uint4 a, uint4 b) {
 template <int S>
 __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlashBwdP p) {
   using C = SamFlashCfg<S>;
+  using CB = SamFlashBwdCfg<S>;
   constexpr int NJ = (SF_D + 2 * C::SP + 31) / 32;   // 32-row blocks of dQext^T: 4 (112 rows) / 5 (144 rows)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -82,7 +83,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
   const long wh = B.wh(p.nws);
 
   // bias image of the padded keys (k, v), as the forward: loads first, the LDS write after the other prologue loads are in flight
-  char* bimg = smem + 2 * C::TILE;
+  char* bimg = smem + 2 * CB::TILE;
   float4 bias0 = make_float4(0.f, 0.f, 0.f, 0.f), bias1 = bias0;
   const int bsec = 1 + tid / 10, bc8 = (tid % 10) * 8;
   if (tid < 20 && p.bias) {
@@ -92,13 +93,14 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
 
   // ---- K/V tile staging, as the forward (SfKvStager, sam_flash_dev.h)
   const SfGeo geo{B.img, B.wy, B.wx, B.G};
-  SfKvStager<S> stager;
+  SfKvStager<S, CB::KS, CB::TILE, true> stager;
   auto fetch = [&](int t) __attribute__((always_inline)) { stager.fetch(p.qkv, p.ld, Cq, head, bimg, geo, t, tid); };
   auto commit = [&](int buf, int t) __attribute__((always_inline)) { stager.commit(smem, buf, t, tid); };
-  // the pad bytes of the K rows (beyond 160 + 4 SP) are read by the transposing loads of the last row block: keep them finite
-  for (int i = tid; i < 2 * 64; i += C::NT) {
-    char* row = smem + (i >> 6) * C::TILE + (i & 63) * C::KS;
-    for (int b = 160 + 4 * C::SP; b < C::KS; b += 16) *reinterpret_cast<uint4*>(row + b) = make_uint4(0, 0, 0, 0);
+  // the last four-chunk group of the K rows holds two data and two pad chunks (at swizzled places): the transposing loads of the last
+  // row block read them all - zero the group once, the stager then rewrites the data chunks only
+  for (int i = tid; i < 2 * 64 * 4; i += C::NT) {
+    const int buf = i >> 8, row = (i >> 2) & 63, cc = i & 3;
+    *reinterpret_cast<uint4*>(smem + buf * CB::TILE + row * CB::KS + (CB::PADK + cc) * 16) = make_uint4(0, 0, 0, 0);
   }
   stager.fetch_first_global(p.qkv, p.ld, Cq, head, geo, tid);   // (tokens inside the image) in flight together with the query's own loads below
   // ---- this lane's query: operand [q | qext], dO fragments, D = dO . O, lse
@@ -136,6 +138,10 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
   __syncthreads();
 
   const float c = p.scale * SF_LOG2E;
+  const SfSwzRow swz(fr, h);
+  const SfTrLane trk(lane, CB::KS, true);
+  const int rk_e = fr * CB::KS + swz.even, rk_o = fr * CB::KS + swz.odd;   // by-row fragments: lane constants for even / odd k-steps
+  const int rv_e = fr * CB::VS + swz.even, rv_o = fr * CB::VS + swz.odd;
   f32x16 dq[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) dq[j] = sf_zero();
@@ -145,9 +151,15 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
 #pragma unroll 1
   for (int t = 0; t < C::NTILES; ++t) {
     const int buf = t & 1;
-    if (t + 1 < C::NTILES) fetch(t + 1);   // global loads of the next tile fly during this tile's products
-    const char* kt = smem + buf * C::TILE;
-    const char* vt = kt + 64 * C::KS;
+    // the next tile: its global loads fly during this tile's products where the staging registers fit beside the accumulators (S = 14);
+    // otherwise it is staged whole before the products (the other block of the CU covers the wait)
+    constexpr bool OVERLAP = S == 14;
+    if (t + 1 < C::NTILES) {
+      fetch(t + 1);
+      if (!OVERLAP) commit(buf ^ 1, t + 1);   // stage buf^1 was last read during tile t-1: every wave passed that barrier
+    }
+    const char* kt = smem + buf * CB::TILE;
+    const char* vt = kt + 64 * CB::KS;
     if (active) {
       const int nkb = t == C::NTILES - 1 ? NKB_LAST : 2;
 #pragma unroll 1
@@ -155,12 +167,12 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
         f32x16 sacc = sf_zero(), dp = sf_zero();
 #pragma unroll
         for (int kk = 0; kk < C::KSTEPS; ++kk) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(kt + (kb * 32 + fr) * C::KS + (2 * kk + h) * 16);
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(kt + kb * 32 * CB::KS + ((kk & 1) ? rk_o : rk_e) + 32 * kk);
           sacc = SF_MFMA(a, qa[kk], sacc);
         }
 #pragma unroll
         for (int kk = 0; kk < 5; ++kk) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(vt + (kb * 32 + fr) * C::VS + (2 * kk + h) * 16);
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(vt + kb * 32 * CB::VS + ((kk & 1) ? rv_o : rv_e) + 32 * kk);
           dp = SF_MFMA(a, da[kk], dp);
         }
 #pragma unroll
@@ -179,18 +191,17 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
 #pragma unroll
           for (int e = 0; e < 8; ++e) pb[e] = (__bf16)sacc[8 * s + e];
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) dq[j] = SF_MFMA(sf_tr_frag(kt, C::KS, kb * 32 + 16 * s, j, lane), pb, dq[j]);
+          for (int j = 0; j < NJ; ++j) dq[j] = SF_MFMA(trk.frag(kt + (kb * 32 + 16 * s) * CB::KS, j), pb, dq[j]);
         }
       }
     }
-    if (t + 1 < C::NTILES) commit(buf ^ 1, t + 1);   // stage buf^1 was last read during tile t-1: every wave passed that barrier
+    if (OVERLAP && t + 1 < C::NTILES) commit(buf ^ 1, t + 1);
     __syncthreads();
   }
 
   // ---- epilogue: rows 80.. of dQext^T = dBh^T / dBw^T -> wave-private image [2][SP][32 queries] fp32; table images -> LDS
   float* db = reinterpret_cast<float*>(smem) + wave * (2 * C::SP * 32);
-  char* timg = smem + 2 * C::TILE - C::TIMG;
-  static_assert(C::NW * 2 * C::SP * 32 * 4 + C::TIMG <= 2 * C::TILE, "epilogue images overlap");
+  char* timg = smem + 2 * CB::TILE - C::TIMG;
 #pragma unroll
   for (int j = 2; j < NJ; ++j)
 #pragma unroll
@@ -243,23 +254,16 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
   }
   // output image: behind the dB images (S = 14) or over this wave's own dB image (S = 32, read above); never over the table images
   constexpr int IMG0 = S == 14 ? C::NW * 2 * C::SP * 32 * 4 : 0, IMGSZ = S == 14 ? SF_OIMG : 2 * C::SP * 32 * 4;
-  static_assert(IMGSZ >= SF_OIMG && IMG0 + C::NW * IMGSZ <= 2 * C::TILE - C::TIMG, "output images overlap the table images");
+  static_assert(IMGSZ >= SF_OIMG && IMG0 + C::NW * IMGSZ <= 2 * CB::TILE - C::TIMG, "output images overlap the table images");
   sf_store_rows(smem + IMG0 + wave * IMGSZ, reinterpret_cast<const f32x16(&)[3]>(dq[0]), 1.0f, (qi < C::NWIN && q_inside) ? (int)q_row : -1,
                 p.dqkv + head * SF_D, p.ldg, lane);
 }
 
 // ============================================================ dk, dv
 template <int S>
-struct SamFlashDkvCfg {
-  using C = SamFlashCfg<S>;
-  static constexpr int TILE = 64 * (C::KS + C::VS) + 512;   // [q | qext] rows, dO rows, lse[64], D[64]
-  static constexpr int SMEM = 2 * TILE;
-};
-
-template <int S>
 __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlashBwdP p) {
   using C = SamFlashCfg<S>;
-  using CB = SamFlashDkvCfg<S>;
+  using CB = SamFlashBwdCfg<S>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -312,26 +316,28 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlas
     }
   };
   auto commit = [&](int buf) __attribute__((always_inline)) {
-    char* qt = smem + buf * CB::TILE + srow * C::KS + sq * 16;
-    char* dt = smem + buf * CB::TILE + 64 * C::KS + srow * C::VS + sq * 16;
-    char* st = smem + buf * CB::TILE + 64 * (C::KS + C::VS);
+    const int x = (srow >> 2) & 3;   // chunk swizzle (SamFlashBwdCfg)
+    char* qt = smem + buf * CB::TILE_DKV + srow * CB::KS;
+    char* dt = smem + buf * CB::TILE_DKV + 64 * CB::KS + srow * CB::VS;
+    char* st = smem + buf * CB::TILE_DKV + 64 * (CB::KS + CB::VS);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       if (i < 2 || sq < 2) {
-        *reinterpret_cast<uint4*>(qt + 64 * i) = stq[i];
-        *reinterpret_cast<uint4*>(dt + 64 * i) = std_[i];
+        *reinterpret_cast<uint4*>(qt + ((sq + 4 * i) ^ x) * 16) = stq[i];
+        *reinterpret_cast<uint4*>(dt + ((sq + 4 * i) ^ x) * 16) = std_[i];
       }
 #pragma unroll
-    for (int i = 0; i < NE; ++i) *reinterpret_cast<uint4*>(qt + 160 + 64 * i) = stge[i];
+    for (int i = 0; i < NE; ++i) *reinterpret_cast<uint4*>(qt + ((10 + sq + 4 * i) ^ x) * 16) = stge[i];
     if (tid < 32) *reinterpret_cast<uint4*>(st + tid * 16) = stgs;
   };
-  // pad bytes that the transposing reads of column block 2 touch (q rows beyond 160 + 4 SP, dO rows beyond 160): keep them finite
-  for (int i = tid; i < 2 * 64; i += C::NT) {
-    char* qrow = smem + (i >> 6) * CB::TILE + (i & 63) * C::KS;
-    char* drow = smem + (i >> 6) * CB::TILE + 64 * C::KS + (i & 63) * C::VS;
-    for (int b = 160 + 4 * C::SP; b < C::KS; b += 16) *reinterpret_cast<uint4*>(qrow + b) = make_uint4(0, 0, 0, 0);
-    for (int b = 160; b < C::VS; b += 16) *reinterpret_cast<uint4*>(drow + b) = make_uint4(0, 0, 0, 0);
+  // the four-chunk groups that hold data AND pad chunks (at swizzled places) are read whole by the transposing loads: zero them once
+  // ([q | qext] rows: group PADK; dO rows: chunks 8..11), the stager then rewrites the data chunks only
+  for (int i = tid; i < 2 * 64 * 4; i += C::NT) {
+    const int buf = i >> 8, row = (i >> 2) & 63, cc = i & 3;
+    *reinterpret_cast<uint4*>(smem + buf * CB::TILE_DKV + row * CB::KS + (CB::PADK + cc) * 16) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(smem + buf * CB::TILE_DKV + 64 * CB::KS + row * CB::VS + (8 + cc) * 16) = make_uint4(0, 0, 0, 0);
   }
+  __syncthreads();   // (these zeros and the first commit touch the same chunks from different threads)
   fetch(0);   // in flight together with the key's own loads below
   // ---- this lane's key: operands [k | onehot(kh) | onehot(kw)] and v
   const int k0 = B.sub * (C::NW * 32) + wave * 32;
@@ -381,6 +387,10 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlas
   __syncthreads();
 
   const float c = p.scale * SF_LOG2E;
+  const SfSwzRow swz(fr, h);
+  const SfTrLane trq(lane, CB::KS, true), trd(lane, CB::VS, true);
+  const int rq_e = fr * CB::KS + swz.even, rq_o = fr * CB::KS + swz.odd;
+  const int rd_e = fr * CB::VS + swz.even, rd_o = fr * CB::VS + swz.odd;
   f32x16 dk[3] = {sf_zero(), sf_zero(), sf_zero()}, dv[3] = {sf_zero(), sf_zero(), sf_zero()};
   const bool active = (C::NWIN % (C::NW * 32) == 0) || k0 < C::NWIN;
   constexpr int LASTQ = C::NWIN - 64 * (C::NTILES - 1);
@@ -388,10 +398,13 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlas
 #pragma unroll 1
   for (int t = 0; t < C::NTILES; ++t) {
     const int buf = t & 1;
-    if (t + 1 < C::NTILES) fetch(t + 1);
-    const char* qt = smem + buf * CB::TILE;
-    const char* dt = qt + 64 * C::KS;
-    const char* st = dt + 64 * C::VS;
+    if (t + 1 < C::NTILES) {   // staged whole before the products: dk + dv + the key operands leave no room for live staging registers
+      fetch(t + 1);
+      commit(buf ^ 1);
+    }
+    const char* qt = smem + buf * CB::TILE_DKV;
+    const char* dt = qt + 64 * CB::KS;
+    const char* st = dt + 64 * CB::VS;
     if (active) {
       const int nqb = t == C::NTILES - 1 ? NQB_LAST : 2;
 #pragma unroll 1
@@ -399,12 +412,12 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlas
         f32x16 sacc = sf_zero(), dp = sf_zero();   // rows = queries of this 32-block, lanes = keys
 #pragma unroll
         for (int kk = 0; kk < C::KSTEPS; ++kk) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(qt + (qb * 32 + fr) * C::KS + (2 * kk + h) * 16);
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(qt + qb * 32 * CB::KS + ((kk & 1) ? rq_o : rq_e) + 32 * kk);
           sacc = SF_MFMA(a, kk < 5 ? kq[kk] : onehot((kk - 5) / (C::SP / 16), (kk - 5) % (C::SP / 16)), sacc);
         }
 #pragma unroll
         for (int kk = 0; kk < 5; ++kk) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(dt + (qb * 32 + fr) * C::VS + (2 * kk + h) * 16);
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(dt + qb * 32 * CB::VS + ((kk & 1) ? rd_o : rd_e) + 32 * kk);
           dp = SF_MFMA(a, vb[kk], dp);
         }
 #pragma unroll
@@ -426,13 +439,12 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlas
           for (int e = 0; e < 8; ++e) pp_[e] = (__bf16)sacc[8 * s + e], ps_[e] = (__bf16)dp[8 * s + e];
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
-            dv[j] = SF_MFMA(sf_tr_frag(dt, C::VS, qb * 32 + 16 * s, j, lane), pp_, dv[j]);
-            dk[j] = SF_MFMA(sf_tr_frag(qt, C::KS, qb * 32 + 16 * s, j, lane), ps_, dk[j]);
+            dv[j] = SF_MFMA(trd.frag(dt + (qb * 32 + 16 * s) * CB::VS, j), pp_, dv[j]);
+            dk[j] = SF_MFMA(trq.frag(qt + (qb * 32 + 16 * s) * CB::KS, j), ps_, dk[j]);
           }
         }
       }
     }
-    if (t + 1 < C::NTILES) commit(buf ^ 1);
     __syncthreads();
   }
 
@@ -444,16 +456,16 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlas
 template <int S>
 static void launch_sam_flash_bwd(const SamFlashBwdP& p, hipStream_t s) {
   using C = SamFlashCfg<S>;
-  using CB = SamFlashDkvCfg<S>;
+  using CB = SamFlashBwdCfg<S>;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_sam_flash_dq<S>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-    (void)hipFuncSetAttribute((const void*)k_sam_flash_dkv<S>, hipFuncAttributeMaxDynamicSharedMemorySize, CB::SMEM);
+    (void)hipFuncSetAttribute((const void*)k_sam_flash_dq<S>, hipFuncAttributeMaxDynamicSharedMemorySize, CB::SMEM_DQ);
+    (void)hipFuncSetAttribute((const void*)k_sam_flash_dkv<S>, hipFuncAttributeMaxDynamicSharedMemorySize, CB::SMEM_DKV);
     attr = true;
   }
   const long blocks = (long)p.nimg * p.nws * p.nws * p.H * C::QBLK;
-  hipLaunchKernelGGL(k_sam_flash_dq<S>, dim3((unsigned)blocks), dim3(C::NT), C::SMEM, s, p);    // writes D, which dkv reads
-  hipLaunchKernelGGL(k_sam_flash_dkv<S>, dim3((unsigned)blocks), dim3(C::NT), CB::SMEM, s, p);
+  hipLaunchKernelGGL(k_sam_flash_dq<S>, dim3((unsigned)blocks), dim3(C::NT), CB::SMEM_DQ, s, p);    // writes D, which dkv reads
+  hipLaunchKernelGGL(k_sam_flash_dkv<S>, dim3((unsigned)blocks), dim3(C::NT), CB::SMEM_DKV, s, p);
 }
 
 extern "C" long vfm_sam_attn_flash_stat_rows(int nimg, int G, int S, int H) {

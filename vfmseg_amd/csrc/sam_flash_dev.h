@@ -62,19 +62,74 @@ __device__ __forceinline__ uint32_t sf_pack2(float a, float b) {
 
 
 // A operand (rows = stored columns 32 j .., k = stored rows of 16-row step `r16`) by transposing LDS reads, as the forward's P V product
+// SWZ: the tile stores chunk c (16 bytes) of row r at chunk c ^ ((r >> 2) & 3) (backward tiles, see SamFlashBwdCfg); r16 is a multiple
+// of 16, so the four rows of a read share one XOR value: hh for the low half, hh + 2 for the rows eight further on.
+template <bool SWZ = false>
 __device__ __forceinline__ bf16x8 sf_tr_frag(const char* base, int stride, int r16, int j, int lane) {
   const int g = lane >> 4, i = lane & 15, q4 = i >> 2, pp = i & 3, hh = g >> 1;
   const int chunk = 4 * j + 2 * (g & 1) + (pp >> 1);
   const int r0 = r16 + 4 * hh + q4;
+  const int c_lo = SWZ ? chunk ^ hh : chunk, c_hi = SWZ ? chunk ^ (hh + 2) : chunk;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4*)(base + r0 * stride + chunk * 16 + ((pp & 1) << 3)));
+      (__attribute__((address_space(3))) s16x4*)(base + r0 * stride + c_lo * 16 + ((pp & 1) << 3)));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4*)(base + (r0 + 8) * stride + chunk * 16 + ((pp & 1) << 3)));
+      (__attribute__((address_space(3))) s16x4*)(base + (r0 + 8) * stride + c_hi * 16 + ((pp & 1) << 3)));
   union { struct { s16x4 a, b; } st; bf16x8 v; } u;
   u.st.a = lo;
   u.st.b = hi;
   return u.v;
 }
+
+// ---- LDS layout of the BACKWARD tiles.  There every tile is read BOTH by rows (ds_read_b128: 16 rows per LDS pass, wants the rows'
+// 16-byte chunks in 16 different bank groups) and transposed (ds_read_b64_tr_b16: 4 rows x 64 bytes per pass, wants the rows' 64-byte
+// windows in different quarters of the 64 banks).  No linear pitch serves both (the forward's 240 / 304-byte K rows conflict 4-way when
+// read transposed, the 192-byte V rows 4-way when read by rows: 50 % LDS bank-conflict cycles, profiles/r02_pmc_sam_flash.txt), so the
+// backward uses pitches of 16 or 48 dwords mod 64 (transposed reads conflict-free) and stores chunk c of row r at c ^ ((r >> 2) & 3)
+// (rows r, r + 4, r + 8, r + 12 - which share a bank group at these pitches - then differ in the chunk's low bits).
+template <int S>
+struct SamFlashBwdCfg {
+  using C = SamFlashCfg<S>;
+  static constexpr int KS = 320, VS = 192;                 // 80 / 48 dwords
+  static constexpr int NCK = (SF_D + 2 * C::SP) / 8;        // data chunks of a [k | onehot] / [q | qext] row: 14 / 18
+  static constexpr int PADK = NCK / 4 * 4;                  // their last four-chunk group also holds two pad chunks: kept zero
+  static constexpr int TILE = 64 * (KS + VS);
+  static constexpr int SMEM_DQ = 2 * TILE + 4 * SF_D;       // + the bias image
+  static constexpr int TILE_DKV = TILE + 512;               // + lse[64], D[64]
+  static constexpr int SMEM_DKV = 2 * TILE_DKV;
+  static_assert(PADK + 4 <= KS / 16 && C::NW * 2 * C::SP * 32 * 4 + C::TIMG <= 2 * TILE, "row pitch / epilogue images");
+};
+// by-row fragment of a swizzled tile: chunk 2 kk + h of row (.. + fr) sits at (2 kk + h) ^ x, x = (fr >> 2) & 3; with b0 = x & 1, b1 = x >> 1
+// that is byte 32 (kk ^ b1) + 16 (h ^ b0): two lane constants (for even and for odd kk) and an immediate
+struct SfSwzRow {
+  int even, odd;   // byte offsets inside the row for k-step 0 / relative to 32 kk
+  __device__ __forceinline__ SfSwzRow(int fr, int h) {
+    const int x = (fr >> 2) & 3, b0 = x & 1, b1 = x >> 1;
+    even = 16 * (h ^ b0) + 32 * b1;
+    odd = 16 * (h ^ b0) - 32 * b1;
+  }
+  __device__ __forceinline__ int at(int kk) const { return ((kk & 1) ? odd : even) + 32 * kk; }
+};
+
+// lane constants of the transposing fragment reads (sf_tr_frag's address arithmetic, done once per kernel: these kernels are bound by
+// VALU issue, and the per-call form cost ~8 VALU instructions per fragment): fragment (16-row step at byte `step`, column block j) =
+// the two reads at step + 64 j + lo / + hi
+struct SfTrLane {
+  int lo, hi;
+  __device__ __forceinline__ SfTrLane(int lane, int stride, bool swz) {
+    const int g = lane >> 4, i = lane & 15, q4 = i >> 2, pp = i & 3, hh = g >> 1;
+    const int cl = 2 * (g & 1) + (pp >> 1);
+    lo = (4 * hh + q4) * stride + ((swz ? cl ^ hh : cl) * 16) + ((pp & 1) << 3);
+    hi = (4 * hh + q4 + 8) * stride + ((swz ? cl ^ (hh + 2) : cl) * 16) + ((pp & 1) << 3);
+  }
+  __device__ __forceinline__ bf16x8 frag(const char* step, int j) const {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(step + lo + 64 * j));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(step + hi + 64 * j));
+    union { struct { s16x4 a, b; } st; bf16x8 v; } u;
+    u.st.a = a;
+    u.st.b = b;
+    return u.v;
+  }
+};
 
 // ---- window geometry and the K/V tile stager shared by the forward and the dq kernel
 struct SfGeo {
@@ -97,7 +152,7 @@ struct SfGeo {
 // of ITS key row in k and in v: one token-row computation and one address per tile and thread, the pieces at immediate offsets
 // (a piece-major split costs ~30 VALU instructions of index arithmetic per piece, which made the staging ~60 % of the loop's VALU work).
 // A token outside the image has k / v = the projection bias, read from the block's packed image in LDS (bimg: [2][80] bf16).
-template <int S>
+template <int S, int KSTR = SamFlashCfg<S>::KS, int TILEB = SamFlashCfg<S>::TILE, bool SWZ = false>
 struct SfKvStager {
   using C = SamFlashCfg<S>;
   static_assert(C::NT == 256, "row / quarter split of 256 threads");
@@ -149,13 +204,14 @@ struct SfKvStager {
   }
   __device__ __forceinline__ void commit(char* smem, int buf, int t, int tid) const {
     const int row = tid >> 2, sq = tid & 3, key = t * 64 + row;
-    char* kt = smem + buf * C::TILE + row * C::KS + sq * 16;
-    char* vt = smem + buf * C::TILE + 64 * C::KS + row * C::VS + sq * 16;
+    const int x = SWZ ? (row >> 2) & 3 : 0;   // chunk swizzle of the backward tiles (SamFlashBwdCfg)
+    char* kt = smem + buf * TILEB + row * KSTR;
+    char* vt = smem + buf * TILEB + 64 * KSTR + row * C::VS;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       if (i < 2 || sq < 2) {
-        *reinterpret_cast<uint4*>(kt + 64 * i) = k[i];
-        *reinterpret_cast<uint4*>(vt + 64 * i) = v[i];
+        *reinterpret_cast<uint4*>(kt + ((sq + 4 * i) ^ x) * 16) = k[i];
+        *reinterpret_cast<uint4*>(vt + ((sq + 4 * i) ^ x) * 16) = v[i];
       }
     // the one-hot pieces (2 SP / 8 per row: one or two per thread) come from the key index alone
     const int kh = key / S, kw = key - kh * S;
@@ -169,7 +225,7 @@ struct SfKvStager {
         const int wi = want >> 1;
         o = make_uint4(wi == 0 ? val : 0u, wi == 1 ? val : 0u, wi == 2 ? val : 0u, wi == 3 ? val : 0u);
       }
-      *reinterpret_cast<uint4*>(kt - sq * 16 + 160 + c * 16) = o;
+      *reinterpret_cast<uint4*>(kt + ((10 + c) ^ x) * 16) = o;
     }
   }
 };
