@@ -183,6 +183,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
   SF_T(4)
 
   const float c = p.scale * SF_LOG2E;
+  const SfTrLane trv(lane, C::VS, false);
   f32x16 oacc[3] = {sf_zero(), sf_zero(), sf_zero()};
   float m = -INFINITY;
   const bool active = (C::NWIN % (C::NW * 32) == 0) || q0 < C::NWIN;   // wave-uniform
@@ -213,7 +214,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
     SF_T(5)
     // the V^T fragments of the first P V step do not depend on the softmax: read them now
     constexpr int NST = (SF_EXP == 3 ? 0 : (NKB - 1) * 2 + NSL);
-    auto vfrag = [&](int n, int j) __attribute__((always_inline)) -> bf16x8 { return sf_tr_frag(vt, C::VS, (n >> 1) * 32 + 16 * (n & 1), j, lane); };
+    auto vfrag = [&](int n, int j) __attribute__((always_inline)) -> bf16x8 { return trv.frag(vt + 16 * n * C::VS, j); };
     bf16x8 vf[2][3];
     if (NST > 0) {
 #pragma unroll
