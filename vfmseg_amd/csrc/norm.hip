@@ -209,6 +209,67 @@ __global__ void k_ln_fwd_v2(const float* __restrict__ x, long ld_x, const float*
   }
 }
 
+// the same rows when their PITCH is a multiple of four elements (EVA02 keeps the 2730-wide SwiGLU hidden in a 2752-wide buffer): 16-byte
+// pieces, the last piece of a row partly valid (read as a whole - the pitch covers it -, used and written element by element).
+template <typename TO, int MAXP4>
+__global__ void k_ln_fwd_v4t(const float* __restrict__ x, long ld_x, const float* __restrict__ w, const float* __restrict__ b, float eps,
+                             TO* __restrict__ y, long ld_y, float* __restrict__ stats, long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ld_x;
+  float v[MAXP4][4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    const float4 t = c < C ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[i][0] = t.x, v[i][1] = t.y, v[i][2] = t.z, v[i][3] = t.w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < C) s += v[i][e];
+  }
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c + e < C) q += (v[i][e] - mean) * (v[i][e] - mean);
+  }
+  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+  if (stats && lane == 0) {
+    stats[row * 2] = mean;
+    stats[row * 2 + 1] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXP4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) {
+      if (c + 4 <= C) {
+        const float4 ww = *reinterpret_cast<const float4*>(w + c), bv = *reinterpret_cast<const float4*>(b + c);
+        const float o0 = (v[i][0] - mean) * rstd * ww.x + bv.x, o1 = (v[i][1] - mean) * rstd * ww.y + bv.y;
+        const float o2 = (v[i][2] - mean) * rstd * ww.z + bv.z, o3 = (v[i][3] - mean) * rstd * ww.w + bv.w;
+        if constexpr (sizeof(TO) == 2) {
+          const ushort4 pk = {f32_to_bf16(o0), f32_to_bf16(o1), f32_to_bf16(o2), f32_to_bf16(o3)};
+          *reinterpret_cast<ushort4*>(y + row * ld_y + c) = pk;
+        } else {
+          *reinterpret_cast<float4*>(y + row * ld_y + c) = make_float4(o0, o1, o2, o3);
+        }
+      } else {   // the partly valid last piece: element by element, nothing is written past column C
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < C) {
+            const float o = (v[i][e] - mean) * rstd * w[c + e] + b[c + e];
+            if constexpr (sizeof(TO) == 2) y[row * ld_y + c + e] = f32_to_bf16(o);
+            else y[row * ld_y + c + e] = o;
+          }
+      }
+    }
+  }
+}
+
 extern "C" int vfm_layernorm_fwd(const float* x, long ld_x, const float* w, const float* b, float eps, void* y, int y_dt,
                                  long ld_y, float* stats, long rows, long C, void* stream) {
   VFM_CHECK(C > 0 && C <= 3072 && ld_x >= C && ld_y >= C, VFM_E_SHAPE, "vfm_layernorm_fwd: C=%ld unsupported", C);
@@ -226,6 +287,14 @@ extern "C" int vfm_layernorm_fwd(const float* x, long ld_x, const float* w, cons
     else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_fwd: dtype");
 #undef LV
     if (!(nv == 1 || nv == 2 || nv == 4 || nv == 5 || nv == 8)) VFM_FAIL(VFM_E_SHAPE, "vfm_layernorm_fwd: C=%ld", C);
+    VFM_LAUNCH_CHECK();
+    return VFM_OK;
+  }
+  if (C > 1024 && C <= 2816 && ld_x % 4 == 0 && ld_y % 4 == 0 && ld_x >= (C + 3) / 4 * 4 && ld_y >= (C + 3) / 4 * 4 && (uintptr_t)x % 16 == 0 &&
+      (uintptr_t)y % 16 == 0) {   // padded pitch: 16-byte pieces, partly valid last piece (2.8 -> ~5 TB/s on EVA02's 2730-wide sub-LN)
+    if (y_dt == VFM_BF16) hipLaunchKernelGGL((k_ln_fwd_v4t<bf16_t, 11>), grid, blk, 0, s, x, ld_x, w, b, eps, (bf16_t*)y, ld_y, stats, rows, (int)C);
+    else if (y_dt == VFM_F32) hipLaunchKernelGGL((k_ln_fwd_v4t<float, 11>), grid, blk, 0, s, x, ld_x, w, b, eps, (float*)y, ld_y, stats, rows, (int)C);
+    else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_fwd: dtype");
     VFM_LAUNCH_CHECK();
     return VFM_OK;
   }
@@ -349,6 +418,76 @@ __global__ void k_ln_bwd_fin(const float* __restrict__ ws, int parts, int C, flo
   }
 }
 
+// padded-pitch form of the above (see k_ln_fwd_v4t): 16-byte pieces of x / dx, 8-byte pieces of a bf16 dy
+template <typename TD, int MAXP4>
+__global__ void k_ln_bwd_v4t(const TD* __restrict__ dy, long ld_dy, const float* __restrict__ x, long ld_x, const float* __restrict__ w,
+                             const float* __restrict__ stats, float* __restrict__ dx, long ld_dx, int accumulate_dx, long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+  float g[MAXP4][4], xh[MAXP4][4];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[i][e] = xh[i][e] = 0.f;
+    if (c < C) {
+      float d[4];
+      if constexpr (sizeof(TD) == 2) {
+        const ushort4 pp = *reinterpret_cast<const ushort4*>(dy + row * ld_dy + c);
+        d[0] = bf16_to_f32(pp.x), d[1] = bf16_to_f32(pp.y), d[2] = bf16_to_f32(pp.z), d[3] = bf16_to_f32(pp.w);
+      } else {
+        const float4 t = *reinterpret_cast<const float4*>(dy + row * ld_dy + c);
+        d[0] = t.x, d[1] = t.y, d[2] = t.z, d[3] = t.w;
+      }
+      const float4 xv4 = *reinterpret_cast<const float4*>(x + row * ld_x + c);
+      const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+      float wv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (c + 4 <= C) {
+        const float4 ww = *reinterpret_cast<const float4*>(w + c);
+        wv[0] = ww.x, wv[1] = ww.y, wv[2] = ww.z, wv[3] = ww.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < C) wv[e] = w[c + e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e < C) {
+          xh[i][e] = (xv[e] - mean) * rstd;
+          g[i][e] = d[e] * wv[e];
+          s1 += g[i][e];
+          s2 += g[i][e] * xh[i][e];
+        }
+    }
+  }
+  s1 = wave_sum(s1) / C;
+  s2 = wave_sum(s2) / C;
+#pragma unroll
+  for (int i = 0; i < MAXP4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = rstd * (g[i][e] - s1 - xh[i][e] * s2);
+      if (c + 4 <= C) {
+        float4* pp = reinterpret_cast<float4*>(dx + row * ld_dx + c);
+        if (accumulate_dx) {
+          const float4 old = *pp;
+          o[0] += old.x, o[1] += old.y, o[2] += old.z, o[3] += old.w;
+        }
+        *pp = make_float4(o[0], o[1], o[2], o[3]);
+      } else {   // partly valid last piece: nothing is written past column C
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < C) dx[row * ld_dx + c + e] = accumulate_dx ? dx[row * ld_dx + c + e] + o[e] : o[e];
+      }
+    }
+  }
+}
+
 static int ln_bwd_impl(const void* dy, int dy_dt, long ld_dy, const float* x, long ld_x, const float* w, const float* stats,
                        float* dx, long ld_dx, int accumulate_dx, float* dw, float* db, float* ws, long rows, long C, void* t_out,
                        long ld_t, const float* t_scale, void* stream);
@@ -436,6 +575,20 @@ static int ln_bwd_impl(const void* dy, int dy_dt, long ld_dy, const float* x, lo
     return VFM_OK;
   }
   VFM_CHECK(!t_out, VFM_E_UNSUPPORTED, "vfm_layernorm_bwd_scaled: needs the vectorised path (C %% 256 == 0, aligned operands, no dw/db)");
+  {
+    const long cp = (C + 3) / 4 * 4;
+    if (!need_w && C > 1024 && C <= 2816 && ld_x % 4 == 0 && ld_dx % 4 == 0 && ld_dy % 4 == 0 && ld_x >= cp && ld_dx >= cp && ld_dy >= cp &&
+        (uintptr_t)x % 16 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)dy % 16 == 0) {
+      dim3 grid(cdiv(rows, 4)), blk(256);
+      if (dy_dt == VFM_BF16)
+        hipLaunchKernelGGL((k_ln_bwd_v4t<bf16_t, 11>), grid, blk, 0, s, (const bf16_t*)dy, ld_dy, x, ld_x, w, stats, dx, ld_dx, accumulate_dx, rows, (int)C);
+      else if (dy_dt == VFM_F32)
+        hipLaunchKernelGGL((k_ln_bwd_v4t<float, 11>), grid, blk, 0, s, (const float*)dy, ld_dy, x, ld_x, w, stats, dx, ld_dx, accumulate_dx, rows, (int)C);
+      else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_bwd: dtype");
+      VFM_LAUNCH_CHECK();
+      return VFM_OK;
+    }
+  }
   if (!need_w && C > 1024 && C % 2 == 0 && ld_x % 2 == 0 && ld_dx % 2 == 0 && ld_dy % 2 == 0 && (uintptr_t)x % 8 == 0 &&
       (uintptr_t)dx % 8 == 0 && (uintptr_t)dy % 8 == 0 && (uintptr_t)w % 8 == 0) {
     dim3 grid(cdiv(rows, 4)), blk(256);
