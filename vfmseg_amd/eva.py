@@ -267,7 +267,9 @@ class EvaEngine:
             Lp["w12"].fwd(a2, h12, bias=Lp["b12"])
             hidden = torch.empty(M, hid_p, dtype=torch.float32, device=dev)
             ops.swiglu_fwd(h12, hidden, hid_p)                                      # pad columns: silu(0)*0 = 0
-            hn = torch.zeros(M, hid_p, dtype=cd, device=dev)
+            hn = torch.empty(M, hid_p, dtype=cd, device=dev)
+            if hid_p > Lp["hid"]:
+                hn[:, Lp["hid"]:].zero_()     # K padding of the next GEMM: only the pad columns need the fill (the LN writes the rest)
             st3 = torch.empty(M, 2, dtype=torch.float32, device=dev)
             ops.layernorm_fwd(hidden[:, :Lp["hid"]], Lp["n3w"], Lp["n3b"], 1e-5, hn[:, :Lp["hid"]], st3)
             xo = torch.empty(M, D, dtype=torch.float32, device=dev)
@@ -311,7 +313,9 @@ class EvaEngine:
                 ops.cast(dx, t)
             dhn = torch.empty(M, hid_p, dtype=cd, device=dev)
             Lp["w3"].dgrad(t, dhn)
-            dhid = torch.zeros(M, hid_p, dtype=torch.float32, device=dev)
+            dhid = torch.empty(M, hid_p, dtype=torch.float32, device=dev)
+            if hid_p > hid:
+                dhid[:, hid:].zero_()         # (pad columns only: the LN backward writes the rest)
             ops.layernorm_bwd(dhn[:, :hid], S["hidden"][:, :hid], Lp["n3w"], S["st3"], dhid[:, :hid], accumulate_dx=False)
             dh12 = torch.empty(M, 2 * hid_p, dtype=cd, device=dev)
             ops.swiglu_bwd(S["h12"], dhid, dh12, hid_p)
