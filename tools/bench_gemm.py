@@ -26,6 +26,7 @@ SHAPES = [  # (M, N, K, out_dtype, label)
 if os.environ.get("SHAPES") == "small":
     SHAPES = [
         (4096, 64, 1024, torch.bfloat16, "lora T fwd"),
+        (4100, 64, 4096, torch.bfloat16, "lora T K4096"),
         (4096, 1024, 64, torch.bfloat16, "lora dgrad"),
         (4096, 256, 1024, torch.bfloat16, "head 256"),
         (2048, 256, 1024, torch.bfloat16, "head 2048x256"),
