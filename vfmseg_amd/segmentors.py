@@ -193,7 +193,8 @@ class EncoderDecoder(nn.Module):
         losses = self.forward(data["inputs"], data["data_samples"], mode="loss")
         total, log = self.parse_losses(losses)
         optim_wrapper.update_params(total)
-        return log
+        # mmengine's parse_losses returns detached log_vars: after the update nobody may backpropagate through them again
+        return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in log.items()}
 
     def encode_decode(self, inputs, batch_img_metas):
         return self.decode_head.predict(self.extract_feat(inputs), batch_img_metas, self.test_cfg)
