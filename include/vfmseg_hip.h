@@ -233,7 +233,8 @@ int vfm_sam_attn_bwd_merge(const void* dqa, const void* dkT, const void* dvT, in
 /* Flash-style forward of the same attention (inference; head dim 80 = SAM ViT-H): token-major qkv [nimg*G*G, 3*H*d] -> token-major
  * out [nimg*G*G, H*d] in ONE launch - windows of S = 14 on the zero-padded grid (padded tokens: k / v = projection bias) or global
  * attention (S = G = 32).  tbl_h / tbl_w: bf16 [2*SP, d] (SP = 16 for S = 14, 32 for S = 32) relative-index tables,
- * tbl[j] = rel_pos(re-interpolated)[j] = Rh[qh, kh] for qh - kh + S - 1 = j, rows >= 2S-1 zero.  No score matrix in memory. */
+ * tbl[j] = rel_pos(re-interpolated)[j] = Rh[qh, kh] for qh - kh + S - 1 = j, rows >= 2S-1 zero.  No score matrix in memory.
+ * Alignment: qkv, out, tables and bias 16 bytes; ld, ldo multiples of 8 elements (rows move as 16-byte pieces).  VFM_E_ALIGN otherwise. */
 int vfm_sam_attn_flash_fwd(const void* qkv, long ld, const float* bias, const void* tbl_h, const void* tbl_w, void* out, long ldo,
                            int nimg, int G, int S, int H, int d, float scale, void* stream);
 /* Training form of the same launch: also writes, per (image, window, head) and window token (row pitch NWINP = 256 for S = 14,
