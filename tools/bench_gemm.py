@@ -34,6 +34,15 @@ if os.environ.get("SHAPES") == "small":
     ]
 
 
+if os.environ.get("SHAPES") == "eval":  # DINOv2-L ms_slide_inference: nine 1025-token windows at once
+    SHAPES = [
+        (9225, 1024, 1024, torch.float32, "eval proj"),
+        (9225, 3072, 1024, torch.bfloat16, "eval qkv"),
+        (9225, 4096, 1024, torch.bfloat16, "eval fc1"),
+        (9225, 1024, 4096, torch.float32, "eval fc2"),
+    ]
+
+
 if os.environ.get("SHAPES") == "sam":   # SAM-H train step at bs 2 (4 images of 32 x 32 tokens), D = 1280
     SHAPES = [
         (4096, 1280, 1280, torch.float32, "sam proj"),
