@@ -131,3 +131,44 @@ def test_sam_engine_flash_equals_materialised_path():
         e_f, e_m = rel_err(outs["1"][i], ref[i]), rel_err(outs["0"][i], ref[i])
         print(f"[sam engine tap {i}] flash vs oracle {e_f:.2e}, materialised vs oracle {e_m:.2e}")
         assert e_f < 4e-2 and e_f < 2.0 * e_m + 5e-3
+
+
+def test_sam_engine_flash_backward_equals_materialised_backward():
+    """SAM-H widths, depth 4 (one global block), train mode, LoRA dropout off: the LoRA gradients of the engine with the flash
+    forward + backward against the same engine on the materialised path (VFMSEG_SAM_FLASH=0), same input and d(taps)."""
+    from tests.helpers import sam_state_dict
+    from vfmseg_amd import presets
+    from vfmseg_amd.precision import set_compute_dtype
+    from vfmseg_amd.registry import MODELS
+    from vfmseg_amd.synth import synth_image
+    import vfmseg_amd.sam  # noqa: F401
+    set_compute_dtype("bf16")
+    depth, gidx, oidx = 4, (3,), (0, 1, 2, 3)
+    sd = sam_state_dict(depth=depth, global_idx=gidx)
+    cfg = dict(type="LoRABackbone", backbone=presets.sam_backbone(depth=depth, global_idx=gidx, out_indices=oidx), Lora_config=presets.lora_cfg(dropout=0.0))
+    m = MODELS.build(cfg)
+    m.load_state_dict({k[len("backbone."):]: v for k, v in sd.items()}, strict=False)
+    m = m.cuda().train()
+    for n, p_ in m.named_parameters():   # B starts at zero: give it values so that dA is not identically zero
+        if "lora_B" in n:
+            with torch.no_grad():
+                p_.copy_(torch.randn(p_.shape, generator=torch.Generator().manual_seed(len(n))).to(p_.device) * 0.02)
+    img = synth_image(2, 512, seed=46).cuda()
+    grads = {}
+    try:
+        for flag in ("1", "0"):
+            os.environ["VFMSEG_SAM_FLASH"] = flag
+            for p_ in m.parameters():
+                p_.grad = None
+            feats = m(img)
+            g = torch.Generator().manual_seed(5)
+            loss = sum((f.float() * torch.randn(f.shape, generator=g).to(f.device)).sum() for f in feats)
+            loss.backward()
+            grads[flag] = {n: p_.grad.detach().float().cpu().clone() for n, p_ in m.named_parameters() if p_.grad is not None}
+    finally:
+        os.environ.pop("VFMSEG_SAM_FLASH", None)
+    assert len(grads["1"]) == 2 * depth == len(grads["0"])
+    for n in grads["1"]:
+        e = rel_err(grads["1"][n], grads["0"][n])
+        print(f"[sam engine bwd] {n}: flash vs materialised {e:.2e}")
+        assert grads["0"][n].abs().max() > 0 and e < 6e-2, (n, e)
