@@ -16,17 +16,25 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+np = torch = None   # imported by _heavy(): the launcher parent (`python bench.py --gpus N`, no WORLD_SIZE) must stay GPU-free
+
+
+def _heavy():
+    global np, torch
+    if torch is None:
+        import numpy as _np
+        import torch as _torch
+        np, torch = _np, _torch
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense")
 PEAK_HBM_GBS = 8000.0
 
 
-def build(device, batch, seed=0, workload="ms1024"):
+def build(device, batch, seed=0, workload="ms1024", depth=None):
+    _heavy()
     import vfmseg_amd  # noqa: F401  (registers the model classes)
     from vfmseg_amd import presets
     from vfmseg_amd.optim import PEFTOptimWrapperConstructor
@@ -34,7 +42,12 @@ def build(device, batch, seed=0, workload="ms1024"):
     from vfmseg_amd.synth import synth_like
 
     torch.manual_seed(seed)
-    model = MODELS.build(presets.dinov2_ms_masked() if workload == "ms1024" else presets.dinov2_linear())
+    kw = {} if depth is None else dict(depth=depth)   # depth: launcher / DP rehearsals only, never the headline line
+    cfg = presets.dinov2_ms_masked(**kw) if workload == "ms1024" else presets.dinov2_linear(**kw)
+    if depth is not None:
+        assert depth % 4 == 0, "--depth: a multiple of 4 (the four feature taps sit at the quarter points)"
+        cfg["backbone"]["backbone"]["out_indices"] = [depth * (i + 1) // 4 - 1 for i in range(4)]
+    model = MODELS.build(cfg)
     # random-init weights of the named architecture (no checkpoints offline): key-hashed synthetic values
     sd = synth_like(model.state_dict())
     model.load_state_dict(sd)
@@ -46,6 +59,7 @@ def build(device, batch, seed=0, workload="ms1024"):
 
 
 def make_batch(batch, rank, step, device, size=1024):
+    _heavy()
     from vfmseg_amd.segmentors import SegDataSample
     from vfmseg_amd.synth import synth_image, synth_label
     img = synth_image(batch, size, seed=100 + rank).to(device)
@@ -110,6 +124,7 @@ def eval_leg(device, timer, iters=5):
       dinov2 : dg_lora_dinov2_ms_masked test_cfg (ms_slide_inference: coarse 512x1024 pass + confidence-gated refinement of the
                3x3 windows; random-init logits are never confident, conf forced so that all 9 refine: the worst case)
       sam    : configs[4] = lora_sam_linear semantics (SAM-ViT-H + LoRA + LinearHead, mode slide, stride 320, crop 512: 3x3 windows)"""
+    _heavy()
     import vfmseg_amd  # noqa: F401
     from vfmseg_amd import presets
     from vfmseg_amd.registry import MODELS
@@ -160,6 +175,7 @@ def eval_leg(device, timer, iters=5):
 def cpu_baseline(seconds_cap=40.0, model_kw=None):
     """The oracle (CPU fp32 restatement of the reference path) timed on this box's host cores: one train step
     (forward_train + backward + AdamW on the trainable tensors), B=1, 1024^2 input -> 2 x 512^2 passes."""
+    _heavy()
     from oracle import torch_ref as R
     from vfmseg_amd import presets
     from vfmseg_amd.registry import MODELS
@@ -227,8 +243,54 @@ def _reserve_stdout():
     return real
 
 
-def main():
-    real_stdout = _reserve_stdout()
+def _launcher_rehearsal(a, rank, world, real_stdout):
+    """--rehearse-launcher: everything of the N-rank bench EXCEPT the model - process start, rendezvous, the product's bucketed
+    gradient all-reduce (parallel.GradSync) on a flat fp32 buffer of the real size (16.6 M values), the barrier-bracketed timing,
+    MAX over ranks, rank 0's one JSON line.  Runs on gloo/CPU where there is no GPU (the product path has no CPU fallback, so a
+    model step cannot run there); the line it prints is labelled as a rehearsal and is never the headline metric."""
+    _heavy()
+    import torch.distributed as dist
+    from vfmseg_amd import parallel
+    n = 16_600_000 // 64
+    g = torch.full((n,), float(rank + 1))
+    names = ["aux_decoder.w", "decode_head.w"] + [f"backbone.model.base_model.model.blocks.{i}.attn.qkv.lora_A.default.weight" for i in (1, 0)]
+    offs = [0, n // 4, n // 2, 3 * n // 4, n]
+    gs = parallel.GradSync(g, parallel.make_buckets(names, offs), None)
+
+    def step():
+        g.fill_(float(rank + 1))
+        gs.ready(0)
+        gs.finish()
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ok = bool(torch.allclose(g, torch.full((n,), (world + 1) / 2.0)))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        real_stdout.write(json.dumps({
+            "metric": "launcher rehearsal: bucketed gradient all-reduce steps/s (no model; NOT the headline metric)",
+            "value": round(a.steps / dt, 3), "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "allreduce_mean_ok": ok,
+            "config": {"workload": "rehearsal of bench.py's N-rank plumbing on %s" % dist.get_backend() if world > 1 else "single rank",
+                       "parallelism": "dp%d" % world}}) + "\n")
+        real_stdout.flush()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -237,19 +299,43 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eval", action="store_true", help="skip the eval ms/img @1024x1024 leg (N=1 only)")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the f32 parity-mode speed leg (N=1 only)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--workload", default="ms1024", choices=["ms1024", "single512"],
                     help="ms1024: BASELINE configs[1] (1024^2 sample -> LR + HR 512^2 passes, both heads; the headline metric); "
                          "single512: one 512^2 pass per sample, DINOv2-L + LoRA + LinearHead (SURVEY 8: the labelled single-pass step)")
     ap.add_argument("--tune", action="append", default=[], help="kernel tuning knob KEY=INT (vfm_tune), repeatable")
-    a = ap.parse_args()
+    ap.add_argument("--depth", type=int, default=None, help="backbone depth for launcher / DP rehearsals (default: the config's 24; "
+                                                            "any other value marks the line as not the headline metric)")
+    ap.add_argument("--rehearse-launcher", action="store_true", help="N-rank plumbing without the model (runs on CPU/gloo): see _launcher_rehearsal")
+    ap.add_argument("--launch-timeout", type=float, default=None, help="launcher parent: stop all ranks after this many seconds")
+    return ap.parse_args(argv)
+
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (the reference's tools/dist_train.sh:9-17 role).  It starts N
+        # fresh interpreters of this file with the torchrun env, relays rank 0's JSON line and returns the worst exit code.  It has not
+        # imported torch and never touches the GPU; under `python -m torch.distributed.run ... bench.py` WORLD_SIZE is set and this branch
+        # is not taken.
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("dist_launch", os.path.join(ROOT, "tools", "dist_launch.py"))
+        dl = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(dl)
+        sys.exit(dl.launch([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], a.gpus, timeout=a.launch_timeout))
+    real_stdout = _reserve_stdout()
+    _heavy()
 
     from vfmseg_amd import parallel
     from vfmseg_amd.precision import set_compute_dtype
+    if a.rehearse_launcher:
+        rank, world, local = parallel.init_from_env("gloo")
+        sys.exit(_launcher_rehearsal(a, rank, world, real_stdout))
     rank, world, local = parallel.init_from_env("nccl")
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start with plain `python bench.py --gpus N` (self-launching) or "
+                         f"`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
     ndev = torch.cuda.device_count()
     dev_index = local if local < ndev else local % max(ndev, 1)   # rehearsal: several gloo ranks may share one GPU
     torch.cuda.set_device(dev_index)
@@ -263,7 +349,7 @@ def main():
         k, v = kv.split("=")
         _ops.tune(k, int(v))
 
-    model, ow = build(device, a.batch, workload=a.workload)
+    model, ow = build(device, a.batch, workload=a.workload, depth=a.depth)
     parallel.attach(model, ow)
     from vfmseg_amd import functional as Fh
     Fh.manual_seed(1234 + rank)
@@ -305,6 +391,9 @@ def main():
                                "bs=%d/GPU, full train step (fwd+bwd+allreduce+AdamW), LoRA dropout on" % a.batch,
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world},
     }
+    if a.depth is not None and a.depth != 24:
+        out["metric"] = "REHEARSAL at backbone depth %d (not the headline metric): " % a.depth + out["metric"]
+        out["config"]["depth"] = a.depth
     if a.workload == "single512":
         out["metric"] = "train images/sec @512x512 DINOv2-L+LoRA + LinearHead, single 512^2 pass per sample (not the headline metric)"
         out["config"]["workload"] = "single-pass variant of configs[1]: EncoderDecoder(LoRABackbone(DINOv2-L), LinearHead), 512^2 inputs, bs=%d/GPU" % a.batch

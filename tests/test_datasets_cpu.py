@@ -154,3 +154,32 @@ def test_load_annotations_reduce_zero_label_and_label_map(tmp_path):
                                     img_shape=(2, 4), flip=False))
     assert tuple(packed["inputs"].shape) == (3, 2, 4) and packed["data_samples"].metainfo["img_path"] == "x.png"
     assert packed["data_samples"].gt_sem_seg.data.dtype == torch.int64
+
+
+def test_worker_seeds_differ_between_ranks(tmp_path):
+    """Round-2 advisor finding: DataLoader workers were seeded from torch.initial_seed() + worker_id, and the main-process torch
+    generator is seeded alike on every rank, so worker k drew the SAME rare-class samples, crops and flips on every rank.  mmengine
+    seeds worker k of rank r with num_workers * r + k + seed: the ranks' first batches must differ, a rank must reproduce itself."""
+    root = str(tmp_path)
+    _tree(root, n=12)
+
+    def first_batches(rank, n=3):
+        torch.manual_seed(0)            # Runner.from_cfg: identical on every rank
+        it = D.DataLoaderIter(_cfg(root), batch_size=2, num_workers=2, shuffle=True, seed=0, rank=rank, world=2)
+        out = [next(it) for _ in range(n)]
+        del it
+        return [np.stack([x.numpy() for x in b["inputs"]]) for b in out]
+
+    r0, r1, r0b = first_batches(0), first_batches(1), first_batches(0)
+    assert all(np.array_equal(a, b) for a, b in zip(r0, r0b)), "same rank, same seed: reproducible"
+    assert not any(np.array_equal(a, b) for a, b in zip(r0, r1)), "ranks must not train on identical samples"
+
+
+def test_sampler_fast_forward_continues_the_index_stream(tmp_path):
+    s = D.InfiniteSampler(10, True, seed=3, rank=1, world=2)
+    it = iter(s)
+    head = [next(it) for _ in range(12)]
+    s2 = D.InfiniteSampler(10, True, seed=3, rank=1, world=2)
+    s2.skip = 8
+    it2 = iter(s2)
+    assert [next(it2) for _ in range(4)] == head[8:]

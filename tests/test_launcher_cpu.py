@@ -1,0 +1,62 @@
+"""`python bench.py --gpus N` must start its own N ranks (round-2 verdict, Missing #2; the role of the reference's
+tools/dist_train.sh:9-17): the parent never touches the GPU, relays rank 0's one JSON line and returns the worst exit code.
+On CPU the ranks run the launcher rehearsal (gloo; process start, rendezvous, the product's bucketed gradient all-reduce, barrier
+timing, MAX over ranks) - the model step itself needs the HIP library and is covered by tests/test_launcher_gpu.py."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None, timeout=240):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable] + args, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_launches_its_own_ranks_on_gloo():
+    r = _run(["bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--rehearse-launcher"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines            # ONE JSON line, rank 0's
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["allreduce_mean_ok"] is True
+    assert out["config"]["parallelism"] == "dp2" and "NOT the headline" in out["metric"]
+
+
+def test_bench_parent_does_not_import_torch():
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--gpus', '2', '--steps', '1', '--warmup', '0', '--rehearse-launcher']\n"
+            "try:\n    runpy.run_path('bench.py', run_name='__main__')\nexcept SystemExit as e:\n"
+            "    assert (e.code or 0) == 0, e.code\n"
+            "assert 'torch' not in sys.modules, 'the launcher parent imported torch'\nprint('PARENT_CLEAN')\n")
+    r = _run(["-c", code])
+    assert r.returncode == 0 and "PARENT_CLEAN" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_torchrun_form_still_works():
+    r = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29713",
+              "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--rehearse-launcher"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2
+
+
+def test_launcher_returns_a_failing_ranks_exit_code(tmp_path):
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\nr = int(os.environ['RANK'])\nassert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                      "print('hello from', r, flush=True)\nif r == 1:\n    sys.exit(7)\ntime.sleep(30)\n")
+    r = _run([os.path.join("tools", "dist_launch.py"), "--nproc", "3", str(script)], timeout=60)
+    assert r.returncode == 7
+    assert r.stdout.strip() == "hello from 0"           # only rank 0's stdout is relayed
+    assert "[rank 1] hello from 1" in r.stderr and "rank 1 exited with code 7" in r.stderr
+
+
+def test_dist_train_sh_keeps_the_reference_argument_order():
+    txt = open(os.path.join(ROOT, "tools", "dist_train.sh")).read()
+    assert "CONFIG=$1" in txt and "GPUS=$2" in txt and "--launcher pytorch" in txt and '"${@:3}"' in txt
+    for var in ("NNODES", "NODE_RANK", "PORT", "MASTER_ADDR"):
+        assert var in txt

@@ -1,0 +1,28 @@
+"""`python bench.py --gpus 2` end to end on the one GPU of the test box: the self-launcher starts two fresh ranks (gloo, both on
+cuda:0 - a one-GPU box cannot host two RCCL ranks), each runs the product train step of a depth-4 DINOv2-L + LoRA `ms_masked` model
+through parallel.attach (bucketed gradient all-reduce from inside backward, SyncBN exchange) and rank 0 prints the one JSON line.
+Reference role: tools/dist_train.sh:9-17 + configs/_base_/default_runtime.py:5."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_two_ranks_share_the_gpu():
+    env = dict(os.environ, VFMSEG_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--depth", "4", "--steps", "3", "--warmup", "2", "--no-eval",
+                        "--no-cpu-baseline", "--no-parity-mode", "--launch-timeout", "500"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] > 0 and out["scaling"] == "weak" and "REHEARSAL" in out["metric"] and out["config"]["depth"] == 4

@@ -291,7 +291,7 @@ extern "C" int vfm_layernorm_fwd(const float* x, long ld_x, const float* w, cons
     return VFM_OK;
   }
   if (C > 1024 && C <= 2816 && ld_x % 4 == 0 && ld_y % 4 == 0 && ld_x >= (C + 3) / 4 * 4 && ld_y >= (C + 3) / 4 * 4 && (uintptr_t)x % 16 == 0 &&
-      (uintptr_t)y % 16 == 0) {   // padded pitch: 16-byte pieces, partly valid last piece (2.8 -> ~5 TB/s on EVA02's 2730-wide sub-LN)
+      (uintptr_t)y % 16 == 0 && (uintptr_t)w % 16 == 0 && (uintptr_t)b % 16 == 0) {   // padded pitch: 16-byte pieces, partly valid last piece (2.8 -> ~5 TB/s on EVA02's 2730-wide sub-LN)
     if (y_dt == VFM_BF16) hipLaunchKernelGGL((k_ln_fwd_v4t<bf16_t, 11>), grid, blk, 0, s, x, ld_x, w, b, eps, (bf16_t*)y, ld_y, stats, rows, (int)C);
     else if (y_dt == VFM_F32) hipLaunchKernelGGL((k_ln_fwd_v4t<float, 11>), grid, blk, 0, s, x, ld_x, w, b, eps, (float*)y, ld_y, stats, rows, (int)C);
     else VFM_FAIL(VFM_E_INVAL, "vfm_layernorm_fwd: dtype");
@@ -578,7 +578,7 @@ static int ln_bwd_impl(const void* dy, int dy_dt, long ld_dy, const float* x, lo
   {
     const long cp = (C + 3) / 4 * 4;
     if (!need_w && C > 1024 && C <= 2816 && ld_x % 4 == 0 && ld_dx % 4 == 0 && ld_dy % 4 == 0 && ld_x >= cp && ld_dx >= cp && ld_dy >= cp &&
-        (uintptr_t)x % 16 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)dy % 16 == 0) {
+        (uintptr_t)x % 16 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)w % 16 == 0) {
       dim3 grid(cdiv(rows, 4)), blk(256);
       if (dy_dt == VFM_BF16)
         hipLaunchKernelGGL((k_ln_bwd_v4t<bf16_t, 11>), grid, blk, 0, s, (const bf16_t*)dy, ld_dy, x, ld_x, w, stats, dx, ld_dx, accumulate_dx, rows, (int)C);

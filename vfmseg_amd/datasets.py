@@ -391,16 +391,21 @@ class InfiniteSampler:
 
     def __init__(self, size, shuffle=True, seed=0, rank=0, world=1):
         self.size, self.shuffle, self.seed, self.rank, self.world = size, shuffle, seed, rank, world
+        self.skip = 0
 
     def __iter__(self):
         g = torch.Generator()
         g.manual_seed(self.seed)
         k = 0
+        skip = self.skip     # resume: this rank's first `skip` indices were consumed before the checkpoint
         while True:
             idx = torch.randperm(self.size, generator=g).tolist() if self.shuffle else list(range(self.size))
             for i in idx:
                 if k % self.world == self.rank:
-                    yield i
+                    if skip > 0:
+                        skip -= 1
+                    else:
+                        yield i
                 k += 1
 
 
@@ -412,15 +417,24 @@ def pseudo_collate(batch):
 class DataLoaderIter:
     """Iterator of training batches dict(inputs=[uint8 CHW] * B, data_samples=[SegDataSample] * B) from a dataset config
     (`train_dataloader` of the reference's configs).  num_workers > 0 uses torch's DataLoader worker processes; every worker
-    seeds numpy from its torch seed (mmengine worker_init_fn)."""
+    is seeded with num_workers * rank + worker_id + seed (mmengine.dataset.worker_init_fn): the DataLoader's own base seed comes from
+    the main process's torch generator, which Runner.from_cfg seeds identically on every rank, so it must not be the only source -
+    with rare class sampling the dataset ignores idx and draws class, file and crop from np.random, and equal worker seeds would make
+    every rank train on the same samples."""
 
     def __init__(self, dataset, batch_size=2, num_workers=0, shuffle=True, seed=0, rank=0, world=1, infinite=True):
         self.dataset = DATASETS.build(dataset) if isinstance(dataset, dict) else dataset
         self.bs, self.i = batch_size, 0
         self.sampler = InfiniteSampler(len(self.dataset), shuffle, seed, rank, world) if infinite else range(rank, len(self.dataset), world)
+        self.seed, self.rank, self.num_workers, self.epoch_offset = seed, rank, num_workers, 0
+        loader_self = self
 
         def init_fn(worker_id):
-            np.random.seed((torch.initial_seed() + worker_id) % 2 ** 32)
+            import random
+            ws = (loader_self.num_workers * loader_self.rank + worker_id + loader_self.seed + 7919 * loader_self.epoch_offset) % 2 ** 32
+            np.random.seed(ws)
+            random.seed(ws)
+            torch.manual_seed(ws)
 
         self.loader = torch.utils.data.DataLoader(self.dataset, batch_size=batch_size, sampler=self.sampler, num_workers=num_workers,
                                                   collate_fn=pseudo_collate, worker_init_fn=init_fn, drop_last=infinite,
@@ -436,5 +450,14 @@ class DataLoaderIter:
             self._it = iter(self.loader)
         self.i += 1
         return next(self._it)
+
+    def fast_forward(self, batches):
+        """Resume: continue the sample order where the checkpoint stopped (this rank consumed `batches` batches) and give the
+        workers seeds they have not used yet."""
+        self.i = batches
+        if isinstance(self.sampler, InfiniteSampler):
+            self.sampler.skip = batches * self.bs
+        self.epoch_offset = batches
+        self._it = None
 
     next = __next__

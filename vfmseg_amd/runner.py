@@ -58,6 +58,7 @@ class Runner:
         self.cfg, self.model, self.ow, self.loader, self.work_dir = cfg, model, optim_wrapper, loader, work_dir
         self.rank, self.world = rank, world
         self.iter = 0
+        self.seed = 0
 
     @classmethod
     def from_cfg(cfg_cls, cfg, synthetic=True, device=None):
@@ -90,23 +91,38 @@ class Runner:
         elif ds is not None and rank == 0:
             import warnings
             warnings.warn(f"train_dataloader.dataset ({ds.get('type', '?') if isinstance(ds, dict) else type(ds).__name__}) is NOT read: "
-                          "synthetic=True trains on the synthetic 19-class stream (pass synthetic=False / tools/train.py --real-data "
+                          "synthetic=True trains on the synthetic 19-class stream (pass synthetic=False / tools/train.py --data real "
                           "to read it through vfmseg_amd.datasets)")
         if loader is None:
             size = tuple(cfg.get("crop_size", cfg["model"].get("data_preprocessor", {}).get("size", (1024, 1024))))
             loader = SyntheticLoader(bs, size, rank, world, seed)
         work_dir = cfg.get("work_dir", "./work_dirs/run")
-        return cfg_cls(cfg, model, ow, loader, work_dir, rank, world)
+        r = cfg_cls(cfg, model, ow, loader, work_dir, rank, world)
+        r.seed = seed
+        return r
+
+    @staticmethod
+    def _rng_path(path, rank):
+        return f"{path}.rng_rank{rank}"
+
+    def _rng_state(self):
+        from . import functional as Fh
+        return dict(iter=self.iter, loader_pos=getattr(self.loader, "i", None), np_random=np.random.get_state(),
+                    mask_rng=dict(Fh._seed_state), torch_rng=torch.get_rng_state())
+
+    def save_rank_state(self, path):
+        """Every rank > 0 keeps ITS random streams (np.random = crop boxes, and rare class sampling / transforms when num_workers = 0;
+        the dropout / query-mask counter; the loader position) in a side file next to rank 0's checkpoint: the streams were seeded
+        seed + rank and must stay different after a resume."""
+        if self.rank != 0:
+            torch.save(self._rng_state(), self._rng_path(path, self.rank))
 
     def save_checkpoint(self, path):
-        """mmengine CheckpointHook: weights, optimiser state, iteration - plus the RNG consumers of the hot path (the crop-box
+        """mmengine CheckpointHook: weights, optimiser state, iteration - plus rank 0's RNG consumers of the hot path (the crop-box
         np.random stream, the dropout / query-mask counter, the loader position) so that a resumed run continues the same
-        sample and mask sequence - and a `last_checkpoint` pointer file next to it."""
-        from . import functional as Fh
+        sample and mask sequence - and a `last_checkpoint` pointer file next to it.  Ranks > 0: save_rank_state."""
         sd = {k: v.detach().cpu() for k, v in self.model.state_dict().items()}
-        meta = dict(iter=self.iter, loader_pos=getattr(self.loader, "i", None), np_random=np.random.get_state(),
-                    mask_rng=dict(Fh._seed_state), torch_rng=torch.get_rng_state())
-        torch.save(dict(state_dict=sd, meta=meta, optimizer=self.ow.optimizer.state_dict(), optim_wrapper=self.ow.state_dict()), path)
+        torch.save(dict(state_dict=sd, meta=self._rng_state(), optimizer=self.ow.optimizer.state_dict(), optim_wrapper=self.ow.state_dict()), path)
         with open(os.path.join(os.path.dirname(path) or ".", "last_checkpoint"), "w") as f:
             f.write(os.path.abspath(path))
 
@@ -119,8 +135,22 @@ class Runner:
         if "optim_wrapper" in ck:   # AmpOptimWrapper: the loss scaler's state
             self.ow.load_state_dict(ck["optim_wrapper"])
         self.iter = self.ow.iter = meta["iter"]
-        if meta.get("loader_pos") is not None and hasattr(self.loader, "i"):
-            self.loader.i = meta["loader_pos"]
+        if self.rank != 0:
+            # rank 0's streams are NOT this rank's: take this rank's side file, else re-derive streams that differ per rank
+            side = self._rng_path(path, self.rank)
+            if os.path.exists(side):
+                own = torch.load(side, map_location="cpu", weights_only=False)
+                meta = dict(meta, **{k: own[k] for k in ("np_random", "mask_rng", "torch_rng", "loader_pos")})
+            else:
+                np.random.seed((self.seed + self.rank + 1000003 * meta["iter"]) % 2 ** 32)
+                meta = dict(meta, np_random=None, torch_rng=None,
+                            mask_rng=None if meta.get("mask_rng") is None else
+                            dict(seed=(int(meta["mask_rng"]["seed"]) + 0x9E3779B1 * self.rank) % 2 ** 62, offset=meta["mask_rng"]["offset"]))
+        if meta.get("loader_pos") is not None:
+            if hasattr(self.loader, "fast_forward"):
+                self.loader.fast_forward(meta["loader_pos"])   # sampler continues where it stopped; workers get fresh seeds
+            elif hasattr(self.loader, "i"):
+                self.loader.i = meta["loader_pos"]
         if meta.get("np_random") is not None:
             np.random.set_state(meta["np_random"])
         if meta.get("mask_rng") is not None:
@@ -147,6 +177,7 @@ class Runner:
                     log.write(json.dumps(rec) + "\n")
                     log.flush()
                     print(rec, flush=True)
-            if self.rank == 0 and ckpt_interval and (self.iter % ckpt_interval == 0 or self.iter == max_iters):
-                self.save_checkpoint(os.path.join(self.work_dir, f"iter_{self.iter}.pth"))  # always one at the last iteration
+            if ckpt_interval and (self.iter % ckpt_interval == 0 or self.iter == max_iters):   # always one at the last iteration
+                ck = os.path.join(self.work_dir, f"iter_{self.iter}.pth")
+                self.save_checkpoint(ck) if self.rank == 0 else self.save_rank_state(ck)
         return self.model

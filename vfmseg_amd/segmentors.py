@@ -283,6 +283,56 @@ class EncoderDecoder(nn.Module):
         return out
 
 
+def tta_views(tta_pipeline):
+    """(ratio, flip) views of an mmseg `tta_pipeline` (the TestTimeAug entry: a list of Resize alternatives x a list of RandomFlip
+    alternatives; tools/test.py:131-134 installs it under --tta)."""
+    ratios, flips = [1.0], [False]
+    for t in tta_pipeline:
+        if t.get("type") != "TestTimeAug":
+            continue
+        for alts in t["transforms"]:
+            kinds = {a_.get("type") for a_ in alts}
+            if kinds == {"Resize"}:
+                ratios = [float(a_.get("scale_factor", 1.0)) for a_ in alts]
+            elif kinds == {"RandomFlip"}:
+                flips = [float(a_.get("prob", 0.0)) >= 1.0 for a_ in alts]
+    return [(r, f) for r in ratios for f in flips]
+
+
+@torch.no_grad()
+def predict_tta(model, inputs, data_samples, views):
+    """mmseg SegTTAModel.merge_preds (restated): every view is predicted and post-processed back to `ori_shape` (the flip is undone
+    there), the views' class softmax is averaged, argmax.  Views are produced from the loaded tensor (bilinear resize, flip)."""
+    B, C, H, W = inputs.shape
+    acc = None
+    for ratio, flip in views:
+        x = inputs
+        if ratio != 1.0:
+            h, w = int(H * ratio + 0.5), int(W * ratio + 0.5)
+            y = torch.empty(B, C, h, w, dtype=torch.float32, device=inputs.device)
+            ops.resize_bilinear(inputs.contiguous(), True, B, H, W, C, y, 1, (h, w))
+            x = y
+        if flip:
+            x = torch.flip(x, dims=[3]).contiguous()
+        samples = []
+        for i in range(B):
+            m = dict((data_samples[i].metainfo if data_samples else None) or {})
+            m.setdefault("ori_shape", (H, W))
+            m.update(img_shape=tuple(x.shape[2:]), pad_shape=tuple(x.shape[2:]), padding_size=[0, 0, 0, 0], flip=flip, flip_direction="horizontal")
+            samples.append(SegDataSample(metainfo=m))
+        out = model.predict(x, samples)
+        probs = [o.seg_logits.data.softmax(dim=0) for o in out]
+        acc = probs if acc is None else [a_ + p_ for a_, p_ in zip(acc, probs)]
+    res = []
+    for i in range(B):
+        ds = data_samples[i] if data_samples else SegDataSample()
+        mean = acc[i] / len(views)
+        ds.seg_logits = PixelData(mean)
+        ds.pred_sem_seg = PixelData(mean.argmax(dim=0, keepdim=True))
+        res.append(ds)
+    return res
+
+
 @MODELS.register_module()
 class LoraBackboneEncoderDecoder(EncoderDecoder):
     """Lora_encoder_decoder.py:12-44: plain EncoderDecoder whose backbone is LoRA-wrapped."""
