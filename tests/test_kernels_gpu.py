@@ -419,6 +419,51 @@ def test_gemm_bf16_configs_fast_epilogues(cfg, M, N, K):
         ops.tune("gemm_cfg", -1)
 
 
+@pytest.mark.parametrize("cfg", [37, 38])
+@pytest.mark.parametrize("M,N,K", [(4100, 4096, 1024), (512, 256, 640), (1024, 2048, 1088), (256, 256, 4096), (4356, 768, 576)])
+def test_gemm_bf16_persistent_two_accumulators(cfg, M, N, K):
+    """gemm_ps.hip (config 37: two 256 x 128 sub-tiles per block, the first one's epilogue under the second one's K loop; 38: one
+    sub-tile per block) on its four epilogue kinds, with and without [cls] tail rows, against float64; three launches each as a race
+    screen for the hand-counted LDS-DMA ring (every output element is checked, NaN-prefilled)."""
+    if cfg == 37 and N % 256:
+        pytest.skip("config 37 walks 256-column regions")
+    a, b = rnd(M, K, seed=90).bfloat16().to(DEV), rnd(N, K, seed=91).bfloat16().to(DEV)
+    bias = rnd(N, seed=92).to(DEV)
+    aux = rnd(M, N, seed=93).bfloat16().to(DEV)
+    acc = a.double() @ b.double().t()
+    bd, ad = bias.double(), aux.double()
+    gelu = lambda t: 0.5 * t * (1 + torch.erf(t / 2 ** 0.5))
+    gelu_grad = lambda t: 0.5 * (1 + torch.erf(t / 2 ** 0.5)) + t * torch.exp(-0.5 * t * t) / (2 * 3.141592653589793) ** 0.5
+    nan = lambda: torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.tune("gemm_cfg", cfg)
+    try:
+        for rep in range(3):
+            c = nan()
+            ops.gemm(a, b, c, bias=bias, alpha=0.5)
+            assert relerr(c.float(), 0.5 * acc + bd) < 1e-2
+            c, c2 = nan(), nan()
+            ops.gemm(a, b, c, bias=bias, ep_mode=ops.EP_GELU_DGELU, c2=c2)
+            assert relerr(c.float(), gelu(acc + bd)) < 1e-2 and relerr(c2.float(), gelu_grad(acc + bd)) < 1e-2
+            c = nan()
+            ops.gemm(a, b, c, ep_mode=ops.EP_MUL, aux=aux)
+            assert relerr(c.float(), acc * ad) < 1e-2
+            c = nan()
+            ops.gemm(a, b, c, bias=bias, ep_mode=ops.EP_GELU)
+            assert relerr(c.float(), gelu(acc + bd)) < 1e-2
+    finally:
+        ops.tune("gemm_cfg", -1)
+    # the dispatcher's own choice (config 37 for whole rounds of 256 x 256 regions) gives the same numbers as the tile kernel
+    if (M, N, K) == (4100, 4096, 1024):
+        c1, c2 = nan(), nan()
+        ops.gemm(a, b, c1, bias=bias, ep_mode=ops.EP_GELU)
+        ops.tune("gemm_use_ps", 0)
+        try:
+            ops.gemm(a, b, c2, bias=bias, ep_mode=ops.EP_GELU)
+        finally:
+            ops.tune("gemm_use_ps", 1)
+        assert relerr(c1.float(), c2.float().double()) < 1e-2
+
+
 @pytest.mark.parametrize("cfg", [-1, 17, 32, 33, 34])  # (35 / 36 need K >= 256)
 def test_gemm_bf16_batched_ragged(cfg):
     """Batched bf16 GEMMs (SAM's per-window products) with ragged M / N, a batch stride wider than the matrix, a bf16 residual

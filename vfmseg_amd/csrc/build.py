@@ -15,7 +15,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=f
 
 # per-file extras.  attention_fwd64.hip places every VALU instruction by hand between MFMAs: SLP-packed f32 adds (v_pk_add_f32)
 # cost more issue cycles there than the two scalar adds they replace
-EXTRA = {"attention_fwd64.hip": ["-fno-slp-vectorize"]}
+EXTRA = {"attention_fwd64.hip": ["-fno-slp-vectorize"],
+         # gemm_ps.hip runs its epilogue arithmetic between the MFMAs of the next sub-tile: packed f32 VALU is an anti-lever there
+         "gemm_ps.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():

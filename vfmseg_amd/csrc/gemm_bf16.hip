@@ -321,6 +321,8 @@ static int g_fold_tail = 1;  // run the tail rows as extra blocks of the tile ke
 // per shape (+2.6 % images/s).  The big-tile kernels win on long-K / light-epilogue shapes (4096^3: 1.26 PF vs 1.0) and stay
 // selectable per call (vfm_tune gemm_cfg 30..33).
 static int g_use_pp = 40;
+long g_nt_bytes = 0;   // vfm_tune("gemm_nt_mb"): outputs of at least this many bytes are stored nontemporally (0 = never)
+static int g_use_ps = 1;   // the persistent two-accumulator kernel (gemm_ps.hip) for whole rounds of 256 x 256 regions with a bf16 epilogue
 static int g_deep_tail_k = 0;  // K from which one-tile-per-CU launches WITH tail rows take the seven-chunk ring, the tail rows riding
                                // inside the regular blocks (gemm_w4.hip CLSIN); 0 = never (five-chunk ring + tail blocks).  Measured:
                                // with cold operands 62.8 -> 53.9 us at K = 4096 (19.8 -> 22.2 at K = 1024), inside the train step
@@ -357,6 +359,19 @@ extern "C" int vfm_tune(const char* key, int value) {
   }
   if (key && strcmp(key, "gemm_deep_tail_k") == 0) {
     g_deep_tail_k = value;
+    return VFM_OK;
+  }
+  if (key && strcmp(key, "gemm_nt_mb") == 0) {
+    g_nt_bytes = (long)value << 20;
+    return VFM_OK;
+  }
+  if (key && strcmp(key, "ps_burst") == 0) {
+    extern int g_ps_burst;
+    g_ps_burst = value;
+    return VFM_OK;
+  }
+  if (key && strcmp(key, "gemm_use_ps") == 0) {
+    g_use_ps = value;
     return VFM_OK;
   }
   if (key && strcmp(key, "gemm_use_pp") == 0) {
@@ -403,6 +418,8 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
 bool vfm_gemm_launch_pp256(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail);  // gemm_pp.hip
 bool vfm_gemm_launch_pp128(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail);  // gemm_pp.hip
 bool vfm_gemm_launch_w4(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail, int waves);  // gemm_w4.hip
+bool vfm_gemm_ps_ok(const vfm_gemm_desc* d, int per);                                                       // gemm_ps.hip
+bool vfm_gemm_launch_ps(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail, int per);         // gemm_ps.hip
 
 int vfm_gemm_bf16_impl(const vfm_gemm_desc* d0, hipStream_t s) {
   // A few rows past a 128-row boundary (M = B*1024 patch tokens + B [cls] tokens) would cost a whole extra row of
@@ -470,6 +487,9 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
     const bool span31 = (d->M + 128) * d->sa_m < (1l << 31) && (d->N + 128) * d->sb_n < (1l << 31);
     const bool span33 = (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31);
     if (d->N <= 32) cfg = 10;                                        // 64x64 tiles: many rows, few columns
+    else if ((g_use_ps & 1) && d->N >= 2048 && t256 >= 224 && t256 % 256 == 0 && d->K >= 1024 && vfm_gemm_ps_ok(d, 2))
+      cfg = 37;  // whole rounds of 256 x 256 regions with a bf16 store-heavy epilogue (fc1 forward, fc2 input gradient [4096 x 4096 x 1024]):
+                 // one persistent block per CU, the first half's epilogue under the second half's K loop
     else if (!(g_use_pp & 64) && tail && t128 >= 96 && t128 <= 160 && d->N >= 512 && d->K >= 1024 && span31 && nbatch == 1)
       cfg = 31;  // half a wave of 128x128 tiles over a long K in a backbone GEMM (tail rows present: the coarse eval pass, 2049 tokens x
                  // 1024 columns): the ping-pong kernel beats the 64x64 tiles by 10-20 % (tools/scratch/_coarse_gemm.py: 15.9 / 36.3 us
@@ -547,6 +567,13 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
                 "vfm_gemm(bf16): the 4-wave 256x256 kernel needs K >= 128 and operands spanning < 4 GiB");
       VFM_CHECK(cfg < 35 || d->K >= 256, VFM_E_UNSUPPORTED, "vfm_gemm(bf16): the deep-ring 128x128 kernels need K >= 256");
       fd = vfm_gemm_launch_w4(d, s, vec, tail, cfg == 32 ? 4 : (cfg == 33 ? 8 : (cfg == 34 ? 2 : (cfg == 35 ? 3 : 5))));
+      break;
+    case 37:
+    case 38:
+      VFM_CHECK(vfm_gemm_ps_ok(d, cfg == 37 ? 2 : 1), VFM_E_UNSUPPORTED,
+                "vfm_gemm(bf16): the persistent kernel needs M %% 256 == 0, N %% %d == 0, K %% 64 == 0, K >= 576 and a bf16 bias / GELU / multiply epilogue",
+                cfg == 37 ? 256 : 128);
+      fd = vfm_gemm_launch_ps(d, s, tail, cfg == 37 ? 2 : 1);
       break;
     case 30:
       VFM_CHECK(d->K >= 128, VFM_E_UNSUPPORTED, "vfm_gemm(bf16): the ping-pong kernel needs K >= 128");

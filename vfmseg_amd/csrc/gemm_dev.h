@@ -245,6 +245,13 @@ __device__ __forceinline__ void epi_fast(const EpiParams& e, long zoff, f32x16 (
 // Measured inside the train step: the epilogue of the fc1 / fc2-dgrad GEMMs (GELU on 16.8 M values, 64 MB of
 // stores) cost 27-34 us of a 54-59 us launch.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// 16-byte store, nontemporal on request: the store-heavy GEMMs (fc1 forward: 67 MB per launch) lose ~4 us to write-allocated lines
+// that only leave the L2 at the end of the kernel; streamed out as they are produced they overlap the remaining tiles' loops
+__device__ __forceinline__ void st16(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d, int nt) {
+  if (nt) __builtin_nontemporal_store(u32x4_t{a, b, c, d}, reinterpret_cast<u32x4_t*>(p));
+  else *reinterpret_cast<uint4*>(p) = make_uint4(a, b, c, d);
+}
 
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
@@ -381,7 +388,7 @@ __device__ __forceinline__ void epi_fast8(const EpiParams& e, long zoff, f32x16 
         }
       }
       if constexpr (C2MODE != 0) {
-        if (ok) *reinterpret_cast<uint4*>((bf16_t*)e.C2 + zoff + m * e.ldc2 + n) = make_uint4(pack_bf16x2(d[0]), pack_bf16x2(d[1]), pack_bf16x2(d[2]), pack_bf16x2(d[3]));
+        if (ok) st16((bf16_t*)e.C2 + zoff + m * e.ldc2 + n, pack_bf16x2(d[0]), pack_bf16x2(d[1]), pack_bf16x2(d[2]), pack_bf16x2(d[3]), e.nt);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) x[i] = x[i] * s2[i];
@@ -395,7 +402,7 @@ __device__ __forceinline__ void epi_fast8(const EpiParams& e, long zoff, f32x16 
       if (ok) {
         const long o = zoff + m * e.ldc + n;
         if constexpr (CDT == VFM_BF16) {
-          *reinterpret_cast<uint4*>((bf16_t*)e.C + o) = make_uint4(pack_bf16x2(x[0]), pack_bf16x2(x[1]), pack_bf16x2(x[2]), pack_bf16x2(x[3]));
+          st16((bf16_t*)e.C + o, pack_bf16x2(x[0]), pack_bf16x2(x[1]), pack_bf16x2(x[2]), pack_bf16x2(x[3]), e.nt);
         } else {
           float* cp = (float*)e.C + o;
           *reinterpret_cast<float4*>(cp) = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);

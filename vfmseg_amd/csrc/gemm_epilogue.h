@@ -10,6 +10,7 @@ struct EpiParams {
   const void* residual; int r_dt; long ldr;
   int ep_mode; const void* aux; int aux_dt; long ld_aux;
   void* C2; int c2_dt; long ldc2;
+  int nt;   // nontemporal stores of C / C2 in the vector epilogues (large write-once outputs: see g_nt_bytes in gemm_bf16.hip)
 };
 
 static inline EpiParams make_epi(const vfm_gemm_desc* d) {
@@ -21,6 +22,9 @@ static inline EpiParams make_epi(const vfm_gemm_desc* d) {
   e.residual = d->residual; e.r_dt = d->r_dt; e.ldr = d->ldr;
   e.ep_mode = d->ep_mode; e.aux = d->aux; e.aux_dt = d->aux_dt; e.ld_aux = d->ld_aux;
   e.C2 = d->C2; e.c2_dt = d->c2_dt; e.ldc2 = d->ldc2;
+  extern long g_nt_bytes;
+  const long out_bytes = d->M * d->N * (d->c_dt == VFM_BF16 ? 2 : 4) * (d->C2 ? 2 : 1) * (d->batch > 0 ? d->batch : 1);
+  e.nt = g_nt_bytes > 0 && out_bytes >= g_nt_bytes;
   return e;
 }
 
