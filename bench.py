@@ -172,6 +172,65 @@ def eval_leg(device, timer, iters=5):
     return res
 
 
+def parity_leg(device, batch, steps=3, iters=2):
+    """The two modes whose results meet north_star's tolerance (logits <= 1e-3 rel, argmax mismatches only on near-ties against the
+    reference's fp32 CPU path: tests/test_model_gpu.py::test_ms_inference_matches_reference_golden[f32|bf16x3],
+    test_train_step_matches_reference_goldens[f32|bf16x3]) on the same two workloads as the bf16 headline:
+      f32    - exact-fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate) and exact-fp32 attention
+      bf16x3 - the same fp32 data path with every GEMM as ONE bf16 MFMA GEMM over split operands (hi / lo halves, K' = 3 K)"""
+    _heavy()
+    import vfmseg_amd  # noqa: F401
+    from vfmseg_amd import presets
+    from vfmseg_amd.precision import set_compute_dtype
+    from vfmseg_amd.registry import MODELS
+    from vfmseg_amd.synth import synth_image, synth_like
+    out = {"what": "in-tolerance modes (the configurations the 1e-3 / argmax parity tests run in), same workloads as the bf16 lines"}
+    for mode in ("bf16x3", "f32"):
+        res = {}
+        set_compute_dtype(mode)
+        try:
+            print(f"[bench] parity-mode leg: {mode} train step", file=sys.stderr, flush=True)
+            model, ow = build(device, batch)
+            data = make_batch(batch, 0, 0, device)
+            for _ in range(2):
+                model.train_step(data, ow)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                model.train_step(data, ow)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res["train_images_per_s"] = round(batch * steps / dt, 3)
+            res["train_ms_per_step"] = round(1e3 * dt / steps, 2)
+            res["train_steps"] = steps
+            del model, ow, data
+            torch.cuda.empty_cache()
+            print(f"[bench] parity-mode leg: {mode} eval", file=sys.stderr, flush=True)
+            cfg_d = presets.dinov2_ms_masked()
+            cfg_d["test_cfg"]["conf"] = 2.0
+            model = MODELS.build(cfg_d)
+            model.load_state_dict(synth_like(model.state_dict()), strict=False)
+            model = model.to(device).eval()
+            img = synth_image(1, 1024, seed=77).to(device)
+            with torch.no_grad():
+                model.predict(img)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    model.predict(img)
+                torch.cuda.synchronize()
+            res["eval_dinov2_ms_slide_inference_ms_per_img"] = round(1e3 * (time.perf_counter() - t0) / iters, 2)
+            res["eval_iters"] = iters
+            del model
+            torch.cuda.empty_cache()
+        except Exception as e:   # noqa: BLE001
+            res["error"] = repr(e)
+        finally:
+            set_compute_dtype("bf16")
+        out[mode] = res
+    return out
+
+
 def cpu_baseline(seconds_cap=40.0, model_kw=None):
     """The oracle (CPU fp32 restatement of the reference path) timed on this box's host cores: one train step
     (forward_train + backward + AdamW on the trainable tensors), B=1, 1024^2 input -> 2 x 512^2 passes."""
@@ -206,7 +265,16 @@ def cpu_baseline(seconds_cap=40.0, model_kw=None):
         for k, g in zip(tk, grads):
             R.adamw_step(sd[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, 1e-4, 0.05)
     dt = time.time() - t0
-    out = dict(value=1.0 / dt, unit="images/s", cores=cores, kind="port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    out = dict(value=1.0 / dt, unit="images/s", cores=cores, cpu_model=cpu_model, host_cpus=os.cpu_count(), kind="port",
                sample=f"1 train step (fwd+bwd+AdamW), B=1, 1024^2 -> 2x512^2 passes, fp32 torch CPU, {dt:.1f} s")
     if model_kw is None and os.environ.get("VFMSEG_CPU_EXTRAS", "1") != "0":
         # the other CPU timings BASELINE.md section 3 lists (bounded samples): configs[0] = DINOv2-L + LinearHead, 1x512^2, forward + CE
@@ -300,7 +368,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eval", action="store_true", help="skip the eval ms/img @1024x1024 leg (N=1 only)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the f32 parity-mode speed leg (N=1 only)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3"])
     ap.add_argument("--workload", default="ms1024", choices=["ms1024", "single512"],
                     help="ms1024: BASELINE configs[1] (1024^2 sample -> LR + HR 512^2 passes, both heads; the headline metric); "
                          "single512: one 512^2 pass per sample, DINOv2-L + LoRA + LinearHead (SURVEY 8: the labelled single-pass step)")
@@ -450,6 +518,11 @@ def main():
                 out["eval"] = eval_leg(device, timer if not a.no_roofline else None)
             except Exception as e:
                 out["eval"] = {"error": repr(e)}
+        if world == 1 and not a.no_parity_mode and a.workload == "ms1024" and a.dtype == "bf16" and a.depth is None:
+            try:
+                out["parity_mode"] = parity_leg(device, a.batch)
+            except Exception as e:
+                out["parity_mode"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline and a.workload == "ms1024":
             try:
                 out["cpu_baseline"] = cpu_baseline()

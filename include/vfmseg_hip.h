@@ -37,6 +37,12 @@ int vfm_abi_version(void);
 /* dst[r,c] = src[r,c] * (colscale ? colscale[c] : 1)          (casts; LayerScale prologue for dgrad) */
 int vfm_cast(const void* src, int src_dt, long ld_src, void* dst, int dst_dt, long ld_dst, long rows, long cols,
              const float* colscale, void* stream);
+/* Split-bf16 ("bf16 x 3") form of an fp32 GEMM operand: src[rows, K] fp32 with element strides (stride_r, stride_c) -> dst[rows, 3 Kp] bf16,
+ * Kp = ceil64(K): pattern 0 = [hi | hi | lo] (A side), 1 = [hi | lo | hi] (B side), hi = bf16(x), lo = bf16(x - hi), zero pad columns.
+ * vfm_gemm over K' = 3 Kp of two such operands is the fp32 product to ~2^-16 relative per term (fp32 accumulate) at the bf16 MFMA rate / 3:
+ * the parity configuration's GEMMs without the 157-TFLOP/s fp32 MFMA (replaces cuBLAS fp32 Linear of the reference's CPU / fp32 path;
+ * rein/models/backbones/dino_layers/attention.py:51-58, mlp.py:34-40 in fp32). */
+int vfm_split3(const float* src, long stride_r, long stride_c, void* dst, long ld_dst, long rows, long K, int pattern, void* stream);
 /* dst[c, r] = src[r, c] for r<rows, c<cols; dst has ld_dst >= rows, columns rows..pad_rows-1 are zero-filled.
  * Used to feed weight-gradient GEMMs (reduction over tokens) to the NT GEMM. */
 int vfm_transpose(const void* src, int src_dt, long ld_src, void* dst, int dst_dt, long ld_dst, long rows, long cols,
@@ -202,6 +208,11 @@ typedef struct vfm_attn_desc {
 } vfm_attn_desc;
 int vfm_attn_fwd(const vfm_attn_desc* d, void* stream);
 int vfm_attn_bwd(const vfm_attn_desc* d, void* stream);
+/* Split-bf16 ("bf16 x 3") forward, head dim 64: q / o fp32 (dt = VFM_F32), k / v SPLIT bf16 operands as vfm_split3(pattern 1) writes them
+ * for K = H*64 - the hi half of head h at columns h*64.., the lo half at lo_off + h*64.. (lo_off >= H*64).  S = q k^T and O = P v are
+ * computed as hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation, softmax and output in fp32: the exact-fp32 attention of the
+ * parity configuration (rein/models/backbones/dino_layers/attention.py:73-89 in fp32) to ~1e-5 at MFMA speed.  lse as vfm_attn_fwd. */
+int vfm_attn_fwd_x3(const vfm_attn_desc* d, long lo_off, void* stream);
 
 /* ---- SAM (ViTDet) windowed attention with decomposed relative-position bias (sam_vit.py:273-430) --------------
  * The bias q.Rh[qh,kh] + q.Rw[qw,kw] is folded into augmented operands so the attention is batched GEMMs + softmax:

@@ -419,6 +419,40 @@ def test_gemm_bf16_configs_fast_epilogues(cfg, M, N, K):
         ops.tune("gemm_cfg", -1)
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb", [(4100, 1024, 1024, False, False), (300, 200, 192, True, False), (513, 64, 100, False, True), (64, 19, 27, True, True)])
+def test_gemm_split_bf16x3(M, N, K, ta, tb):
+    """The bf16 x 3 form of an fp32 GEMM (vfm_split3 + one bf16 MFMA GEMM over K' = 3 ceil64(K)): hi / lo halves are exact bf16
+    roundings, and the product agrees with float64 to ~2^-16 - 100x closer than a plain bf16 GEMM, 100x inside the 1e-3 budget."""
+    from vfmseg_amd.precision import set_compute_dtype
+    a, b = rnd(M, K, seed=70), rnd(N, K, seed=71)
+    bias, res = rnd(N, seed=72), rnd(M, N, seed=73)
+    ref = a.double() @ b.double().t() + bias.double() + res.double()
+    ad = (a.t().contiguous() if ta else a).to(DEV)
+    bd = (b.t().contiguous() if tb else b).to(DEV)
+    x3 = ops.split3(ad, 0, trans=ta)
+    kp = (K + 63) // 64 * 64
+    hi = x3[:, :kp].float().cpu()[:, :K]
+    lo = x3[:, 2 * kp:].float().cpu()[:, :K]
+    assert torch.equal(hi, a.bfloat16().float()) and torch.equal(x3[:, kp:2 * kp].float().cpu()[:, :K], hi)
+    assert torch.equal(lo, (a - hi).bfloat16().float())
+    assert x3[:, K:kp].abs().sum() == 0
+    set_compute_dtype("bf16x3")
+    try:
+        c = torch.full((M, N), float("nan"), device=DEV)
+        ops.gemm(ad, bd, c, bias=bias.to(DEV), residual=res.to(DEV), trans_a=ta, trans_b=tb)
+        e3 = relerr(c, ref)
+    finally:
+        set_compute_dtype("bf16")
+    c16 = torch.empty(M, N, device=DEV)
+    kpad = (-K) % 64
+    a16 = F.pad(a, (0, kpad)).bfloat16().to(DEV)
+    b16 = F.pad(b, (0, kpad)).bfloat16().to(DEV)
+    ops.gemm(a16, b16, c16, bias=bias.to(DEV), residual=res.to(DEV))
+    e1 = relerr(c16, ref)
+    print(f"[parity] split-bf16 GEMM {M}x{N}x{K}: rel err {e3:.2e} (plain bf16 operands: {e1:.2e})")
+    assert e3 < 3e-5 and e3 < e1 / 50
+
+
 @pytest.mark.parametrize("cfg", [37, 38])
 @pytest.mark.parametrize("M,N,K", [(4100, 4096, 1024), (512, 256, 640), (1024, 2048, 1088), (256, 256, 4096), (4356, 768, 576)])
 def test_gemm_bf16_persistent_two_accumulators(cfg, M, N, K):
@@ -565,6 +599,46 @@ def test_attention(dt, nq_extra, nk_extra, nq, nk, B1024):
     assert relerr(dq.float(), scatter(qq.grad, nq, nq_extra)) < tol * 2
     assert relerr(dk.float(), scatter(kk.grad, nk, nk_extra)) < tol * 2
     assert relerr(dv.float(), scatter(vv.grad, nk, nk_extra)) < tol * 2
+
+
+@pytest.mark.parametrize("nq_extra,nk_extra,nq,nk,B,H", [(1, 1, 200, 200, 2, 3), (0, 0, 130, 70, 2, 3), (1, 1, 1024, 1024, 3, 8), (0, 0, 256, 320, 1, 16)])
+def test_attention_split_bf16x3_forward(nq_extra, nk_extra, nq, nk, B, H):
+    """vfm_attn_fwd_x3 (bf16x3 mode: fp32 in / out, every product as hi*hi + hi*lo + lo*hi on the bf16 MFMA) against float64 softmax
+    attention: ~1e-5, where the plain bf16 kernel sits at ~1e-2; lse too (the exact-fp32 backward consumes it); a spike in the later
+    keys forces the lazy-rescale branch."""
+    from vfmseg_amd.precision import set_compute_dtype
+    d, hd = 64, H * 64
+    q = rnd(B * nq + B * nq_extra, hd, seed=42)
+    k = rnd(B * nk + B * nk_extra, hd, seed=43)
+    k[B * nk // 2: B * nk // 2 + 7] *= 4.0
+    k[B * nk - 5: B * nk] *= 6.0
+    v = rnd(B * nk + B * nk_extra, hd, seed=44)
+
+    def gather(t, n, ne):
+        main = t[: B * n].reshape(B, n, H, d)
+        if ne:
+            main = torch.cat([main, t[B * n:].reshape(B, 1, H, d)], 1)
+        return main.permute(0, 2, 1, 3).double()
+
+    qq, kk, vv = gather(q, nq, nq_extra), gather(k, nk, nk_extra), gather(v, nk, nk_extra)
+    sc = (qq @ kk.transpose(-1, -2)) * d ** -0.5
+    ref = sc.softmax(-1) @ vv
+    ref_lse = torch.logsumexp(sc, -1)
+    g = ref.permute(0, 2, 1, 3)
+    ref_tok = torch.cat([g[:, :nq].reshape(B * nq, hd), g[:, nq:].reshape(B * nq_extra, hd)], 0) if nq_extra else g.reshape(B * nq, hd)
+    # K and V as column slices of a packed [rows, 3 hd] buffer, as the backbones pass them
+    packed = torch.cat([q if nq == nk and nq_extra == nk_extra else torch.zeros(k.shape[0], hd), k, v], 1).to(DEV)
+    o = torch.full(q.shape, float("nan"), device=DEV)
+    lse = torch.empty(B, H, nq + nq_extra, device=DEV)
+    set_compute_dtype("bf16x3")
+    try:
+        ops.attn_fwd(q.to(DEV), packed[:, hd:2 * hd], packed[:, 2 * hd:], o, lse, B, H, d, nq, nq_extra, nk, nk_extra, d ** -0.5)
+    finally:
+        set_compute_dtype("bf16")
+    e = relerr(o, ref_tok)
+    el = (lse.double().cpu() - ref_lse).abs().max().item()
+    print(f"[parity] split-bf16 attention fwd nq {nq}+{nq_extra} nk {nk}+{nk_extra}: out rel err {e:.2e}, lse abs err {el:.2e}")
+    assert e < 5e-5 and el < 2e-5 * max(1.0, ref_lse.abs().max().item()) + 1e-4   # (spiked keys: |lse| ~ 30)
 
 
 def test_attention_fwd64_experimental():

@@ -79,7 +79,7 @@ def test_heads_match_reference_goldens(golden_dir):
         set_compute_dtype("bf16")
 
 
-@pytest.mark.parametrize("mode,ltol,gtol", [("f32", 2e-4, 5e-3), ("bf16", 3e-2, 1.5e-1)])
+@pytest.mark.parametrize("mode,ltol,gtol", [("f32", 2e-4, 5e-3), ("bf16x3", 2e-4, 5e-3), ("bf16", 3e-2, 1.5e-1)])
 def test_train_step_matches_reference_goldens(golden_dir, mode, ltol, gtol):
     """Full forward_train + backward (B=2, 1024^2 -> 2x512^2 passes) against tests/golden/train_step.npz, which was
     produced by the reference's own MsVFMEncoderDecoder."""
@@ -126,12 +126,14 @@ def test_train_step_matches_reference_goldens(golden_dir, mode, ltol, gtol):
         set_compute_dtype("bf16")
 
 
-def test_ms_inference_matches_reference_golden(golden_dir):
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_ms_inference_matches_reference_golden(golden_dir, mode):
     """Coarse-to-fine gated sliding inference (one 1024^2 image) vs the reference's own ms_inference output: which
-    windows were refined, logits, and the argmax mask."""
+    windows were refined, logits, and the argmax mask - in the exact-fp32 mode and in the split-bf16 (bf16 x 3) mode, the two
+    configurations that claim north_star's tolerance (logits <= 1e-3 relative, argmax mismatches only on near-ties)."""
     import hashlib
     G = np.load(os.path.join(golden_dir, "ms_inference.npz"))
-    set_compute_dtype("f32")
+    set_compute_dtype(mode)
     try:
         sd = cached_full_state_dict()
         model = MODELS.build(presets.dinov2_ms_masked()).cuda()
@@ -147,8 +149,16 @@ def test_ms_inference_matches_reference_golden(golden_dir):
         assert rel_err(sl(logits), G["logits_slice"]) < 1e-3
         assert rel_err(logits[0, :, 500:504, 636:644], G["logits_center"]) < 1e-3
         pred = out[0].pred_sem_seg.data[0].cpu().numpy().astype(np.uint8)
-        mism = (pred[::4, ::4] != G["pred_sub4"]).mean()
+        diff = pred[::4, ::4] != G["pred_sub4"]
+        mism = diff.mean()
         assert mism < 2e-4, mism   # only near-tie pixels (top-2 margin ~1e-5) may flip between fp32 evaluation orders
+        # ... and every flipped pixel IS a near-tie: its top-2 logit margin is a vanishing fraction of the logit range
+        top2 = torch.topk(logits[0, :, ::4, ::4], 2, dim=0).values
+        margin = ((top2[0] - top2[1]) / (logits.max() - logits.min())).cpu().numpy()
+        worst = float(margin[diff].max()) if diff.any() else 0.0
+        print(f"[parity] ms_inference {mode}: logits rel err {rel_err(sl(logits), G['logits_slice']):.2e}, argmax mismatches {mism:.2e} "
+              f"({int(diff.sum())} of {diff.size} sampled pixels), largest top-2 margin among them {worst:.2e} of the logit range")
+        assert worst < 1e-4, worst
         if hashlib.sha256(pred.tobytes()).hexdigest() != str(G["pred_sha256"]):
             hist = np.bincount(pred.reshape(-1), minlength=19)
             assert np.abs(hist - G["pred_hist"]).sum() < 200

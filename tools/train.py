@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--launcher", choices=["none", "pytorch", "slurm", "mpi"], default="none")
     ap.add_argument("--local_rank", "--local-rank", type=int, default=0)
     ap.add_argument("--max-iters", type=int, default=None)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3"])
     ap.add_argument("--data", choices=["auto", "synthetic", "real"], default="auto",
                     help="auto: read train_dataloader.dataset when its data_root exists, else the synthetic 19-class stream")
     a = ap.parse_args()

@@ -55,6 +55,53 @@ extern "C" int vfm_cast(const void* src, int src_dt, long ld_src, void* dst, int
   return VFM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ split-bf16 operands
+// An fp32 GEMM operand X[rows, K] (any strides) as three bf16 K-segments of Kp = ceil64(K) columns each, so that ONE bf16 MFMA GEMM over
+// K' = 3 Kp computes  sum_k (a_hi b_hi + a_hi b_lo + a_lo b_hi)  with fp32 accumulation - the "bf16 x 3" form of an fp32 product
+// (hi = bf16(x), lo = bf16(x - hi): 16 significant bits between them; the dropped a_lo b_lo term is 2^-18 relative):
+//     pattern 0 (the A side): [hi | hi | lo]        pattern 1 (the B side): [hi | lo | hi]
+// Columns K .. Kp-1 of every segment are zero.  Rounding is RNE on both halves (plain casts: v_cvt_pk_bf16_f32).
+__global__ void k_split3(const float* __restrict__ src, long sr, long sc, bf16_t* __restrict__ dst, long ld_dst, long rows, long K, long Kp,
+                         int pattern) {
+  const long per_row = Kp / 4;
+  const long total = rows * per_row;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / per_row, c = (i % per_row) * 4;
+    float v[4];
+    if (sc == 1 && c + 3 < K && ((reinterpret_cast<uintptr_t>(src + r * sr + c) & 15) == 0)) {
+      const float4 f = *reinterpret_cast<const float4*>(src + r * sr + c);
+      v[0] = f.x, v[1] = f.y, v[2] = f.z, v[3] = f.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (c + e < K) ? src[r * sr + (c + e) * sc] : 0.f;
+    }
+    ushort4 hi, lo;
+    bf16_t* ph = &hi.x;
+    bf16_t* pl = &lo.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ph[e] = f32_to_bf16(v[e]);
+      pl[e] = f32_to_bf16(v[e] - bf16_to_f32(ph[e]));
+    }
+    bf16_t* d = dst + r * ld_dst + c;
+    *reinterpret_cast<ushort4*>(d) = hi;
+    *reinterpret_cast<ushort4*>(d + Kp) = pattern == 0 ? hi : lo;
+    *reinterpret_cast<ushort4*>(d + 2 * Kp) = pattern == 0 ? lo : hi;
+  }
+}
+
+extern "C" int vfm_split3(const float* src, long stride_r, long stride_c, void* dst, long ld_dst, long rows, long K, int pattern, void* stream) {
+  const long Kp = (K + 63) / 64 * 64;
+  VFM_CHECK(rows >= 0 && K > 0 && ld_dst >= 3 * Kp && ld_dst % 4 == 0 && ((uintptr_t)dst % 8) == 0 && (pattern == 0 || pattern == 1), VFM_E_SHAPE,
+            "vfm_split3: dst must hold rows x 3 ceil64(K) bf16 (ld %% 4 == 0, 8-byte aligned)");
+  if (rows == 0) return VFM_OK;
+  const long total = rows * (Kp / 4);
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_split3, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, stride_r, stride_c, (bf16_t*)dst, ld_dst, rows, K, Kp, pattern);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ transpose
 // 64x64 tiles through LDS (+1 pad): coalesced reads along cols, coalesced writes along rows.
 template <typename TI, typename TO>

@@ -49,6 +49,7 @@ class AttnDesc(C.Structure):
 # name -> argtypes (return type is always int); mirrors include/vfmseg_hip.h
 SIGNATURES = {
     "vfm_cast": [vp, ci, cl, vp, ci, cl, cl, cl, vp, vp],
+    "vfm_split3": [vp, cl, cl, vp, cl, cl, cl, ci, vp],
     "vfm_transpose": [vp, ci, cl, vp, ci, cl, cl, cl, cl, vp],
     "vfm_strided_copy": [vp, ci, vp, ci] + [cl] * 12 + [ci, vp],
     "vfm_strided_copy_batch": [vp, ci, cl, vp],
@@ -82,6 +83,7 @@ SIGNATURES = {
     "vfm_gemm": [C.POINTER(GemmDesc), vp],
     "vfm_tune": [C.c_char_p, ci],
     "vfm_attn_fwd": [C.POINTER(AttnDesc), vp],
+    "vfm_attn_fwd_x3": [C.POINTER(AttnDesc), cl, vp],
     "vfm_attn_bwd": [C.POINTER(AttnDesc), vp],
     "vfm_sam_relpos_table": [vp, ci, ci, ci, vp, vp],
     "vfm_sam_attn_prep": [vp, ci, cl, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp],

@@ -329,10 +329,38 @@ def bn_bwd_apply(dy, x, mean_var, w, b, eps, act, sums_dy, total_rows, dx):
     return dx
 
 
+def split3(x, pattern, trans=False, cache=False):
+    """fp32 operand x [rows, K] ([K, rows] if trans) -> bf16 [rows, 3 ceil64(K)] split form (vfm_split3).  cache=True keeps the result on
+    the tensor OBJECT (weights packed once by the engines: same object every call) and rebuilds it when the tensor's version counter
+    moves (LoRA-merged weights are re-packed in place); activations are fresh objects and never hit."""
+    if cache:
+        from .optim import PARAM_EPOCH   # the fused AdamW / LoRA re-pack kernels rewrite packed operands behind torch's version counters
+        key = (PARAM_EPOCH[0], x._version, x.data_ptr(), pattern, trans, tuple(x.shape), tuple(x.stride()))
+        hit = getattr(x, "_vfm_split3", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+    rows, K = (x.shape[1], x.shape[0]) if trans else (x.shape[0], x.shape[1])
+    sr, sc = (x.stride(1), x.stride(0)) if trans else (x.stride(0), x.stride(1))
+    kp = (K + 63) // 64 * 64
+    out = torch.empty(rows, 3 * kp, dtype=torch.bfloat16, device=x.device)
+    L.check(L.load().vfm_split3(L.ptr(x), sr, sc, L.ptr(out), out.stride(0), rows, K, pattern, L.stream()), "vfm_split3")
+    if cache:
+        try:
+            x._vfm_split3 = (key, out)
+        except AttributeError:
+            pass
+    return out
+
+
 def gemm(a, b, c, *, alpha=1.0, bias=None, bias_mod=0, colscale=None, residual=None, ep_mode=EP_NONE, aux=None, c2=None,
          trans_a=False, trans_b=False, kb_rows=0):
     """c[M,N] = epilogue(alpha * A @ B^T).  a: [M,K] (or [K,M] if trans_a), b: [N,K] (or [K,N] if trans_b); 2-D views
-    (or 3-D batched with equal batch).  bf16 inputs require K-contiguous operands with K % 64 == 0."""
+    (or 3-D batched with equal batch).  bf16 inputs require K-contiguous operands with K % 64 == 0.
+    In the bf16x3 mode (precision.split3()) an fp32 x fp32 2-D product is computed by the bf16 MFMA kernels on split operands."""
+    if a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and not kb_rows and _split3_on():
+        a3 = split3(a, 0, trans=trans_a)
+        b3 = split3(b, 1, trans=trans_b, cache=not b.requires_grad)
+        return gemm(a3, b3, c, alpha=alpha, bias=bias, bias_mod=bias_mod, colscale=colscale, residual=residual, ep_mode=ep_mode, aux=aux, c2=c2)
     lib = L.load()
     d = L.GemmDesc()
     batched = a.dim() == 3
@@ -503,6 +531,11 @@ def gemm_tn_batched(xs, y, out, valid_rows, alpha=1.0):
     return out
 
 
+def _split3_on():
+    from .precision import split3 as _s3
+    return _s3()
+
+
 def tune(key, value):
     lib = L.load()
     L.check(lib.vfm_tune(key.encode(), int(value)), "vfm_tune")
@@ -526,6 +559,13 @@ _attn_bwd_ws = {}
 def attn_fwd(q, k, v, o, lse, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale):
     """q,k,v,o: 2-D row-major views [rows, >=H*d] (column slices of a packed qkv buffer are fine)."""
     lib = L.load()
+    if q.dtype == torch.float32 and d == 64 and _split3_on() and k.shape[1] == H * d and v.shape[1] == H * d:
+        # bf16x3 mode: K and V as split bf16 operands ([hi | lo | hi] per row), Q split in the kernel, fp32 softmax and output
+        k3, v3 = split3(k, 1), split3(v, 1)
+        a = _attn_desc(q, k3, v3, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, lse)
+        a.dt = L.dt_of(q)
+        L.check(lib.vfm_attn_fwd_x3(C.byref(a), H * d, L.stream()), "vfm_attn_fwd_x3")
+        return o
     a = _attn_desc(q, k, v, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, lse)
     fin = None
     if PROFILE is not None and q.dtype == torch.bfloat16:   # QK^T + PV: 4 B H Nq Nk d

@@ -4,14 +4,22 @@ bf16  - MFMA bf16 GEMMs / flash attention with fp32 accumulation, fp32 residual 
         (the throughput configuration; BASELINE.json asks for bf16 MFMA).
 f32   - exact-fp32 MFMA GEMMs and attention (the parity configuration: <=1e-3 rel logits, bit-exact argmax vs the
         reference's fp32 CPU path).
+bf16x3 - the f32 configuration (fp32 tensors, exact-fp32 attention / norms / losses) with every fp32 GEMM computed as ONE bf16 MFMA
+        GEMM over split operands ([hi | hi | lo] x [hi | lo | hi], K' = 3 K, fp32 accumulate; ops.gemm / vfm_split3): 16 significant bits
+        per operand instead of 24 - products to ~2^-16 relative, three orders inside north_star's 1e-3 - at a third of the bf16 GEMM
+        rate instead of the fp32 MFMA's 1/16.  The in-tolerance mode with a usable speed.
 """
 import torch
 
 _compute = torch.bfloat16
+_split3 = False
 
 
 def set_compute_dtype(dt):
-    global _compute
+    global _compute, _split3
+    _split3 = isinstance(dt, str) and dt in ("bf16x3", "split3")
+    if _split3:
+        dt = "f32"
     if isinstance(dt, str):
         dt = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32,
               "float32": torch.float32}[dt]
@@ -25,3 +33,12 @@ def compute_dtype():
 
 def is_bf16():
     return _compute == torch.bfloat16
+
+
+def split3():
+    """True in the bf16x3 mode: fp32 GEMMs run as split-bf16 MFMA GEMMs."""
+    return _split3
+
+
+def mode_name():
+    return "bf16x3" if _split3 else ("bf16" if _compute == torch.bfloat16 else "f32")
