@@ -268,6 +268,39 @@ def gen_ms_inference(model):
     print("ms_inference refined", len(refined), "of 9;", out["pred_sha256"], out["pred_hist"])
 
 
+def gen_slide_modes(model):
+    """The other three test modes of MsVFMEncoderDecoder.inference (Ms_VFM_encoder_decoder.py:278-332) on one 1024^2 image, run by the
+    reference's own code: lr_slide_inference (the class default), hr_slide_inference, msfull_slide_inference.  msfull draws a query mask
+    per refined window (torch.rand in MaskTransformerDecoder.forward, Transformer.py:265): recorded, so that the oracle and the HIP
+    path can inject the same masks."""
+    out = {}
+    img = synth_image(1, 1024, seed=11)
+    metas = [dict(ori_shape=(1024, 1024), img_shape=(1024, 1024), pad_shape=(1024, 1024), padding_size=[0, 0, 0, 0])]
+    out["test_cfg_stride_crop"] = np.array(list(model.test_cfg["stride"]) + list(model.test_cfg["crop_size"]))
+    for mode in ("lr_slide_inference", "hr_slide_inference", "msfull_slide_inference"):
+        reset(model)
+        model.eval()
+        model.test_cfg["mode"] = mode
+        with RandRecorder() as rr, torch.no_grad():
+            logits = model.inference(img, metas)
+        if mode == "msfull_slide_inference":
+            assert len(rr.vals) == 9 and tuple(rr.vals[0].shape) == (1, 1, 32, 32), [tuple(v.shape) for v in rr.vals]
+            out["msfull_mask_rand"] = torch.stack(rr.vals).reshape(9, 32, 32).numpy().astype(np.float32)
+        else:
+            assert len(rr.vals) == 0, "lr / hr slide run the LinearHead only: no query mask"
+        assert tuple(logits.shape) == (1, 19, 1024, 1024)
+        pred = logits.argmax(dim=1)[0].numpy().astype(np.uint8)
+        out[mode + "::logits_stats"] = stats(logits)
+        out[mode + "::logits_slice"] = sl(logits)
+        out[mode + "::logits_center"] = logits[0, :, 500:504, 636:644].numpy().copy()
+        out[mode + "::pred_sub4"] = pred[::4, ::4].copy()
+        out[mode + "::pred_sha256"] = np.array(mask_digest(pred))
+        out[mode + "::pred_hist"] = np.bincount(pred.reshape(-1), minlength=19)
+        print(mode, out[mode + "::logits_stats"], out[mode + "::pred_sha256"])
+    model.test_cfg["mode"] = "ms_slide_inference"
+    np.savez_compressed(os.path.join(GOLD, "slide_modes.npz"), **out)
+
+
 def gen_eva02(_model=None):
     """EVA02-L + LoRA (q/k/v/attn.proj targets; only attn.proj is live): taps and LoRA gradients."""
     M = ref_shim.load_eva02()
@@ -418,7 +451,7 @@ def main():
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
-    steps = dict(dinov2=gen_dinov2, heads=gen_heads, train_step=gen_train_step, ms_inference=gen_ms_inference)
+    steps = dict(dinov2=gen_dinov2, heads=gen_heads, train_step=gen_train_step, ms_inference=gen_ms_inference, slide_modes=gen_slide_modes)
     model = build_reference_model() if a.only in (None,) + tuple(steps) else None  # noqa: E501
     for name, fn in steps.items():
         if a.only in (None, name):

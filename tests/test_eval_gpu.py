@@ -1,6 +1,8 @@
 """SURVEY 8 row f1 on the HIP path: confusion-histogram kernel, IoUMetric / DGIoUMetric (per-dataset grouping, mean_* keys),
 postprocess_result (un-pad, flip undo, resize to ori_shape), the lr / msfull sliding modes, and the north_star target
 "mIoU within +-0.1 of reference on a fixed synthetic batch" stated from HIP predictions vs oracle predictions."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -9,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 import vfmseg_amd  # noqa: E402,F401
 from oracle import torch_ref as R  # noqa: E402
-from tests.helpers import full_state_dict, rel_err  # noqa: E402
+from tests.helpers import full_state_dict, rel_err, sl  # noqa: E402
 from vfmseg_amd import metrics as M, ops, presets  # noqa: E402
 from vfmseg_amd.precision import set_compute_dtype  # noqa: E402
 from vfmseg_amd.registry import METRICS, MODELS  # noqa: E402
@@ -146,6 +148,40 @@ def test_lr_and_msfull_slide_modes_match_oracle():
         set_compute_dtype("bf16")
 
 
+# (bf16 bounds = 3x the measured values: logits 8.6e-3, mismatches 8.3e-3, margin 3.2e-3 - profiles/r03_parity_*.log)
+@pytest.mark.parametrize("prec,ltol,mtol", [("f32", 1e-3, 2e-4), ("bf16x3", 1e-3, 2e-4), ("bf16", 2.6e-2, 2.5e-2)])
+def test_slide_modes_match_reference_goldens(golden_dir, prec, ltol, mtol):
+    """lr_slide_inference / hr_slide_inference / msfull_slide_inference at full depth on the HIP path against the reference's OWN
+    MsVFMEncoderDecoder.inference output in those modes (tests/golden/slide_modes.npz; Ms_VFM_encoder_decoder.py:278-332), msfull with
+    the reference's recorded query masks.  f32 and bf16x3 claim north_star's tolerance; bf16 (the timed mode) is measured and bounded."""
+    from tests.helpers import cached_full_state_dict
+    G = np.load(os.path.join(golden_dir, "slide_modes.npz"))
+    set_compute_dtype(prec)
+    try:
+        model = MODELS.build(presets.dinov2_ms_masked())
+        model.load_state_dict(cached_full_state_dict(), strict=False)
+        model = model.cuda().eval()
+        img = synth_image(1, 1024, seed=11).cuda()
+        for mode in ("lr_slide_inference", "hr_slide_inference", "msfull_slide_inference"):
+            model.test_cfg["mode"] = mode
+            model.aux_decoder.transformer_decoder.fixed_keep = (
+                torch.from_numpy(G["msfull_mask_rand"]).reshape(9, 1, 32, 32) > 0.2 if mode == "msfull_slide_inference" else None)
+            with torch.no_grad():
+                out = model.predict(img)
+            logits = out[0].seg_logits.data.unsqueeze(0)
+            e1, e2 = rel_err(sl(logits), G[mode + "::logits_slice"]), rel_err(logits[0, :, 500:504, 636:644], G[mode + "::logits_center"])
+            pred = out[0].pred_sem_seg.data[0].cpu().numpy().astype(np.uint8)
+            diff = pred[::4, ::4] != G[mode + "::pred_sub4"]
+            top2 = torch.topk(logits[0, :, ::4, ::4], 2, dim=0).values
+            margin = ((top2[0] - top2[1]) / (logits.max() - logits.min())).cpu().numpy()
+            worst = float(margin[diff].max()) if diff.any() else 0.0
+            print(f"[parity] {mode} {prec}: logits rel err {max(e1, e2):.2e}, argmax mismatches {diff.mean():.2e}, largest top-2 margin among them {worst:.2e}")
+            assert max(e1, e2) < ltol and diff.mean() < mtol
+            assert worst < (1e-4 if prec != "bf16" else 1e-2)   # every flipped pixel is a near-tie at that mode's precision
+    finally:
+        set_compute_dtype("bf16")
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_miou_within_0p1_of_oracle_on_fixed_synthetic_batch(mode):
     """north_star: "mIoU within +-0.1 of reference on a fixed synthetic batch".  Predictions of the HIP path (ms_slide_inference,
@@ -165,6 +201,64 @@ def test_miou_within_0p1_of_oracle_on_fixed_synthetic_batch(mode):
             ref_batches.append([(ref.argmax(1)[0], lab[0, 0], f"citys/{i}.png")])
         got, want = metric.evaluate(3), R.dg_iou_metrics(ref_batches, ["citys"])
         print(f"[mIoU {mode}] HIP {got} | oracle {want}")
+        for k in ("citys_mIoU", "citys_mAcc", "citys_aAcc", "mean_mIoU"):
+            assert abs(got[k] - want[k]) <= 0.1, (k, got[k], want[k])
+    finally:
+        set_compute_dtype("bf16")
+
+
+def _colour_coded(seed, size=1024):
+    """A synthetic sample whose image carries its label: every class has a colour, plus noise - something a few dozen optimiser steps
+    can learn, so that mIoU is measured at an operating point where predictions carry signal (random-init weights score ~2 %)."""
+    lab = synth_label(1, size, seed=seed)
+    g = torch.Generator().manual_seed(9000 + seed)
+    table = torch.randn(256, 3, generator=torch.Generator().manual_seed(77)) * 1.5
+    img = table[lab[0, 0].clamp(max=255)].permute(2, 0, 1).unsqueeze(0) + 0.3 * torch.randn(1, 3, size, size, generator=g)
+    return img.contiguous(), lab
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
+def test_miou_after_training_within_0p1_of_oracle(mode):
+    """Round-2 verdict: the +-0.1 mIoU target was only tested at random-init weights (mIoU 2.3 % on both sides).  Here a depth-4 model is
+    first trained for 60 optimiser steps (product train_step, bf16, lr 1e-3) on three colour-coded 1024^2 samples; the trained weights
+    then score the same images through ms_slide_inference on the HIP path (mode under test) and through the oracle, both against the
+    labels with DGIoUMetric semantics."""
+    from vfmseg_amd.optim import PEFTOptimWrapperConstructor
+    set_compute_dtype("bf16")
+    depth = 4
+    kw = dict(depth=depth, out_indices=(0, 1, 2, 3))
+    try:
+        cfg = presets.dinov2_ms_masked(depth=depth)
+        cfg["backbone"]["backbone"]["out_indices"] = [0, 1, 2, 3]
+        model = MODELS.build(cfg)
+        model.load_state_dict(full_state_dict(depth=depth))
+        model = model.cuda().train()
+        oc = presets.optim_cfg()
+        oc["optim_wrapper"]["optimizer"]["lr"] = 1e-3
+        ow = PEFTOptimWrapperConstructor(oc["optim_wrapper"])(model, oc["param_scheduler"])
+        np.random.seed(5)
+        samples = [_colour_coded(400 + i) for i in range(3)]
+        for t in range(60):
+            img, lab = samples[t % 3]
+            model.train_step(dict(inputs=img.cuda(), data_samples=[SegDataSample(gt_sem_seg=lab[0])]), ow)
+        sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+        set_compute_dtype(mode)
+        model = MODELS.build(cfg)
+        model.load_state_dict(sd)
+        model = model.cuda().eval()
+        model.test_cfg["mode"] = "ms_slide_inference"
+        metric = METRICS.build(dict(type="DGIoUMetric", dataset_keys=["citys"]))
+        ref_batches, flips = [], []
+        for i, (img, lab) in enumerate(samples):
+            with torch.no_grad():
+                out = model.predict(img.cuda(), [SegDataSample(gt_sem_seg=lab[0].cuda(), metainfo=dict(seg_map_path=f"citys/{i}.png", ori_shape=(1024, 1024)))])
+                ref = R.ms_inference(sd, img, thr=model.test_cfg["threadshod"], conf=model.test_cfg["conf"], **kw)
+            metric.process(None, out)
+            ref_batches.append([(ref.argmax(1)[0], lab[0, 0], f"citys/{i}.png")])
+            flips.append((out[0].pred_sem_seg.data[0].cpu().long() != ref.argmax(1)[0]).float().mean().item())
+        got, want = metric.evaluate(3), R.dg_iou_metrics(ref_batches, ["citys"])
+        print(f"[parity] mIoU after 60 train steps, {mode}: HIP {got} | oracle {want} | argmax mismatches {max(flips):.2e}")
+        assert want["citys_mIoU"] > 10.0, "the trained model must carry signal for this test to mean anything"
         for k in ("citys_mIoU", "citys_mAcc", "citys_aAcc", "mean_mIoU"):
             assert abs(got[k] - want[k]) <= 0.1, (k, got[k], want[k])
     finally:

@@ -184,8 +184,11 @@ def test_sam_slide_inference_bf16_vs_oracle():
     assert e < 4e-2 and frac < 1e-2 and worst < 4e-2
 
 
-@pytest.mark.parametrize("mode,ptol,ltol", [("f32", 2e-3, 3e-4), ("bf16", 2e-1, 3e-2)])
-def test_three_train_steps_match_oracle(mode, ptol, ltol):
+# measured (profiles/r03_parity_train_step.log): bulk update error f32 <= 4e-4, bf16 <= 5.1e-2; cosine of the update f32 1.0000, bf16 >= 0.9785
+# (Adam's first steps are sign-like, so element-wise maxima are O(1) in bf16 whenever a near-zero gradient flips: direction and bulk are
+# what the optimiser's output can be held to)
+@pytest.mark.parametrize("mode,ptol,ltol,ctol", [("f32", 2e-3, 3e-4, 0.9999), ("bf16", 1.5e-1, 1e-2, 0.95)])
+def test_three_train_steps_match_oracle(mode, ptol, ltol, ctol):
     """Three full iterations (forward_train, backward, the product's PEFTOptimWrapperConstructor groups, fused AdamW, PolyLR,
     SyncBN running stats) on a depth-4 model vs the oracle's train_step: per-iteration losses, the UPDATE of every probed
     parameter (param_after - param_before, which is what the optimiser produces), and the BN running statistics."""
@@ -230,10 +233,17 @@ def test_three_train_steps_match_oracle(mode, ptol, ltol):
             assert dr.abs().max() > 0
         print(f"[3 train steps {mode}] update rel err", {k.split('.')[-3] + '.' + k.split('.')[-1]: f"{v:.1e}" for k, v in worst.items()})
         # Adam's first steps are sign-like (g / sqrt(g^2)): a handful of near-zero gradients flip in bf16; bound the bulk instead
+        bulks, coss = {}, {}
         for k in probes:
-            du, dr = got[k] - sd0[k], sdo[k] - sd0[k]
-            bulk = ((du - dr).abs().mean() / dr.abs().mean()).item()
-            assert bulk < ptol, (k, bulk)
+            du, dr = (got[k] - sd0[k]).double().flatten(), (sdo[k] - sd0[k]).double().flatten()
+            bulks[k] = ((du - dr).abs().mean() / dr.abs().mean()).item()
+            coss[k] = (du @ dr / (du.norm() * dr.norm()).clamp_min(1e-300)).item()
+        short = lambda k: k.split('.')[-3] + '.' + k.split('.')[-1]   # noqa: E731
+        print(f"[3 train steps {mode}] update bulk err (mean |du - dr| / mean |dr|)", {short(k): f"{v:.1e}" for k, v in bulks.items()})
+        print(f"[3 train steps {mode}] update cosine", {short(k): f"{v:.4f}" for k, v in coss.items()})
+        for k in probes:
+            assert bulks[k] < ptol, (k, bulks[k])
+            assert coss[k] > (0.9999 if mode == "f32" else ctol), (k, coss[k])
         for k in ("decode_head.output_upscaling.1.running_mean", "decode_head.output_upscaling.1.running_var"):
             assert rel_err(got[k], sdo[k]) < (1e-4 if mode == "f32" else 2e-2), k
     finally:

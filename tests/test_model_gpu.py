@@ -79,8 +79,10 @@ def test_heads_match_reference_goldens(golden_dir):
         set_compute_dtype("bf16")
 
 
-@pytest.mark.parametrize("mode,ltol,gtol", [("f32", 2e-4, 5e-3), ("bf16x3", 2e-4, 5e-3), ("bf16", 3e-2, 1.5e-1)])
-def test_train_step_matches_reference_goldens(golden_dir, mode, ltol, gtol):
+# tolerances = ~3-10x the measured errors (profiles/r03_parity_train_step.log): f32 loss 2e-7 / grad norms 3e-7 / worst gradient slice 5e-6;
+# bf16x3 5e-7 / 8e-6 / 8e-4; bf16 1.0e-4 / 7e-4 / 3.7e-2 (round 2 allowed 3e-2 / 1.5e-1 / 3e-1 in bf16: wide enough to hide a bug)
+@pytest.mark.parametrize("mode,ltol,ntol,stol", [("f32", 1e-5, 1e-5, 1e-4), ("bf16x3", 1e-5, 1e-4, 5e-3), ("bf16", 1e-3, 3e-3, 1.2e-1)])
+def test_train_step_matches_reference_goldens(golden_dir, mode, ltol, ntol, stol):
     """Full forward_train + backward (B=2, 1024^2 -> 2x512^2 passes) against tests/golden/train_step.npz, which was
     produced by the reference's own MsVFMEncoderDecoder."""
     G = np.load(os.path.join(golden_dir, "train_step.npz"))
@@ -114,14 +116,21 @@ def test_train_step_matches_reference_goldens(golden_dir, mode, ltol, gtol):
                 continue
             j = 0 if "lora_" in k else (1 if k.startswith("decode_head") else 2)
             norms[j] += p.grad.double().pow(2).sum().item()
-        np.testing.assert_allclose(np.sqrt(norms), G["grad_norms"], rtol=gtol)
+        nerr = np.abs(np.sqrt(norms) / G["grad_norms"] - 1.0)
+        serr = {}
         for name in G.files:
             if name.startswith("grad_slice::"):
                 k = name.split("::", 1)[1]
                 g = named[k].grad
                 g2 = g.reshape(g.shape[0], -1) if g.dim() > 1 else g
-                e = rel_err(sl(g2), G[name])
-                assert e < gtol * 2, (k, e)
+                serr[k] = rel_err(sl(g2), G[name])
+        lerr = np.abs(got[[0, 2]] / G["losses"][[0, 2]] - 1.0)
+        print(f"[parity] train_step {mode}: loss rel err {lerr.max():.2e}, acc abs err {np.abs(got[[1, 3]] - G['losses'][[1, 3]]).max():.2e}, "
+              f"grad-norm rel err (lora, decode_head, aux_decoder) {nerr[0]:.2e} {nerr[1]:.2e} {nerr[2]:.2e}, "
+              f"worst of {len(serr)} gradient slices {max(serr.values()):.2e} ({max(serr, key=serr.get)})")
+        np.testing.assert_allclose(np.sqrt(norms), G["grad_norms"], rtol=ntol)
+        for k, e in serr.items():
+            assert e < stol, (k, e)
     finally:
         set_compute_dtype("bf16")
 
@@ -201,6 +210,72 @@ def test_merged_lora_inference_tracks_the_parameters():
         assert rel_err(c1, a0) < 3e-2, "stale merged weights after load_state_dict"
     finally:
         os.environ.pop("VFMSEG_MERGE_LORA_EVAL", None)
+
+
+def test_lora_backbone_encoder_decoder_matches_oracle():
+    """SURVEY row 14 = BASELINE configs[0]'s model class: LoraBackboneEncoderDecoder (Lora_encoder_decoder.py:12-44: mmseg EncoderDecoder
+    with a peft-wrapped DINOv2 backbone + LinearHead).  Train-mode loss (keys decode.loss_ce / decode.acc_seg) and gradients, `whole`
+    inference and `slide` inference (crop 512, stride 320 on a 1024^2 image) against the oracle, depth 4, f32 parity mode; the same
+    forward through bench.py's single512 preset (type EncoderDecoder + LoRABackbone) must give the same losses."""
+    from tests.helpers import full_state_dict
+    set_compute_dtype("f32")
+    try:
+        depth, out_idx = 4, (0, 1, 2, 3)
+        bb = presets.dinov2_backbone(depth)
+        bb["out_indices"] = list(out_idx)
+        cfg = dict(type="LoraBackboneEncoderDecoder", Lora_config=presets.lora_cfg(dropout=0.0), checkpoint=None, backbone=bb,
+                   decode_head=presets.linear_head(1024), data_preprocessor=None, train_cfg=dict(), test_cfg=dict(mode="whole"))
+        sd = {k: v for k, v in full_state_dict(depth=depth).items() if not k.startswith("aux_decoder.")}
+        model = MODELS.build(cfg)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not missing and not unexpected, (missing, unexpected)
+        model = model.cuda().train()
+        _zero_dropout(model)
+        img, lab = synth_image(2, 512, seed=21), synth_label(2, 512, seed=21)
+        losses = model.loss(img.cuda(), [SegDataSample(gt_sem_seg=lab[i]) for i in range(2)])
+        assert set(losses) == {"decode.loss_ce", "decode.acc_seg"}
+        total, _ = model.parse_losses(losses)
+        total.backward()
+        keys = ["backbone.model.base_model.model.blocks.2.attn.qkv.lora_B.default.weight", "decode_head.conv_seg.weight"]
+        sdo = {k: v.clone() for k, v in sd.items()}
+        for k in keys:
+            sdo[k].requires_grad_(True)
+        feats = R.dinov2_forward(sdo, img, depth=depth, out_indices=out_idx)
+        loss, acc, _ = R.head_loss(R.linear_head_forward(sdo, feats, training=True), lab)
+        grads = torch.autograd.grad(loss, [sdo[k] for k in keys])
+        assert abs(float(losses["decode.loss_ce"]) - float(loss)) <= 2e-4 * max(1.0, abs(float(loss)))
+        assert abs(float(losses["decode.acc_seg"]) - float(acc)) <= 2e-3
+        named = dict(model.named_parameters())
+        for k, g in zip(keys, grads):
+            assert rel_err(named[k].grad.cpu(), g) < 5e-3, k
+        # the single-pass preset of bench.py --workload single512 is the same model under mmseg's class name
+        cfg2 = presets.dinov2_linear(depth=depth)
+        cfg2["backbone"]["backbone"]["out_indices"] = list(out_idx)
+        cfg2["backbone"]["Lora_config"]["lora_dropout"] = 0.0
+        m2 = MODELS.build(cfg2)
+        m2.load_state_dict(sd, strict=False)
+        m2 = m2.cuda().train()
+        _zero_dropout(m2)
+        l2 = m2.loss(img.cuda(), [SegDataSample(gt_sem_seg=lab[i]) for i in range(2)])
+        assert abs(float(l2["decode.loss_ce"]) - float(losses["decode.loss_ce"])) < 1e-6
+        # inference: whole, then slide on a 1024^2 image (the train-mode pass moved the BN running statistics: start from sd again)
+        model.load_state_dict(sd, strict=False)
+        model.eval()
+        with torch.no_grad():
+            got = model.predict(img.cuda())
+            ref = R.whole_inference({k: v.detach() for k, v in sdo.items()}, img, (512, 512), depth=depth, out_indices=out_idx)
+        assert rel_err(torch.stack([o.seg_logits.data for o in got]).cpu(), ref) < 1e-3
+        model.test_cfg = type(model.test_cfg)(dict(mode="slide", crop_size=[512, 512], stride=[320, 320]))
+        big = synth_image(1, 1024, seed=22)
+        with torch.no_grad():
+            got = model.predict(big.cuda())[0].seg_logits.data.cpu()
+            ref = R.slide_inference({k: v.detach() for k, v in sdo.items()}, big, depth=depth, out_indices=out_idx)[0]
+        e = rel_err(got, ref)
+        mism = (got.argmax(0) != ref.argmax(0)).float().mean().item()
+        print(f"[parity] LoraBackboneEncoderDecoder f32: slide logits rel err {e:.2e}, argmax mismatches {mism:.2e}")
+        assert e < 1e-3 and mism < 2e-4
+    finally:
+        set_compute_dtype("bf16")
 
 
 def test_eva02_train_step_matches_oracle():

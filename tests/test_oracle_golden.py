@@ -113,6 +113,31 @@ def test_ms_inference_mask(golden_dir):
         assert np.abs(hist - G["pred_hist"]).sum() < 64
 
 
+@pytest.mark.parametrize("mode", ["lr_slide_inference", "hr_slide_inference", "msfull_slide_inference"])
+def test_other_slide_modes(golden_dir, mode):
+    """The oracle's lr / hr / msfull sliding inference against the reference's OWN MsVFMEncoderDecoder.inference in those modes
+    (tests/golden/slide_modes.npz, written by oracle.gen_golden --only slide_modes; Ms_VFM_encoder_decoder.py:278-332), msfull with the
+    recorded torch.rand query masks.  Round 2 checked these restatements only against themselves."""
+    G = np.load(os.path.join(golden_dir, "slide_modes.npz"))
+    sd = cached_full_state_dict()
+    stride, crop = tuple(int(v) for v in G["test_cfg_stride_crop"][:2]), tuple(int(v) for v in G["test_cfg_stride_crop"][2:])
+    img = synth_image(1, 1024, seed=11)
+    with torch.no_grad():
+        if mode == "lr_slide_inference":
+            lg = R.lr_slide_inference(sd, img, crop, stride)
+        elif mode == "hr_slide_inference":
+            lg = R.slide_inference(sd, img, crop, stride)
+        else:
+            keeps = [torch.from_numpy(G["msfull_mask_rand"][j]).reshape(1, 1, 32, 32) > 0.2 for j in range(9)]
+            lg = R.msfull_slide_inference(sd, img, mask_keeps=keeps, crop=crop, stride=stride)
+    assert rel_err(sl(lg), G[mode + "::logits_slice"]) < 1e-4
+    assert rel_err(lg[0, :, 500:504, 636:644], G[mode + "::logits_center"]) < 1e-4
+    np.testing.assert_allclose(stats(lg), G[mode + "::logits_stats"], rtol=1e-4)
+    pred = lg.argmax(dim=1)[0].numpy().astype(np.uint8)
+    assert (pred[::4, ::4] != G[mode + "::pred_sub4"]).mean() < 2e-4
+    assert np.abs(np.bincount(pred.reshape(-1), minlength=19) - G[mode + "::pred_hist"]).sum() < 200
+
+
 @pytest.mark.slow
 def test_eva02_taps_and_lora_grads(golden_dir):
     from tests.helpers import eva02_state_dict
