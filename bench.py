@@ -473,7 +473,7 @@ def main():
         g = timer.summary(kinds=("gemm",), region="backbone", min_flops=8e9) or allg
         if g is not None:
             traffic, traffic_src = None, None
-            for tj_name in ("r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
+            for tj_name in ("r03_pmc_gemm_traffic.json", "r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
                 tj = os.path.join(ROOT, "profiles", tj_name)
                 if os.path.exists(tj) and a.workload == "ms1024":  # PMC counters cannot be read from inside the timed run: committed rocprofv3 --pmc passes
                     with open(tj) as f:
@@ -484,7 +484,8 @@ def main():
             est = lambda r: round(r["ms"] * timer.every / a.steps, 3)   # noqa: E731
             out["roofline"] = {"bound": "mfma", "achieved": round(g["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(g["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                               "kernel": "k_gemm_w4<true,2,1,2,4,2,0>: the backbone's QKV / proj / fc1 / fc2 forward + input-gradient GEMMs "
+                               "kernel": "the backbone's QKV / proj / fc1 / fc2 forward + input-gradient GEMMs: k_gemm_w4<true,2,1,2,4,2,0> (128x128 LDS-DMA ring) "
+                                         "and, for fc1 forward / fc2 input gradient, k_gemm_ps (persistent 256x128, two accumulator sets) "
                                          "(algorithmic FLOPs of the sampled launches / their HIP-event time)",
                                "launches_timed": g["launches"], "sampled_every": timer.every,
                                "avg_launch_us": round(g["ms"] * 1e3 / g["launches"], 2),

@@ -1,6 +1,8 @@
 """Per-kernel numerics on a real MI355X: every C-ABI entry point against a plain PyTorch fp32 CPU reference."""
 import math
 
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -641,6 +643,7 @@ def test_attention_split_bf16x3_forward(nq_extra, nk_extra, nq, nk, B, H):
     assert e < 5e-5 and el < 2e-5 * max(1.0, ref_lse.abs().max().item()) + 1e-4   # (spiked keys: |lse| ~ 30)
 
 
+@pytest.mark.skipif(os.environ.get("VFMSEG_EXPERIMENTAL", "0") != "1", reason="attention_fwd64.hip is built only with VFMSEG_EXPERIMENTAL=1")
 def test_attention_fwd64_experimental():
     # the 64-queries-per-wave forward (vfm_tune attn_fwd64, off by default) against the regular kernel on the backbone shape
     from vfmseg_amd import lib as L

@@ -416,7 +416,11 @@ static bool short_grid(const vfm_attn_desc* d, int n) { return (long)cdiv(n, 128
 
 int g_attn_xcd = 1;       // vfm_tune("attn_xcd"): 0 = plain (block, pair) order (A/B of the XCD-local order)
 int g_attn_fwd64 = 0;     // vfm_tune("attn_fwd64"): 1 = use the experimental 64-queries-per-wave forward (attention_fwd64.hip) where it fits
+#ifdef VFM_EXPERIMENTAL_FWD64
 bool vfm_attn_fwd64_launch(const vfm_attn_desc* d, const AttnP& p, hipStream_t s);
+#else   // not built (vfmseg_amd/csrc/build.py EXPERIMENTAL): the knob is accepted and ignored
+static bool vfm_attn_fwd64_launch(const vfm_attn_desc*, const AttnP&, hipStream_t) { return false; }
+#endif
 int g_attn_lds_pad = 0;   // vfm_tune("attn_lds_pad"): extra dynamic LDS per forward block (occupancy experiments)
 int vfm_attn_bf16_fwd_impl(const vfm_attn_desc* d, hipStream_t s) {
   VFM_CHECK(aligned_ok(d, false), VFM_E_ALIGN, "vfm_attn_fwd(bf16): operands must be 16-byte aligned, ld %% 8 == 0");
