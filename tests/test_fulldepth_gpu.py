@@ -184,7 +184,7 @@ def test_sam_slide_inference_bf16_vs_oracle():
     assert e < 4e-2 and frac < 1e-2 and worst < 4e-2
 
 
-# measured (profiles/r03_parity_train_step.log): bulk update error f32 <= 4e-4, bf16 <= 5.1e-2; cosine of the update f32 1.0000, bf16 >= 0.9785
+# measured (profiles/r03_parity_gpu_suite.log): bulk update error f32 <= 4e-4, bf16 <= 5.1e-2; cosine of the update f32 1.0000, bf16 >= 0.9785
 # (Adam's first steps are sign-like, so element-wise maxima are O(1) in bf16 whenever a near-zero gradient flips: direction and bulk are
 # what the optimiser's output can be held to)
 @pytest.mark.parametrize("mode,ptol,ltol,ctol", [("f32", 2e-3, 3e-4, 0.9999), ("bf16", 1.5e-1, 1e-2, 0.95)])

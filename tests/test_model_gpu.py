@@ -79,7 +79,7 @@ def test_heads_match_reference_goldens(golden_dir):
         set_compute_dtype("bf16")
 
 
-# tolerances = ~3-10x the measured errors (profiles/r03_parity_train_step.log): f32 loss 2e-7 / grad norms 3e-7 / worst gradient slice 5e-6;
+# tolerances = ~3-10x the measured errors (profiles/r03_parity_gpu_suite.log): f32 loss 2e-7 / grad norms 3e-7 / worst gradient slice 5e-6;
 # bf16x3 5e-7 / 8e-6 / 8e-4; bf16 1.0e-4 / 7e-4 / 3.7e-2 (round 2 allowed 3e-2 / 1.5e-1 / 3e-1 in bf16: wide enough to hide a bug)
 @pytest.mark.parametrize("mode,ltol,ntol,stol", [("f32", 1e-5, 1e-5, 1e-4), ("bf16x3", 1e-5, 1e-4, 5e-3), ("bf16", 1e-3, 3e-3, 1.2e-1)])
 def test_train_step_matches_reference_goldens(golden_dir, mode, ltol, ntol, stol):
