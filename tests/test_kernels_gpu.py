@@ -488,15 +488,15 @@ def test_gemm_bf16_persistent_two_accumulators(cfg, M, N, K):
             assert relerr(c.float(), gelu(acc + bd)) < 1e-2
     finally:
         ops.tune("gemm_cfg", -1)
-    # the dispatcher's own choice (config 37 for whole rounds of 256 x 256 regions) gives the same numbers as the tile kernel
+    # with the knob on, the dispatcher itself picks config 37 for whole rounds of 256 x 256 regions: same numbers as the default path
     if (M, N, K) == (4100, 4096, 1024):
         c1, c2 = nan(), nan()
         ops.gemm(a, b, c1, bias=bias, ep_mode=ops.EP_GELU)
-        ops.tune("gemm_use_ps", 0)
+        ops.tune("gemm_use_ps", 1)
         try:
             ops.gemm(a, b, c2, bias=bias, ep_mode=ops.EP_GELU)
         finally:
-            ops.tune("gemm_use_ps", 1)
+            ops.tune("gemm_use_ps", 0)
         assert relerr(c1.float(), c2.float().double()) < 1e-2
 
 

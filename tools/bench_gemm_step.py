@@ -15,7 +15,11 @@ CASES = [  # (label, M, N, K, kind)
     ("qkv fwd bias", 4100, 3072, 1088, "bias"),
     ("fc1 fwd M4096", 4096, 4096, 1024, "gelu_dgelu"),
     ("eval fc1 gelu", 9225, 4096, 1024, "gelu"),
+    ("N1024 K4096 bias", 4096, 1024, 4096, "bias"),
+    ("N1024 K1024 bias", 4096, 1024, 1024, "bias"),
 ]
+if os.environ.get("CASES"):
+    CASES = [CASES[int(i)] for i in os.environ["CASES"].split(",")]
 
 
 def main():

@@ -5,7 +5,7 @@
 tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_$c -o p -- python3 bench.py --steps 2 --warmup 1 --no-eval --no-cpu-baseline --no-roofline > gpurun_out/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_$c -o p -- python3 bench.py --steps 2 --warmup 1 --no-eval --no-cpu-baseline --no-roofline --no-parity-mode > gpurun_out/pmc_$c.log 2>&1
 done
 f1=$(find gpurun_out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
 f2=$(find gpurun_out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)

@@ -25,7 +25,7 @@ def main():
     cls = collections.defaultdict(list)
     for r in step:
         n = r["Kernel_Name"]
-        key = n.split("(")[0][:70]
+        key = n.replace("(anonymous namespace)::", "").split("(")[0][:70]
         fam[key] += dur(r)
         cnt[key] += 1
         if "gemm" in n or "attn" in n:

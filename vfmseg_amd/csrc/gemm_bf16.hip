@@ -320,9 +320,15 @@ static int g_fold_tail = 1;  // run the tail rows as extra blocks of the tile ke
 // tile's main loop, which a one-block-per-CU kernel cannot - and the 2.5-K-tile ring beats the two-stage pipeline by 5-18 %
 // per shape (+2.6 % images/s).  The big-tile kernels win on long-K / light-epilogue shapes (4096^3: 1.26 PF vs 1.0) and stay
 // selectable per call (vfm_tune gemm_cfg 30..33).
-static int g_use_pp = 40;
+static int g_use_pp = 184;  // round 3: 40 -> 184 (bit 4: fc1 forward / fc2 input gradient on 256 x 256 tiles, +1.7 % images/s; bit 7: the qkv projection too, +1.0 %)
 long g_nt_bytes = 0;   // vfm_tune("gemm_nt_mb"): outputs of at least this many bytes are stored nontemporally (0 = never)
-static int g_use_ps = 1;   // the persistent two-accumulator kernel (gemm_ps.hip) for whole rounds of 256 x 256 regions with a bf16 epilogue
+// the persistent two-accumulator kernel (gemm_ps.hip) for whole rounds of 256 x 256 regions with a bf16 epilogue: OFF by default.  Round 3,
+// one-process A/B inside the train step (tools/ab_step.py, profiles/r03_ab_step_gemm.log): persistent kernel 132.7 images/s, 128 x 128 ring
+// kernel 133.1, 256 x 256 8-wave ring kernel (gemm_use_pp bit 4) 134.5 - the form with the fewest operand bytes per flop wins once its
+// epilogue is the cheap eight-column one; hiding half of the epilogue under the next sub-tile's loop does not pay
+static int g_use_ps = 0;
+static int g_deep_sep_k = 0;   // K from which one-tile-per-CU launches WITH tail rows take the seven-chunk ring and leave the tail rows to a skinny
+                               // launch of their own (vfm_tune gemm_deep_sep_k; 0 = never)
 static int g_deep_tail_k = 0;  // K from which one-tile-per-CU launches WITH tail rows take the seven-chunk ring, the tail rows riding
                                // inside the regular blocks (gemm_w4.hip CLSIN); 0 = never (five-chunk ring + tail blocks).  Measured:
                                // with cold operands 62.8 -> 53.9 us at K = 4096 (19.8 -> 22.2 at K = 1024), inside the train step
@@ -355,6 +361,10 @@ extern "C" int vfm_tune(const char* key, int value) {
   if (key && strcmp(key, "attn_lds_pad") == 0) {
     extern int g_attn_lds_pad;
     g_attn_lds_pad = value;
+    return VFM_OK;
+  }
+  if (key && strcmp(key, "gemm_deep_sep_k") == 0) {
+    g_deep_sep_k = value;
     return VFM_OK;
   }
   if (key && strcmp(key, "gemm_deep_tail_k") == 0) {
@@ -509,6 +519,8 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
     else if (t128 <= 160) cfg = 18;                                  // small problems: 64x128 tiles fill more CUs
     else if ((g_use_pp & 2) && t128 > 160 && t128 <= 272 && d->K >= 256 && (d->M + 128) * d->sa_m < (1l << 31) && (d->N + 128) * d->sb_n < (1l << 31))
       cfg = 31;  // about one 128x128 tile per CU: the ping-pong kernel (one block per CU, 4-slot DMA ring)
+    else if ((g_use_pp & 128) && d->N >= 2048 && t256 >= 176 && t256 < 256 && d->K >= 512 && span33 && nbatch == 1)
+      cfg = 33;  // three quarters of a round of 256 x 256 tiles (qkv + LoRA forward [4096 x 3072 x 1088]: 192 tiles)
     else if ((g_use_pp & 16) && d->N >= 2048 && (t256 % 256 == 0 || t256 >= 768) && d->K >= 128 && (d->M + 256) * d->sa_m < (1l << 31) &&
              (d->N + 256) * d->sb_n < (1l << 31))
       cfg = 33;  // whole waves of 256x256 tiles: 8 waves, 64-wide K-tiles (whole-line LDS-DMA), 5-chunk ring
@@ -522,6 +534,15 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
     // ... and with tail blocks riding along when K is long: one tile per CU streams its operands latency-bound (bytes in flight /
     // latency), so the deeper ring wins more than the tail blocks lose by waiting for a CU (they cannot share the ring's LDS)
     if (cfg == 34 && tail && t128 <= 256 && d->M % 128 == 0 && d->K >= g_deep_tail_k && g_deep_tail_k > 0) cfg = 35;
+    // ... or with the tail rows in a launch of their own behind this one (they cannot share a CU with the deep ring's LDS)
+    if (cfg == 34 && tail && t128 <= 256 && d->M % 128 == 0 && d->K >= 256 && g_deep_sep_k != 0 && d->K >= (g_deep_sep_k < 0 ? -g_deep_sep_k : g_deep_sep_k)) {
+      cfg = 35;
+      tail = nullptr;
+      if (folded) *folded = g_deep_sep_k < 0;   // (negative: timing diagnostic - the tail rows are simply not computed)
+      const bool ok = vfm_gemm_launch_w4(d, s, vec, nullptr, 3);
+      (void)ok;
+      return VFM_OK;
+    }
   }
   switch (cfg) {
     case 0: fd = launch_cfg<128, 128, 2, 2, 2>(d, s, vec, tail); break;
