@@ -468,8 +468,8 @@ def main():
     if rank == 0:
         GEMMS = ("gemm", "gemm_tn")
         allg = timer.summary(kinds=GEMMS)
-        # the dominant kernel: k_gemm_w4<2,1,2,4,2> (128x128 tiles, LDS-DMA chunk ring) = the backbone's QKV / proj / fc1 / fc2 forward
-        # and input-gradient launches (>= 8.6 GFLOP each; 193 launches and ~46 % of the step's GPU time in profiles/*_kernel_stats.csv)
+        # the dominant kernel family: k_gemm_w4 (LDS-DMA chunk ring; 128x128 and 256x256 tile forms) = the backbone's QKV / proj / fc1 / fc2
+        # forward and input-gradient launches (>= 8.6 GFLOP each; 193 launches and ~47 % of the step's GPU time in profiles/*_kernel_stats.csv)
         g = timer.summary(kinds=("gemm",), region="backbone", min_flops=8e9) or allg
         if g is not None:
             traffic, traffic_src = None, None
@@ -484,8 +484,9 @@ def main():
             est = lambda r: round(r["ms"] * timer.every / a.steps, 3)   # noqa: E731
             out["roofline"] = {"bound": "mfma", "achieved": round(g["tflops"], 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": round(g["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                               "kernel": "the backbone's QKV / proj / fc1 / fc2 forward + input-gradient GEMMs: k_gemm_w4<true,2,1,2,4,2,0> (128x128 LDS-DMA ring) "
-                                         "and, for fc1 forward / fc2 input gradient, k_gemm_ps (persistent 256x128, two accumulator sets) "
+                               "kernel": "the backbone's QKV / proj / fc1 / fc2 forward + input-gradient GEMMs (193 launches per step, ~47 % of its GPU time): "
+                                         "k_gemm_w4<true,2,1,2,4,2,0> (128x128 tiles, LDS-DMA chunk ring; the N = 1024 shapes and the qkv input gradient) and "
+                                         "k_gemm_w4<true,4,2,2,4,2,0> (256x256 tiles, 8 waves; fc1 forward, fc2 input gradient, qkv projection) "
                                          "(algorithmic FLOPs of the sampled launches / their HIP-event time)",
                                "launches_timed": g["launches"], "sampled_every": timer.every,
                                "avg_launch_us": round(g["ms"] * 1e3 / g["launches"], 2),

@@ -44,9 +44,9 @@ for tot, n, cnt, fpl, wpl in rows[:12]:
     out["kernels"].append({"kernel": n, "launches": cnt, "fetch_bytes_per_launch": fpl, "write_bytes_per_launch": wpl,
                            "bytes_per_launch": fpl + wpl})
     print(f"{cnt:6d}  fetch {fpl / 1e6:8.2f} MB  write {wpl / 1e6:8.2f} MB  {n[:90]}")
-# the dominant family = the backbone's forward + input-gradient GEMM launches: the 128 x 128 ring kernel and (round 3) the persistent
-# two-accumulator kernel that takes its fc1-forward / fc2-dgrad launches; launch-weighted mean over both
-dom = [k for k in out["kernels"] if "k_gemm_w4<true, 2, 1, 2, 4, 2, 0" in k["kernel"] or "k_gemm_ps<" in k["kernel"]]
+# the dominant family = the backbone's forward + input-gradient GEMM launches: the ring kernel in its 128 x 128 and 256 x 256 tile forms
+# (and the persistent two-accumulator kernel when vfm_tune gemm_use_ps is on); launch-weighted mean
+dom = [k for k in out["kernels"] if "k_gemm_w4<true, 2, 1, 2, 4, 2, 0" in k["kernel"] or "k_gemm_w4<true, 4, 2, 2, 4, 2, 0" in k["kernel"] or "k_gemm_ps<" in k["kernel"]]
 if dom:
     nl = sum(k["launches"] for k in dom)
     out["dominant"] = dom
