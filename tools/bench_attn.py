@@ -22,6 +22,10 @@ def timeit(fn, iters=50):
 
 def main():
     dev = "cuda"
+    for kv in sys.argv[1:]:
+        k, v = kv.split("=")
+        ops.tune(k, int(v))
+        print("tune", k, v)
     for label, B, H, n, ex in (("backbone 4x16x(1024+1)", 4, 16, 1024, 1), ("decoder 2x8x1024", 2, 8, 1024, 0), ("eval 9x16x(1024+1)", 9, 16, 1024, 1)):
         d = 64
         rows = B * n + B * ex
