@@ -78,7 +78,7 @@ def main():
         from PIL import Image
         from vfmseg_amd.datasets import CITYSCAPES_PALETTE
         for j, o in enumerate(out):
-            pred = o.pred_sem_seg.squeeze().to(torch.uint8).cpu().numpy()
+            pred = o.pred_sem_seg.data.squeeze().to(torch.uint8).cpu().numpy()
             name = os.path.splitext(os.path.basename(str((o.metainfo or {}).get("img_path") or (o.metainfo or {}).get("seg_map_path") or f"{idx}_{j}")))[0]
             if a.out:
                 Image.fromarray(pred).save(os.path.join(a.out, name + ".png"))
