@@ -86,10 +86,6 @@ constexpr int PS_NSLOT = 8, PS_UNIT = 16384, PS_RING = PS_NSLOT * PS_UNIT, PS_WA
 constexpr int PS_SMEM = PS_RING + 8 * PS_WAVE_AREA;   // 160 KiB
 constexpr int PS_PEEL = 8;                            // slabs per wave tile = K-tiles the previous sub-tile's epilogue rides on
 
-struct PsSub {   // one sub-tile's output coordinates (wave-uniform)
-  long m0, n0;
-};
-
 // DBG (timing diagnostics, results garbage; vfm_tune pp_dbg): 1 = no epilogue stores, 2 = no epilogue at all, 4 = no MFMAs, 8 = no operand DMA,
 // 16 = no fragment reads
 // BURST: all six pieces of an iteration go out in k3, right behind beta (the slots K-tile g just freed take B of K-tile g+2 and A of
@@ -126,8 +122,7 @@ __global__ void __launch_bounds__(512) k_gemm_ps(const bf16_t* __restrict__ A, l
   const int ts = (bid % (GM * sup_n)) / gsz;
   const long m0 = (long)tm * BM;
   const long n00 = (long)ts * per * BN;   // first sub-tile's column origin; sub-tile i: n00 + i * BN
-  const int nk = (int)(K / 64);
-  const int total = per * nk;             // K-tiles of this block's flat sequence
+  const int nk = (int)(K / 64);           // (the block's flat K-tile sequence has per * nk entries)
 
   // ---- per-lane DMA sources (32-bit byte offsets from scalar bases)
   const int prow = wave * 16 + (lane >> 3);   // piece j covers rows prow + 8 j of a unit
@@ -401,7 +396,6 @@ __global__ void __launch_bounds__(512) k_gemm_ps(const bf16_t* __restrict__ A, l
       }
     pn0 = n00 + (long)sub * BN;
   }
-  (void)total;
 
   // ---- the last sub-tile's epilogue, nothing left to hide it under
   wait_vmcnt<0>();
