@@ -368,7 +368,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-eval", action="store_true", help="skip the eval ms/img @1024x1024 leg (N=1 only)")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the f32 parity-mode speed leg (N=1 only)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3", "fp16"])
     ap.add_argument("--workload", default="ms1024", choices=["ms1024", "single512"],
                     help="ms1024: BASELINE configs[1] (1024^2 sample -> LR + HR 512^2 passes, both heads; the headline metric); "
                          "single512: one 512^2 pass per sample, DINOv2-L + LoRA + LinearHead (SURVEY 8: the labelled single-pass step)")

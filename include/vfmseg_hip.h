@@ -11,6 +11,10 @@
  *  - return 0 on success, negative VFM_E_* otherwise; vfm_last_error() gives a thread-local message
  *  - matrices are row-major with explicit leading dimensions in ELEMENTS
  *  - dtypes: VFM_F32 / VFM_BF16 activations and weights, fp32 accumulation and statistics, int64 labels
+ *  - the SAME sources are built twice: libvfmseg_hip.so (16-bit type = bf16, the throughput configuration) and
+ *    libvfmseg_hip_f16.so (16-bit type = IEEE fp16: the autocast dtype of the reference's `--amp`, tools/train.py:87-102).
+ *    Both export this header; in the fp16 library dtype code VFM_BF16 means fp16 storage and the MFMA is v_mfma_f32_32x32x16_f16.
+ *    vfm_half_kind() tells which one was loaded.
  *  - token-major ("NHWC") activations: a feature map [B,H,W,C] is the matrix [B*H*W, C]
  */
 #ifndef VFMSEG_HIP_H
@@ -32,6 +36,7 @@ enum { VFM_ACT_NONE = 0, VFM_ACT_GELU = 1, VFM_ACT_RELU = 2, VFM_ACT_QGELU = 3 }
 
 const char* vfm_last_error(void);
 int vfm_abi_version(void);
+int vfm_half_kind(void); /* 0: the 16-bit type of this library is bf16, 1: IEEE fp16 */
 
 /* ---- elementwise / layout ------------------------------------------------------------------ */
 /* dst[r,c] = src[r,c] * (colscale ? colscale[c] : 1)          (casts; LayerScale prologue for dgrad) */

@@ -271,6 +271,8 @@ def sam_forward(sd, x, depth=32, heads=16, window=14, global_idx=(7, 15, 23, 31)
 def batch_norm_train(x, w, b, running_mean, running_var, momentum=0.1, eps=1e-5, stats=None):
     """nn.SyncBatchNorm without a process group == BatchNorm2d (linear_head.py:44). Returns y and new running stats.
     `stats`=(mean, biased_var, count) overrides local batch stats (what a DP all-reduce of moments would give)."""
+    in_dt = x.dtype
+    x = x.float()   # fp16 inputs (oracle/amp_emul.py): batch-norm kernels accumulate and normalise in fp32 and round the result once
     if stats is None:
         mean = x.mean(dim=(0, 2, 3))
         var = x.var(dim=(0, 2, 3), unbiased=False)
@@ -278,7 +280,7 @@ def batch_norm_train(x, w, b, running_mean, running_var, momentum=0.1, eps=1e-5,
     else:
         mean, var, cnt = stats
     y = (x - mean[None, :, None, None]) * torch.rsqrt(var[None, :, None, None] + eps)
-    y = y * w[None, :, None, None] + b[None, :, None, None]
+    y = (y * w[None, :, None, None] + b[None, :, None, None]).to(in_dt)
     new_rm = (1 - momentum) * running_mean + momentum * mean.detach()
     new_rv = (1 - momentum) * running_var + momentum * var.detach() * (cnt / max(cnt - 1, 1))
     return y, new_rm, new_rv
@@ -585,19 +587,32 @@ DG_CUSTOM_KEYS = {"norm": dict(decay_mult=0.0), "query_embed": dict(lr_mult=1.0,
                   "reins.scale": dict(lr_mult=1.0, decay_mult=0.0)}   # dg_lora_dinov2_ms_masked.py:10-25
 
 
-def train_step(sd, opt_state, img, label, hr_box, mask_keep, t, base_lr=1e-4, base_wd=0.05, end=40000, **kw):
+def train_step(sd, opt_state, img, label, hr_box, mask_keep, t, base_lr=1e-4, base_wd=0.05, end=40000, loss_scale=None, **kw):
     """One iteration of the reference's training loop on the oracle: forward_train -> parse_losses -> backward ->
     AdamW with the PEFTOptimWrapperConstructor groups at lr = PolyLR(t) -> SyncBN running stats
     (tools/train.py:64-121 via mmengine Runner; dg_lora_dinov2_ms_masked.py:10-29).  sd is updated IN PLACE (plain
     tensors); opt_state: {key: (m, v)} carried between calls; t = number of optimiser steps already taken.  Returns the
-    loss dict of this iteration (floats)."""
+    loss dict of this iteration (floats).
+    loss_scale (mmengine AmpOptimWrapper.update_params -> torch GradScaler.scale / unscale_ / step): backward runs on loss * scale,
+    the gradients are divided by the scale, and a step whose gradients hold an inf / NaN is skipped (returned dict gets
+    "skipped": 1.0; the caller owns the scale's schedule).  Run it inside oracle.amp_emul.cuda_autocast() for the `--amp` arithmetic."""
     tk = trainable_keys(sd)
     work = dict(sd)
     for k in tk:
         work[k] = sd[k].detach().clone().requires_grad_(True)
     bn = {}
     losses = forward_train(work, img, label, hr_box, mask_keep, bn_out=bn, **kw)
-    grads = torch.autograd.grad(total_loss(losses), [work[k] for k in tk], allow_unused=True)
+    total = total_loss(losses)
+    grads = torch.autograd.grad(total if loss_scale is None else total * loss_scale, [work[k] for k in tk], allow_unused=True)
+    out = {k: float(v.detach()) for k, v in losses.items()}
+    if bn:   # the forward pass moved the running statistics whether or not the optimiser steps
+        sd["decode_head.output_upscaling.1.running_mean"] = bn["running_mean"].detach()
+        sd["decode_head.output_upscaling.1.running_var"] = bn["running_var"].detach()
+    if loss_scale is not None:
+        grads = [None if g is None else g.float() / loss_scale for g in grads]
+        if not all(bool(torch.isfinite(g).all()) for g in grads if g is not None):
+            out["skipped"] = 1.0
+            return out
     lr_t = poly_lr(base_lr, t, end=end)
     with torch.no_grad():
         for k, g in zip(tk, grads):
@@ -607,10 +622,7 @@ def train_step(sd, opt_state, img, label, hr_box, mask_keep, t, base_lr=1e-4, ba
             m, v = opt_state.get(k, (torch.zeros_like(g), torch.zeros_like(g)))
             sd[k], m, v = adamw_step(sd[k].detach(), g, m, v, t + 1, lr_k, wd_k)
             opt_state[k] = (m, v)
-        if bn:
-            sd["decode_head.output_upscaling.1.running_mean"] = bn["running_mean"].detach()
-            sd["decode_head.output_upscaling.1.running_var"] = bn["running_var"].detach()
-    return {k: float(v.detach()) for k, v in losses.items()}
+    return out
 
 
 def key_is_norm(key):

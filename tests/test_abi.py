@@ -19,19 +19,25 @@ def test_header_declares_entry_points():
     assert "vfm_gemm" in names and "vfm_attn_fwd" in names and "vfm_upsample_ce" in names and len(names) >= 35
 
 
-def test_library_exports_every_declared_symbol():
+@pytest.mark.parametrize("which,kind", [("LIB", 0), ("LIB_F16", 1)])
+def test_library_exports_every_declared_symbol(which, kind):
+    """Both builds of the sources (bf16 and the fp16 twin, csrc/common.h) export the whole header and say which they are."""
     from vfmseg_amd.csrc import build
-    lib_path = build.LIB if os.path.exists(build.LIB) else build.build(verbose=False)
+    lib_path = getattr(build, which)
+    if not os.path.exists(lib_path):
+        build.build(verbose=False, only="f16" if kind else "bf16")
     lib = ctypes.CDLL(lib_path)
     missing = [n for n in _declared() if not hasattr(lib, n)]
     assert not missing, missing
     lib.vfm_abi_version.restype = ctypes.c_int
     assert lib.vfm_abi_version() >= 1
+    lib.vfm_half_kind.restype = ctypes.c_int
+    assert lib.vfm_half_kind() == kind
 
 
 def test_python_binding_matches_header():
     from vfmseg_amd import lib as L
-    declared = set(_declared()) - {"vfm_last_error", "vfm_abi_version"}
+    declared = set(_declared()) - {"vfm_last_error", "vfm_abi_version", "vfm_half_kind"}
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     # argument counts agree with the header prototypes
     txt = open(os.path.join(ROOT, "include", "vfmseg_hip.h")).read()

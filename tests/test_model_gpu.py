@@ -81,10 +81,13 @@ def test_heads_match_reference_goldens(golden_dir):
 
 # tolerances = ~3-10x the measured errors (profiles/r03_parity_gpu_suite.log): f32 loss 2e-7 / grad norms 3e-7 / worst gradient slice 5e-6;
 # bf16x3 5e-7 / 8e-6 / 8e-4; bf16 1.0e-4 / 7e-4 / 3.7e-2 (round 2 allowed 3e-2 / 1.5e-1 / 3e-1 in bf16: wide enough to hide a bug)
-@pytest.mark.parametrize("mode,ltol,ntol,stol", [("f32", 1e-5, 1e-5, 1e-4), ("bf16x3", 1e-5, 1e-4, 5e-3), ("bf16", 1e-3, 3e-3, 1.2e-1)])
+@pytest.mark.parametrize("mode,ltol,ntol,stol", [("f32", 1e-5, 1e-5, 1e-4), ("bf16x3", 1e-5, 1e-4, 5e-3), ("bf16", 1e-3, 3e-3, 1.2e-1),
+                                                    ("fp16", 3e-4, 1e-3, 4e-2)])
 def test_train_step_matches_reference_goldens(golden_dir, mode, ltol, ntol, stol):
     """Full forward_train + backward (B=2, 1024^2 -> 2x512^2 passes) against tests/golden/train_step.npz, which was
-    produced by the reference's own MsVFMEncoderDecoder."""
+    produced by the reference's own MsVFMEncoderDecoder.  fp16 (the `--amp` dtype, libvfmseg_hip_f16.so): backward runs under the
+    loss scale 2**16 as AmpOptimWrapper does (fp16 gradients of a 524288-pixel mean underflow without it) and the gradients are
+    un-scaled before the comparison; its tolerances sit between bf16's and f32's, as 11 vs 8 significant bits should."""
     G = np.load(os.path.join(golden_dir, "train_step.npz"))
     set_compute_dtype(mode)
     try:
@@ -104,10 +107,14 @@ def test_train_step_matches_reference_goldens(golden_dir, mode, ltol, ntol, stol
         keys = ["decode_lr.loss_ce", "decode_lr.acc_seg", "decode_hr.loss_ce", "decode_hr.acc_seg"]
         got = np.array([float(losses[k]) for k in keys])
         np.testing.assert_allclose(got[[0, 2]], G["losses"][[0, 2]], rtol=ltol)
-        np.testing.assert_allclose(got[[1, 3]], G["losses"][[1, 3]], atol=0.05 if mode == "bf16" else 2e-3)
+        np.testing.assert_allclose(got[[1, 3]], G["losses"][[1, 3]], atol=0.05 if mode == "bf16" else (1e-2 if mode == "fp16" else 2e-3))
         total, _ = model.parse_losses(losses)
-        total.backward()
+        gscale = 65536.0 if mode == "fp16" else 1.0
+        (total * gscale).backward()
         named = dict(model.named_parameters())
+        for p_ in named.values():
+            if p_.grad is not None and gscale != 1.0:
+                p_.grad.div_(gscale)
         n_train = sum(p.numel() for p in named.values() if p.requires_grad)
         assert n_train == int(G["n_trainable"][0])
         norms = [0.0, 0.0, 0.0]

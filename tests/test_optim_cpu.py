@@ -130,5 +130,35 @@ def test_amp_optim_wrapper_follows_gradscaler():
     fixed.update_params(_Loss(fixed.optimizer, bad))
     assert fixed.scale == 128.0 and fixed.skipped == 1   # a static scale never moves
     import pytest
+    # autocast dtype as in mmengine: None / 'float16' -> fp16 (what the reference's `--amp` runs: precision mode "fp16", the twin
+    # library), 'bfloat16' -> bf16; anything else is not an autocast dtype
+    assert AmpOptimWrapper(_StubOpt(), None, None).mode == "fp16" and AmpOptimWrapper(_StubOpt(), None, None, dtype="float16").dtype == torch.float16
+    assert AmpOptimWrapper(_StubOpt(), None, None, dtype="bfloat16").mode == "bf16"
     with pytest.raises(NotImplementedError):
-        AmpOptimWrapper(_StubOpt(), None, None, dtype="float16")
+        AmpOptimWrapper(_StubOpt(), None, None, dtype="float64")
+
+
+def test_amp_loss_scale_schedule_equals_torch_gradscaler():
+    """The wrapper's scale / growth-tracker trajectory against torch.amp.GradScaler itself (what mmengine's AmpOptimWrapper holds)
+    over a sequence of good and overflowing steps, and the skip decisions (the parameter moves exactly when torch's optimiser steps)."""
+    from vfmseg_amd.optim import AmpOptimWrapper
+    seq = [0, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0]
+    scaler = torch.amp.GradScaler("cpu", init_scale=1024.0, growth_interval=3)
+    p = torch.nn.Parameter(torch.ones(8))
+    topt = torch.optim.SGD([p], lr=0.1)
+    opt = _StubOpt()
+    ow = AmpOptimWrapper(opt, None, None, loss_scale=dict(init_scale=1024.0, growth_interval=3))
+    for i, bad in enumerate(seq):
+        g = torch.arange(8, dtype=torch.float32) + 1
+        if bad:
+            g[i % 8] = float("inf") if i % 2 else float("nan")
+        topt.zero_grad()
+        scaler.scale((p * g).sum()).backward()
+        before = p.detach().clone()
+        scaler.step(topt)
+        scaler.update()
+        nsteps = len(opt.steps)
+        ow.update_params(_Loss(opt, g))
+        assert ow.scale == scaler.get_scale() and ow.growth_tracker == int(scaler._growth_tracker.item()), (i, ow.scale, scaler.get_scale())
+        assert (len(opt.steps) > nsteps) == (not torch.equal(before, p.detach())) == (not bad)
+    assert ow.skipped == sum(seq) and ow.iter == len(seq)

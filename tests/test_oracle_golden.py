@@ -235,3 +235,54 @@ def test_optimizer_rules():
         opt.step()
         pp, m, v = R.adamw_step(pp, g, m, v, step, 1e-3, 0.05)
     assert torch.allclose(pp, q.detach(), atol=1e-6)
+
+
+def test_amp_emulation_follows_the_cuda_autocast_policy():
+    """oracle/amp_emul.py (the CPU restatement of torch.autocast(cuda, float16) the fp16 `--amp` tests compare with): dtypes and
+    rounding points of the ops the oracle calls, gradient dtypes, and restoration of the patched functions."""
+    import torch.nn.functional as F
+    from oracle.amp_emul import cuda_autocast
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 16, generator=g, requires_grad=True)
+    w = torch.randn(8, 16, generator=g, requires_grad=True)
+    b = torch.randn(8, generator=g)
+    lin0, mm0, sm0 = F.linear, torch.Tensor.__matmul__, torch.Tensor.softmax
+    with cuda_autocast():
+        y = F.linear(x, w, b)
+        assert y.dtype == torch.float16
+        want = (torch.mm(x.half().float(), w.half().float().t()) + b.half().float()).half()   # (torch.mm: `@` is patched in here)
+        assert torch.equal(y, want.detach())                            # fp16 operands, fp32 accumulate, ONE rounding of the result
+        ln = F.layer_norm(y, (8,))
+        assert ln.dtype == torch.float32                                 # fp32 list
+        a = y @ y.t()
+        assert a.dtype == torch.float16 and a.softmax(dim=-1).dtype == torch.float32
+        z = (a.softmax(dim=-1) @ y)                                      # fp32 probabilities are cast down for the product
+        assert z.dtype == torch.float16
+        res = x[:, :8] + 0.5 * z                                         # fp32 residual + fp16 branch -> fp32
+        assert res.dtype == torch.float32
+        assert F.gelu(y).dtype == torch.float16 and F.group_norm(y[None].permute(0, 2, 1), 2).dtype == torch.float32
+        loss = F.cross_entropy(res, torch.tensor([0, 1, 2, 3, 4])) * 1024.0
+        loss.backward()
+    assert F.linear is lin0 and torch.Tensor.__matmul__ is mm0 and torch.Tensor.softmax is sm0
+    assert x.grad.dtype == torch.float32 and w.grad.dtype == torch.float32
+    # the weight gradient went through an fp16 tensor (w.half()): every value is fp16-representable; x.grad has an fp32 residual part
+    assert torch.equal(w.grad, w.grad.half().float()) and not torch.equal(x.grad, x.grad.half().float())
+
+
+@pytest.mark.slow
+def test_amp_emulation_of_forward_train_is_an_fp16_sized_perturbation():
+    from oracle.amp_emul import cuda_autocast
+    from tests.helpers import full_state_dict
+    from vfmseg_amd.synth import synth_image, synth_label
+    depth = 4
+    sd = full_state_dict(depth=depth)
+    keep = torch.rand(1, 1, 32, 32, generator=torch.Generator().manual_seed(3)) > 0.2
+    img, lab = synth_image(1, 1024, seed=60), synth_label(1, 1024, seed=60)
+    kw = dict(depth=depth, out_indices=(0, 1, 2, 3))
+    with torch.no_grad():
+        l32 = R.forward_train(sd, img, lab, (256, 768, 128, 640), keep, **kw)
+        with cuda_autocast():
+            l16 = R.forward_train(sd, img, lab, (256, 768, 128, 640), keep, **kw)
+    for k in ("decode_lr.loss_ce", "decode_hr.loss_ce"):
+        e = abs(float(l16[k]) - float(l32[k])) / abs(float(l32[k]))
+        assert 0 < e < 2e-3, (k, e)

@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--images", type=int, default=None,
                     help="evaluate only the first N samples (default: the whole test set on real data, 4 synthetic images otherwise)")
     ap.add_argument("--size", type=int, nargs=2, default=[1024, 1024])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3", "fp16"])
     ap.add_argument("--data", choices=["auto", "synthetic", "real"], default="auto")
     a = ap.parse_args()
     if "LOCAL_RANK" not in os.environ:

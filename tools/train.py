@@ -14,12 +14,12 @@ def main():
     ap.add_argument("config")
     ap.add_argument("--work-dir")
     ap.add_argument("--resume", action="store_true")
-    ap.add_argument("--amp", action="store_true", help="AmpOptimWrapper with a dynamic loss scale; autocast dtype bf16")
+    ap.add_argument("--amp", action="store_true", help="AmpOptimWrapper: fp16 autocast (the fp16 twin library) with a dynamic loss scale; optim_wrapper.dtype=bfloat16 for bf16")
     ap.add_argument("--cfg-options", nargs="+")
     ap.add_argument("--launcher", choices=["none", "pytorch", "slurm", "mpi"], default="none")
     ap.add_argument("--local_rank", "--local-rank", type=int, default=0)
     ap.add_argument("--max-iters", type=int, default=None)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3", "fp16"])
     ap.add_argument("--data", choices=["auto", "synthetic", "real"], default="auto",
                     help="auto: read train_dataloader.dataset when its data_root exists, else the synthetic 19-class stream")
     a = ap.parse_args()
@@ -40,9 +40,12 @@ def main():
             assert ow_type == "OptimWrapper", f"`--amp` is only supported when the optimizer wrapper type is `OptimWrapper` but got {ow_type}."
             cfg["optim_wrapper"]["type"] = "AmpOptimWrapper"
             cfg["optim_wrapper"]["loss_scale"] = "dynamic"
-        if a.dtype != "bf16":
-            print("--amp: the autocast dtype of this backend is bf16 (vfmseg_amd.optim.AmpOptimWrapper); switching --dtype to bf16")
-            set_compute_dtype("bf16")
+    if cfg["optim_wrapper"].get("type") == "AmpOptimWrapper":
+        # mmengine's AmpOptimWrapper runs the model under torch.autocast(dtype or fp16): here, the engine's precision mode
+        amp_dt = cfg["optim_wrapper"].get("dtype")
+        mode = "bf16" if amp_dt in ("bfloat16", "bf16") else "fp16"
+        print(f"AmpOptimWrapper: autocast dtype {amp_dt or 'float16'} -> precision mode {mode} (dynamic loss scale)")
+        set_compute_dtype(mode)
     cfg["work_dir"] = a.work_dir or cfg.get("work_dir") or os.path.join("./work_dirs", os.path.splitext(os.path.basename(a.config))[0])
     if "train_cfg" not in cfg["model"] or cfg["model"]["train_cfg"] is None:
         cfg["model"]["train_cfg"] = {}

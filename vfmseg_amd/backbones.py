@@ -18,6 +18,7 @@ import os
 import torch
 import torch.nn as nn
 
+from .precision import is_half
 from . import ops
 from .precision import compute_dtype
 from .registry import MODELS
@@ -225,7 +226,7 @@ class Packed:
         self.w = ops.empty_ld(n, k_pad, cd, w_f32.device, zero=True)
         ops.cast(w_f32, self.w[:, :k])
         self.wt = None
-        if cd == torch.bfloat16:
+        if is_half(cd):
             self.wt = ops.empty_ld(k_pad, n, cd, w_f32.device, zero=True)
             ops.transpose(w_f32, self.wt[:k], pad_rows=n)
 
@@ -243,7 +244,7 @@ def wgrad(dy, x, grad_out, alpha=1.0, n_rows=None, accumulate=True):
     bf16: explicit transposes feed the NT MFMA GEMM (K = tokens, zero-padded to 64); f32: strided operands."""
     M = dy.shape[0]
     res = grad_out if accumulate else None
-    if dy.dtype == torch.bfloat16:
+    if is_half(dy.dtype):
         mp = (M + 63) // 64 * 64
         dyt = torch.empty(dy.shape[1], mp, dtype=dy.dtype, device=dy.device)
         xt = torch.empty(x.shape[1], mp, dtype=x.dtype, device=x.device)
@@ -381,7 +382,7 @@ class DinoEngine:
         D, H, ps = v.embed_dim, v.num_heads, v.patch_size
         lora = self.lora_on()
         merged = None
-        if (lora and not training and not torch.is_grad_enabled() and cd == torch.bfloat16
+        if (lora and not training and not torch.is_grad_enabled() and is_half(cd)
                 and os.environ.get("VFMSEG_MERGE_LORA_EVAL", "1") != "0"):
             merged = self.merged_qkv(P)
         elif lora:
@@ -418,7 +419,7 @@ class DinoEngine:
         # training: the K-extended QKV operands [LN(x) | T] and the dropped LN copies of ALL layers live in two layer-batched
         # buffers, so that the LoRA weight gradients of many layers can run as ONE batched GEMM each (see backward)
         nL = len(v.blocks)
-        batched = lora and training and cd == torch.bfloat16 and merged is None
+        batched = lora and training and is_half(cd) and merged is None
         A1all = torch.empty(nL, M, P["layers"][0]["qkv"].k, dtype=cd, device=dev) if batched else None
         XDall = None
         hd = D // H
@@ -430,7 +431,7 @@ class DinoEngine:
             a1 = A1all[li] if batched else torch.empty(M, kq, dtype=cd, device=dev)
             st1 = torch.empty(M, 2, dtype=torch.float32, device=dev)
             q = blk.attn.qkv if lora else None
-            fused_drop = lora and training and q.p > 0 and cd == torch.bfloat16 and D % 256 == 0
+            fused_drop = lora and training and q.p > 0 and is_half(cd) and D % 256 == 0
             if fused_drop:  # LN + dropout multiplier + dropped copy in one pass
                 mask = torch.empty(M, D, dtype=cd, device=dev)
                 if batched and XDall is None:
@@ -507,7 +508,7 @@ class DinoEngine:
             DA1all = torch.empty(nL, M, kq_all, dtype=cd, device=dev)
             DQKVall = torch.empty(nL, M, 3 * D, dtype=cd, device=dev)
         half = nL // 2
-        fuse_t = cd == torch.bfloat16 and D % 256 == 0  # LN backward emits the next dgrad operand bf16(dx * gamma) itself
+        fuse_t = is_half(cd) and D % 256 == 0  # LN backward emits the next dgrad operand bf16(dx * gamma) itself
         def add_tap(li):
             for i, oi in enumerate(v.out_indices):
                 if oi == li:
@@ -676,7 +677,7 @@ def _wgrad_small_t(xs, y, out, alpha=1.0, scatter=None):
     scatter = (dst, rows_used, sp, sq): instead of writing `out`, accumulate dst[p*sp + q*sq] += result[p, q] for
     p < rows_used (the gradient's own layout inside the optimiser's flat buffer); returns True when that was done."""
     M = xs.shape[0]
-    if xs.dtype == torch.bfloat16:
+    if is_half(xs.dtype):
         mp = (M + 63) // 64 * 64
         # few output tiles, long token reduction: split K into the largest divisor <= 16 of the 64-token steps
         steps = mp // 64

@@ -11,6 +11,7 @@ reference: 48 gradient-less LoRA tensors); the two MLP adapters are fused into t
 import torch
 import torch.nn as nn
 
+from .precision import is_half
 from . import ops
 from .backbones import BACKWARD_EVENTS, R_PAD, LoraLinear, Packed, _BackboneFn, _Lin, _pack_at, _refresh_sites, _wgrad_small_t
 from .precision import compute_dtype
@@ -263,7 +264,7 @@ class ClipEngine:
             st2 = torch.empty(M, 2, dtype=torch.float32, device=dev)
             xd1 = mask1 = xd2 = mask2 = None
             q1, q2 = (blk.mlp.c_fc, blk.mlp.c_proj) if lora else (None, None)
-            if lora and training and q1.p > 0 and cd == torch.bfloat16 and D % 256 == 0:
+            if lora and training and q1.p > 0 and is_half(cd) and D % 256 == 0:
                 mask1 = torch.empty(M, D, dtype=cd, device=dev)
                 xd1 = torch.empty(M, D, dtype=cd, device=dev)
                 ops.layernorm_dropout_fwd(xm, Lp["n2w"], Lp["n2b"], 1e-5, a2[:, :D], st2, xd1, mask1, q1.p, seed, offset=rng0 + 2 * li * M * hid)
@@ -335,7 +336,7 @@ class ClipEngine:
         dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
         lora = self.lora_on()
         grads = [None] * (4 * len(v.blocks))
-        fuse_t = cd == torch.bfloat16 and D % 256 == 0  # LN backward emits the next dgrad operand bf16(dx) itself
+        fuse_t = is_half(cd) and D % 256 == 0  # LN backward emits the next dgrad operand bf16(dx) itself
         if fuse_t and "ones" not in P:
             P["ones"] = torch.ones(D, dtype=torch.float32, device=dev)
 

@@ -17,8 +17,8 @@ namespace {
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    hi[e] = (__bf16)x[e];
-    lo[e] = (__bf16)(x[e] - (float)hi[e]);
+    hi[e] = (vfm_h)x[e];
+    lo[e] = (vfm_h)(x[e] - (float)hi[e]);
   }
 }
 

@@ -4,7 +4,7 @@
 #include "attn_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef vfm_h bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 #define TROWS 64
@@ -90,7 +90,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rb, int s, int j
 __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
   bf16x8 r;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) r[e] = (__bf16)a[8 * s + e];
+  for (int e = 0; e < 8; ++e) r[e] = (vfm_h)a[8 * s + e];
   return r;
 }
 __device__ __forceinline__ f32x16 zero16() {
@@ -101,7 +101,7 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }  // row of register r
 
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define MFMA(a, b, c) VFM_MFMA16(a, b, c)
 
 // load the stationary operand's B fragments: 4 k-steps x 8 bf16 of row `row`, columns col0 + 16kk + 8h ..
 __device__ __forceinline__ void load_stationary(const bf16_t* base, long ld, long row, int col0, int h, bf16x8 (&f)[4]) {
@@ -114,9 +114,9 @@ __device__ __forceinline__ void load_stationary(const bf16_t* base, long ld, lon
 // query in 128) and a 9th key block it made 576 equal-cost blocks for 512 resident slots (+30 % forward, +21 % backward).
 // The block that owns only the extra row runs these VALU paths instead: dot products with v_dot2c_f32_bf16, one thread
 // per streamed row for the scores, (row group, 8 columns) per thread for the weighted sums, fixed-order LDS reductions.
-typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef vfm_h bf16x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dot2u(unsigned a, unsigned b, float acc) {
-  return __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<bf16x2v*>(&a), *reinterpret_cast<bf16x2v*>(&b), acc, false);
+  return VFM_DOT2(*reinterpret_cast<bf16x2v*>(&a), *reinterpret_cast<bf16x2v*>(&b), acc);
 }
 __device__ __forceinline__ float dot8(uint4 a, uint4 b) {
   return dot2u(a.w, b.w, dot2u(a.z, b.z, dot2u(a.y, b.y, dot2u(a.x, b.x, 0.f))));
@@ -128,10 +128,10 @@ __device__ __forceinline__ float sum8(float v) {  // over the 8 lanes that share
   return v;
 }
 __device__ __forceinline__ void fma8(float (&acc)[8], float w, uint4 x) {
-  acc[0] = fmaf(w, __uint_as_float(x.x << 16), acc[0]), acc[1] = fmaf(w, __uint_as_float(x.x & 0xffff0000u), acc[1]);
-  acc[2] = fmaf(w, __uint_as_float(x.y << 16), acc[2]), acc[3] = fmaf(w, __uint_as_float(x.y & 0xffff0000u), acc[3]);
-  acc[4] = fmaf(w, __uint_as_float(x.z << 16), acc[4]), acc[5] = fmaf(w, __uint_as_float(x.z & 0xffff0000u), acc[5]);
-  acc[6] = fmaf(w, __uint_as_float(x.w << 16), acc[6]), acc[7] = fmaf(w, __uint_as_float(x.w & 0xffff0000u), acc[7]);
+  acc[0] = fmaf(w, h16_lo(x.x), acc[0]), acc[1] = fmaf(w, h16_hi(x.x), acc[1]);
+  acc[2] = fmaf(w, h16_lo(x.y), acc[2]), acc[3] = fmaf(w, h16_hi(x.y), acc[3]);
+  acc[4] = fmaf(w, h16_lo(x.z), acc[4]), acc[5] = fmaf(w, h16_hi(x.z), acc[5]);
+  acc[6] = fmaf(w, h16_lo(x.w), acc[6]), acc[7] = fmaf(w, h16_hi(x.w), acc[7]);
 }
 // out[d] = mult * sum_i w[i] * X[row(i)][col0 + d], i < n: thread (i-group tid>>3, 8 columns tid&7), then 32-way LDS reduce
 __device__ __forceinline__ void weighted_rowsum(const float* w, const bf16_t* X, long ld, int col0, int b, int n, int n_main, int B,

@@ -1,4 +1,5 @@
-"""Builds libvfmseg_hip.so (gfx950) in-tree with hipcc.  `python -m vfmseg_amd.csrc.build [--force]`."""
+"""Builds libvfmseg_hip.so and its fp16 twin libvfmseg_hip_f16.so (gfx950) in-tree with hipcc.
+`python -m vfmseg_amd.csrc.build [--force] [--only bf16|f16]`.  The twin is the same sources with -DVFM_HALF_F16 (common.h)."""
 import glob
 import os
 import subprocess
@@ -8,7 +9,11 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libvfmseg_hip.so")
+LIB_F16 = os.path.join(HERE, "libvfmseg_hip_f16.so")
 OBJ = os.path.join(HERE, "build")
+OBJ_F16 = os.path.join(HERE, "build_f16")
+# bf16-only kernels that have no place in the fp16 twin (split-bf16 precision mode; the persistent GEMM experiment)
+BF16_ONLY = set()
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast", "-Wno-unused-result",
          "-I" + os.path.join(ROOT, "include")]
 
@@ -39,10 +44,18 @@ def _stale(target, deps):
 EXPERIMENTAL = {"attention_fwd64.hip": "VFM_EXPERIMENTAL_FWD64"}
 
 
-def build(force=False, verbose=True):
-    exp = os.environ.get("VFMSEG_EXPERIMENTAL", "0") == "1"
+def build(force=False, verbose=True, only=None):
+    """Both libraries (or `only` = "bf16" / "f16"); returns the path of the bf16 one."""
+    if only in (None, "bf16"):
+        _build_one(LIB, OBJ, [], force, verbose, exp=os.environ.get("VFMSEG_EXPERIMENTAL", "0") == "1")
+    if only in (None, "f16"):
+        _build_one(LIB_F16, OBJ_F16, ["-DVFM_HALF_F16"], force, verbose, exp=False)
+    return LIB
+
+
+def _build_one(LIB, OBJ, variant_defs, force, verbose, exp):
     srcs = sorted(s for s in glob.glob(os.path.join(HERE, "*.hip")) if exp or os.path.basename(s) not in EXPERIMENTAL)
-    defs = ["-D" + d for d in EXPERIMENTAL.values()] if exp else []
+    defs = (["-D" + d for d in EXPERIMENTAL.values()] if exp else []) + variant_defs
     hdrs = sorted(glob.glob(os.path.join(HERE, "*.h"))) + [os.path.join(ROOT, "include", "vfmseg_hip.h")]
     os.makedirs(OBJ, exist_ok=True)
     jobs = []
@@ -75,4 +88,5 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    print(build(force="--force" in sys.argv, only=only))

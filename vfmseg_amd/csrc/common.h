@@ -7,7 +7,27 @@
 
 #include "../../include/vfmseg_hip.h"
 
-typedef uint16_t bf16_t;  // raw bf16 bits
+// The 16-bit floating type of this build.  The library is compiled twice from the same sources:
+//     libvfmseg_hip.so      (default)          bf16 storage, v_mfma_f32_32x32x16_bf16      - the throughput configuration
+//     libvfmseg_hip_f16.so  (-DVFM_HALF_F16)   IEEE fp16 storage, v_mfma_f32_32x32x16_f16  - what the reference's `--amp` computes in
+//                                              (tools/train.py:87-102 -> mmengine AmpOptimWrapper: fp16 autocast + dynamic loss scale)
+// Everything 16-bit goes through the names below (bf16_t = raw bits of "the half type", vfm_h = its arithmetic type, VFM_MFMA16 = its
+// 32x32x16 MFMA, VFM_DOT2 = its packed dot product, h16_lo / h16_hi = the two halves of a packed pair, VFM_H_ONE = bits of 1.0), so the two builds differ in nothing
+// else; dtype code VFM_BF16 in the C ABI means "the half type of the library that was loaded" (vfm_half_kind() says which).
+typedef uint16_t bf16_t;  // raw bits of the half type
+#ifdef VFM_HALF_F16
+typedef _Float16 vfm_h;
+#define VFM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define VFM_DOT2(a, b, acc) __builtin_amdgcn_fdot2(a, b, acc, false)           /* v_dot2_f32_f16 */
+#define VFM_H_ONE 0x3C00u
+#define VFM_HALF_KIND 1
+#else
+typedef __bf16 vfm_h;
+#define VFM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define VFM_DOT2(a, b, acc) __builtin_amdgcn_fdot2_f32_bf16(a, b, acc, false)  /* v_dot2c_f32_bf16 */
+#define VFM_H_ONE 0x3F80u
+#define VFM_HALF_KIND 0
+#endif
 
 extern thread_local char g_vfm_err[512];
 
@@ -30,10 +50,26 @@ extern thread_local char g_vfm_err[512];
 
 static inline int vfm_dtype_size(int dt) { return dt == VFM_BF16 ? 2 : (dt == VFM_F32 ? 4 : (dt == VFM_U8 ? 1 : 8)); }
 
+#ifdef VFM_HALF_F16
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// low / high half of a packed pair -> fp32
+__device__ __forceinline__ float h16_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float h16_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+#else
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ float h16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float h16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+#endif
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
-  __bf16 b = (__bf16)f;
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 / v_cvt_f16_f32 (RNE, NaN-preserving; fp16 overflows to inf like torch's .half())
+#ifdef VFM_HALF_F16
+  // fp16 only: keep the compiler from folding the producing fma into the conversion (v_fma_mixlo_f16 rounds the exact fma once, the
+  // separate instructions round to fp32 first).  Either is a correct rounding, but WHICH one is picked depends on the surrounding code,
+  // and then two kernels that are meant to be bit-identical (fused vs separate LayerNorm + dropout) differ in one element of 2^13;
+  // "round the fp32 value" is also what torch's .half() of an fp32 result does.
+  asm("" : "+v"(f));
+#endif
+  vfm_h b = (vfm_h)f;
   return *reinterpret_cast<bf16_t*>(&b);
 }
 

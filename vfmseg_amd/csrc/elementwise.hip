@@ -5,6 +5,7 @@ thread_local char g_vfm_err[512] = {0};
 
 extern "C" const char* vfm_last_error(void) { return g_vfm_err; }
 extern "C" int vfm_abi_version(void) { return 1; }
+extern "C" int vfm_half_kind(void) { return VFM_HALF_KIND; }
 
 // ------------------------------------------------------------------------------------------------ cast
 template <typename TI, typename TO>
@@ -361,10 +362,10 @@ struct F8 { float v[8]; };
 __device__ __forceinline__ F8 ld8_bf16(const bf16_t* p) {
   const uint4 u = *reinterpret_cast<const uint4*>(p);
   F8 r;
-  r.v[0] = __uint_as_float(u.x << 16), r.v[1] = __uint_as_float(u.x & 0xffff0000u);
-  r.v[2] = __uint_as_float(u.y << 16), r.v[3] = __uint_as_float(u.y & 0xffff0000u);
-  r.v[4] = __uint_as_float(u.z << 16), r.v[5] = __uint_as_float(u.z & 0xffff0000u);
-  r.v[6] = __uint_as_float(u.w << 16), r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+  r.v[0] = h16_lo(u.x), r.v[1] = h16_hi(u.x);
+  r.v[2] = h16_lo(u.y), r.v[3] = h16_hi(u.y);
+  r.v[4] = h16_lo(u.z), r.v[5] = h16_hi(u.z);
+  r.v[6] = h16_lo(u.w), r.v[7] = h16_hi(u.w);
   return r;
 }
 __device__ __forceinline__ void st8_bf16(bf16_t* p, const F8& r) {

@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
       for (int i = 0; i < C::MI; ++i)
 #pragma unroll
         for (int j = 0; j < C::NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][i], bfr[cur][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = VFM_MFMA16(af[cur][i], bfr[cur][j], acc[i][j]);
     }
   }
 

@@ -3,7 +3,7 @@
 #include "gemm_epilogue.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef vfm_h bf16x8 __attribute__((ext_vector_type(8)));
 
 #define BK 64
 
@@ -277,11 +277,11 @@ __device__ __forceinline__ void gelu_pair(f32x2 v, f32x2& g, f32x2& dg) {
 }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(f32x2 v) {
-  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef vfm_h bf16x2_t __attribute__((ext_vector_type(2)));
   const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);   // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
   return *reinterpret_cast<const uint32_t*>(&b);
 }
-__device__ __forceinline__ f32x2 unpack_bf16x2(uint32_t w) { return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+__device__ __forceinline__ f32x2 unpack_bf16x2(uint32_t w) { return f32x2{h16_lo(w), h16_hi(w)}; }
 
 template <int MODE, int CDT, int RES, int C2MODE, int MI, int NI, int GROUP>
 __device__ __forceinline__ void epi_fast8(const EpiParams& e, long zoff, f32x16 (&acc)[MI][NI], float* img, int lane, long m_base,
@@ -585,7 +585,7 @@ __device__ __forceinline__ void skinny_tile(const bf16_t* __restrict__ A, long l
 #pragma unroll
     for (int s2 = 0; s2 < 8; ++s2) {
       const bf16x8 bf = *reinterpret_cast<const bf16x8*>(W + fr * 256 + (((2 * s2 + fh) ^ (fr & 15)) << 4));
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s2], bf, acc, 0, 0, 0);
+      acc = VFM_MFMA16(af[s2], bf, acc);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -598,7 +598,7 @@ __device__ __forceinline__ void skinny_tile(const bf16_t* __restrict__ A, long l
     for (int s2 = 0; s2 < 4; ++s2) {
       const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + k0 + 16 * s2);
       const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bz + bn * ldb + fh * 8 + k0 + 16 * s2);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      acc = VFM_MFMA16(a, b, acc);
     }
   }
   __syncthreads();  // every wave is done with its staging slice: the partial sums reuse that memory

@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(512)
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[QM * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][s], bfr[j][s], acc[QM * 2 + i][j], 0, 0, 0);
+          acc[QM * 2 + i][j] = VFM_MFMA16(af[i][s], bfr[j][s], acc[QM * 2 + i][j]);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (X != 6) {
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(512)
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[BUF][i][s], bfr[BUF][s], acc[i][0], 0, 0, 0);
+          acc[i][0] = VFM_MFMA16(af[BUF][i][s], bfr[BUF][s], acc[i][0]);
       __builtin_amdgcn_s_setprio(0);
     };
     __builtin_amdgcn_sched_barrier(0);

@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(512) k_gemm_ps(const bf16_t* __restrict__ A, l
       const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        cpk[c] = pack2(ex[2 * c] * __uint_as_float(aw[c] << 16), ex[2 * c + 1] * __uint_as_float(aw[c] & 0xffff0000u));
+        cpk[c] = pack2(ex[2 * c] * h16_lo(aw[c]), ex[2 * c + 1] * h16_hi(aw[c]));
     }
     if constexpr (DBG & 1) {
       asm volatile("" ::"v"(cpk[0]), "v"(cpk[1]), "v"(cpk[2]), "v"(cpk[3]));
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(512) k_gemm_ps(const bf16_t* __restrict__ A, l
       const char* pb = smem + sb * PS_UNIT + rb[rs];
       ps_for<4>([&](auto Mc) {
         constexpr int m = decltype(Mc)::value, i = m >> 1, j = m & 1;
-        if constexpr (!(DBG & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+        if constexpr (!(DBG & 4)) acc[i][j] = VFM_MFMA16(fa[cur][i], fb[cur][j], acc[i][j]);
         if constexpr (!(DBG & 16)) {
           if constexpr (m < 2) fa[nxt][m] = *reinterpret_cast<const bf16x8*>(pa + m * 4096);
           else fb[nxt][m - 2] = *reinterpret_cast<const bf16x8*>(pb + (m - 2) * 4096);

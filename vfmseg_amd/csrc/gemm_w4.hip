@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
     };
     static_for<NMF>([&](auto Mc) {
       constexpr int m = decltype(Mc)::value, i4 = m / NI, j = m % NI;
-      acc[i4 >> 1][i4 & 1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cur][i4], fb[cur][j], acc[i4 >> 1][i4 & 1][j], 0, 0, 0);
+      acc[i4 >> 1][i4 & 1][j] = VFM_MFMA16(fa[cur][i4], fb[cur][j], acc[i4 >> 1][i4 & 1][j]);
       // memory op k goes behind MFMA floor(k * NMF / NOPS): one per gap where there are more MFMAs than ops
       static_for<NOPS>([&](auto Kc) {
         if constexpr (decltype(Kc)::value * NMF / NOPS == m) memop(Kc);
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
       __builtin_amdgcn_sched_barrier(0);
     });
     if constexpr (CLS) {  // the tail rows' MFMA of this k-step against the wave's own B fragment; next k-step's tail fragment
-      acc_cls = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fc[cur], fb[cur][0], acc_cls, 0, 0, 0);
+      acc_cls = VFM_MFMA16(fc[cur], fb[cur][0], acc_cls);
       if constexpr (READ) fc[nxt] = *reinterpret_cast<const bf16x8*>(cls_base + cls_off + rc[rs]);
       __builtin_amdgcn_sched_barrier(0);
     }

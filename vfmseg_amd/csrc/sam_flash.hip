@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
   stager.fetch_first_bias(bimg, geo, tid);   // (its padded tokens: from the bias image, after the barrier)
   // ---- prologue 2: T^T[j, q] = tbl[j, :] . q  (rows j = relative index), both axes, into the wave-private images
   // (stored as bf16 of T / scale, the value the query operand carries; aliased with the start of the K/V ring)
-  __bf16* th = reinterpret_cast<__bf16*>(smem) + wave * (2 * C::JP * 32);
+  vfm_h* th = reinterpret_cast<vfm_h*>(smem) + wave * (2 * C::JP * 32);
   const float inv = 1.0f / p.scale;
 #pragma unroll
   for (int which = 0; which < 2; ++which)
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
         acc = SF_MFMA(a, qa[kk], acc);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) th[(which * C::JP + jb * 32 + sf_acc_row(r, h)) * 32 + fr] = (__bf16)(acc[r] * inv);
+      for (int r = 0; r < 16; ++r) th[(which * C::JP + jb * 32 + sf_acc_row(r, h)) * 32 + fr] = (vfm_h)(acc[r] * inv);
     }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
         for (int e = 0; e < 8; ++e) {
           const int kx = 16 * ks + 8 * h + e;        // key coordinate along this axis
           const int j = (which ? qw : qh) - kx + S - 1;
-          u[e] = kx < S ? th[(which * C::JP + j) * 32 + fr] : (__bf16)0.f;
+          u[e] = kx < S ? th[(which * C::JP + j) * 32 + fr] : (vfm_h)0.f;
         }
         qa[5 + which * (C::SP / 16) + ks] = u;
       }
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
   // the 32 row-sum adds per tile and lane leave the VALU, which is what bounds this kernel.
   for (int i = tid; i < 2 * 64 * 2; i += C::NT) {
     const int buf = i / 128, rem = i - buf * 128, row = rem >> 1, c = rem & 1;
-    *reinterpret_cast<uint4*>(smem + buf * C::TILE + 64 * C::KS + row * C::VS + 160 + c * 16) = make_uint4(c == 0 ? 0x00003F80u : 0u, 0, 0, 0);
+    *reinterpret_cast<uint4*>(smem + buf * C::TILE + 64 * C::KS + row * C::VS + 160 + c * 16) = make_uint4(c == 0 ? VFM_H_ONE : 0u, 0, 0, 0);
   }
   commit(0, 0);
   SF_T(3)
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_fwd(SamFlas
       }
       bf16x8 pb;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) pb[e] = (__bf16)sacc[n >> 1][8 * (n & 1) + e];
+      for (int e = 0; e < 8; ++e) pb[e] = (vfm_h)sacc[n >> 1][8 * (n & 1) + e];
 #pragma unroll
       for (int j = 0; j < 3; ++j) oacc[j] = SF_MFMA(vf[n & 1][j], pb, oacc[j]);
     }

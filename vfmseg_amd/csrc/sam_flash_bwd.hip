@@ -62,8 +62,8 @@ __device__ __forceinline__ float sf_dot8(uint4 a, uint4 b) {
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    s += __uint_as_float(x[i] << 16) * __uint_as_float(y[i] << 16);
-    s += __uint_as_float(x[i] & 0xFFFF0000u) * __uint_as_float(y[i] & 0xFFFF0000u);
+    s += h16_lo(x[i]) * h16_lo(y[i]);
+    s += h16_hi(x[i]) * h16_hi(y[i]);
   }
   return s;
 }
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
         for (int s = 0; s < 2; ++s) {
           bf16x8 pb;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) pb[e] = (__bf16)sacc[8 * s + e];
+          for (int e = 0; e < 8; ++e) pb[e] = (vfm_h)sacc[8 * s + e];
 #pragma unroll
           for (int j = 0; j < NJ; ++j) dq[j] = SF_MFMA(trk.frag(kt + (kb * 32 + 16 * s) * CB::KS, j), pb, dq[j]);
         }
@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dq(SamFlash
         for (int e = 0; e < 8; ++e) {
           const int jj = 16 * js + 4 * h + (e & 3) + 8 * (e >> 2);       // the k index the transposing read pairs with element e
           const int kx = (which ? qw : qh) - jj + S - 1;                 // key coordinate whose bias used table row jj
-          pb[e] = (kx >= 0 && kx < S) ? (__bf16)db[(which * C::SP + kx) * 32 + fr] : (__bf16)0.f;
+          pb[e] = (kx >= 0 && kx < S) ? (vfm_h)db[(which * C::SP + kx) * 32 + fr] : (vfm_h)0.f;
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) dq[j] = SF_MFMA(sf_tr_frag(timg + which * C::JP * C::TS, C::TS, 16 * js, j, lane), pb, dq[j]);
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlas
     for (int which = 0; which < 2; ++which) {
       const int slot = (which ? kw : kh) - 8 * h;
       oh_idx[which] = slot >> 1;
-      oh_val[which] = (slot & 1) ? 0x3F800000u : 0x00003F80u;
+      oh_val[which] = (slot & 1) ? (VFM_H_ONE << 16) : VFM_H_ONE;
     }
   }
   auto onehot = [&](int which, int ks) __attribute__((always_inline)) -> bf16x8 {
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(SamFlashCfg<S>::NT, 2) k_sam_flash_dkv(SamFlas
         for (int s = 0; s < 2; ++s) {
           bf16x8 pp_, ps_;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) pp_[e] = (__bf16)sacc[8 * s + e], ps_[e] = (__bf16)dp[8 * s + e];
+          for (int e = 0; e < 8; ++e) pp_[e] = (vfm_h)sacc[8 * s + e], ps_[e] = (vfm_h)dp[8 * s + e];
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             dv[j] = SF_MFMA(trd.frag(dt + (qb * 32 + 16 * s) * CB::VS, j), pp_, dv[j]);

@@ -4,7 +4,7 @@
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef vfm_h bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 #define SF_D 80
@@ -12,7 +12,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define SF_EXP 0   // timing experiments (tools/scratch/_sam_flash_exp.sh): 1 no restaging, 2 no exp, 3 no P V, 4 no Q K, 5 prologue only
 #endif
 #define SF_LOG2E 1.4426950408889634f
-#define SF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define SF_MFMA(a, b, c) VFM_MFMA16(a, b, c)
 
 struct SamFlashP {
   const bf16_t* qkv; long ld;        // token-major [nimg*G*G, 3*H*80]
@@ -54,7 +54,7 @@ __device__ __forceinline__ f32x16 sf_zero() {
   return z;
 }
 __device__ __forceinline__ uint32_t sf_pack2(float a, float b) {
-  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  typedef vfm_h b2 __attribute__((ext_vector_type(2)));
   typedef float f2 __attribute__((ext_vector_type(2)));
   const b2 v = __builtin_convertvector(f2{a, b}, b2);
   return *reinterpret_cast<const uint32_t*>(&v);
@@ -221,7 +221,7 @@ struct SfKvStager {
       uint4 o = make_uint4(0, 0, 0, 0);
       const int want = (c < C::SP / 8 ? kh : kw + C::SP) - 8 * c;   // position of the 1 inside this piece, if 0..7
       if (want >= 0 && want < 8) {   // (a key beyond the window gets some row's columns: it is masked anyway)
-        const uint32_t val = (want & 1) ? 0x3F800000u : 0x00003F80u;
+        const uint32_t val = (want & 1) ? (VFM_H_ONE << 16) : VFM_H_ONE;
         const int wi = want >> 1;
         o = make_uint4(wi == 0 ? val : 0u, wi == 1 ? val : 0u, wi == 2 ? val : 0u, wi == 3 ? val : 0u);
       }

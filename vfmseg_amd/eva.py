@@ -13,6 +13,7 @@ import math
 import torch
 import torch.nn as nn
 
+from .precision import is_half
 from . import ops
 from .backbones import R_PAD, LoraLinear, Packed, _BackboneFn, _Lin, _PatchEmbed, _pack_at, _refresh_sites, _wgrad_small_t
 from .precision import compute_dtype
@@ -293,7 +294,7 @@ class EvaEngine:
         M, Mp, nimg, Np = ctx["M"], ctx["Mp"], ctx["nimg"], ctx["Np"]
         dx = torch.zeros(M, D, dtype=torch.float32, device=dev)
         grads = [None] * (2 * len(v.blocks))
-        fuse_t = cd == torch.bfloat16 and D % 256 == 0  # LN backward emits the next dgrad operand bf16(dx) itself
+        fuse_t = is_half(cd) and D % 256 == 0  # LN backward emits the next dgrad operand bf16(dx) itself
         if fuse_t and "ones" not in P:
             P["ones"] = torch.ones(D, dtype=torch.float32, device=dev)
 

@@ -6,6 +6,7 @@ corresponding forward input, so autograd never inserts a cast of its own.
 """
 import torch
 
+from .precision import is_half
 from . import ops
 from .precision import compute_dtype
 
@@ -257,7 +258,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.has_res and ctx.needs_input_grad[1]:
             d_res = dy if dy.dtype == ctx.res_dtype else _cast_new(dy, ctx.res_dtype)
         # effective gradient of the linear part, in the compute dtype, zero-padded to a multiple of 64 columns (bf16)
-        npad = _pad64(N) if cd == torch.bfloat16 else N
+        npad = _pad64(N) if is_half(cd) else N
         if mask is None and act is None and dy.dtype == cd and npad == N and dy.data_ptr() % 16 == 0:
             g = gv = dy          # already the GEMM operand: no copy
         else:
@@ -276,7 +277,7 @@ class LinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty(M, Kp, dtype=cd, device=dy.device)
-            if cd == torch.bfloat16:
+            if is_half(cd):
                 ops.gemm(g, wp, dx, trans_b=True, kb_rows=N)   # dX = g @ W: the packed weight [N, Kp] is the [K, N'] operand
             else:
                 ops.gemm(gv, wp, dx, trans_b=True)
@@ -298,8 +299,8 @@ class LinearFn(torch.autograd.Function):
                 ops.colsum(gv, dbias)
         dws = [None] * len(weights)
         if any(ctx.needs_input_grad[4:]):
-            gw = torch.empty(npad if cd == torch.bfloat16 else N, Kp, dtype=torch.float32, device=dy.device)
-            if cd == torch.bfloat16:
+            gw = torch.empty(npad if is_half(cd) else N, Kp, dtype=torch.float32, device=dy.device)
+            if is_half(cd):
                 mp = _pad64(M)
                 tiles = ((N + 127) // 128) * ((Kp + 127) // 128)
                 kch = 1

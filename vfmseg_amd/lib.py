@@ -1,5 +1,9 @@
-"""ctypes binding of libvfmseg_hip.so (include/vfmseg_hip.h).  The product path has NO fallback: if the
-library is missing or a tensor is not on the GPU, the ops raise."""
+"""ctypes binding of libvfmseg_hip.so and its fp16 twin libvfmseg_hip_f16.so (include/vfmseg_hip.h: same sources, same ABI, built with
+-DVFM_HALF_F16).  The product path has NO fallback: if the library is missing or a tensor is not on the GPU, the ops raise.
+
+Which library `load()` returns follows the precision mode (precision.set_compute_dtype -> set_half): bf16 / f32 / bf16x3 use the
+bf16 library, "fp16" (the autocast dtype of the reference's `--amp`) the twin.  dtype code BF16 = "the 16-bit type of the active
+library"; handing a torch.float16 tensor to the bf16 library (or the reverse) raises in dt_of()."""
 import ctypes as C
 import os
 
@@ -7,6 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvfmseg_hip.so")
+LIB_PATH_F16 = os.path.join(_HERE, "csrc", "libvfmseg_hip_f16.so")
 
 F32, BF16, U8, I64 = 0, 1, 2, 3
 EP_NONE, EP_GELU, EP_RELU, EP_MUL_GELU_GRAD, EP_MUL, EP_QGELU, EP_MUL_QGELU_GRAD, EP_GELU_DGELU = 0, 1, 2, 3, 4, 5, 6, 7
@@ -112,30 +117,57 @@ SIGNATURES = {
     "vfm_adamw": [vp, vp, vp, vp, cl, vp, vp, vp, ci, cf, cf, cf, cf, ci, cf, ci, ci, vp],
 }
 
-_lib = None
+_lib = None          # the ACTIVE library (what load() returns)
+_libs = {}           # half kind (0 bf16, 1 fp16) -> loaded library
+_half = 0            # active half kind
+HALF_DTYPES = (torch.bfloat16, torch.float16)
 
 
 class HipLibraryMissing(RuntimeError):
     pass
 
 
-def load():
-    """Load the shared library (once). Raises HipLibraryMissing - there is no CPU fallback in the product path."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _open(kind):
+    path = LIB_PATH_F16 if kind else LIB_PATH
+    if not os.path.exists(path):
         raise HipLibraryMissing(
-            f"{LIB_PATH} not found: build it with `python -m vfmseg_amd.csrc.build` (hipcc --offload-arch=gfx950)")
-    lib = C.CDLL(LIB_PATH)
+            f"{path} not found: build it with `python -m vfmseg_amd.csrc.build` (hipcc --offload-arch=gfx950)")
+    lib = C.CDLL(path)
     lib.vfm_last_error.restype = C.c_char_p
     lib.vfm_abi_version.restype = ci
+    lib.vfm_half_kind.restype = ci
+    if lib.vfm_half_kind() != kind:
+        raise HipLibraryMissing(f"{path} reports half kind {lib.vfm_half_kind()}, expected {kind}: stale build")
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = ci
-    _lib = lib
     return lib
+
+
+def load():
+    """The active shared library (loaded once). Raises HipLibraryMissing - there is no CPU fallback in the product path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if _half not in _libs:
+        _libs[_half] = _open(_half)
+    _lib = _libs[_half]
+    return _lib
+
+
+def set_half(kind):
+    """Select the library whose 16-bit type is bf16 (0 / torch.bfloat16) or IEEE fp16 (1 / torch.float16).  Loaded lazily."""
+    global _half, _lib
+    kind = {torch.bfloat16: 0, torch.float16: 1, "bf16": 0, "fp16": 1, "f16": 1}.get(kind, kind)
+    assert kind in (0, 1)
+    if kind != _half:
+        _half, _lib = kind, None
+
+
+def half_dtype():
+    """torch dtype of the active library's 16-bit type."""
+    return torch.float16 if _half else torch.bfloat16
 
 
 class HipError(RuntimeError):
@@ -170,7 +202,9 @@ def set_device_index(i):
 def dt_of(t):
     if t.dtype == torch.float32:
         return F32
-    if t.dtype == torch.bfloat16:
+    if t.dtype == torch.bfloat16 or t.dtype == torch.float16:
+        if (t.dtype == torch.float16) != bool(_half):
+            raise TypeError(f"{t.dtype} tensor handed to the {'fp16' if _half else 'bf16'} library (precision mode and tensors disagree)")
         return BF16
     if t.dtype == torch.uint8 or t.dtype == torch.bool:
         return U8
@@ -180,7 +214,7 @@ def dt_of(t):
 
 
 def torch_dt(code):
-    return torch.float32 if code == F32 else torch.bfloat16
+    return torch.float32 if code == F32 else half_dtype()
 
 
 def ptr(t):

@@ -6,6 +6,7 @@ import ctypes as C
 
 import torch
 
+from .precision import is_half
 from . import lib as L
 from .lib import (ACT_GELU, ACT_NONE, ACT_QGELU, ACT_RELU, BF16, EP_GELU, EP_GELU_DGELU, EP_MUL, EP_MUL_GELU_GRAD,  # noqa: F401
                   EP_MUL_QGELU_GRAD, EP_NONE, EP_QGELU, EP_RELU, F32)
@@ -242,7 +243,7 @@ def layernorm_dropout_fwd(x, w, b, eps, y, stats, y_drop, mask, p, seed, offset=
     """LN forward that also writes the dropout multiplier `mask` and y_drop = y * mask (bf16 outputs, C % 256 == 0)."""
     lib = L.load()
     rows, c = x.shape
-    assert y.dtype == torch.bfloat16 and y_drop.dtype == torch.bfloat16 and mask.dtype == torch.bfloat16
+    assert is_half(y.dtype) and is_half(y_drop.dtype) and is_half(mask.dtype)
     L.check(lib.vfm_layernorm_dropout_fwd(L.ptr(x), _ld(x), L.ptr(w), L.ptr(b), float(eps), L.ptr(y), _ld(y), L.ptr(stats),
                                           L.ptr(y_drop), _ld(y_drop), L.ptr(mask), _ld(mask), float(p), int(seed), int(offset),
                                           rows, c, L.stream()), "vfm_layernorm_dropout_fwd")
@@ -253,7 +254,7 @@ def layernorm_bwd_scaled(dy, x, w, stats, dx, t_out, t_scale, accumulate_dx=Fals
     """LN backward into dx (fp32) that also emits t_out = bf16(dx_new * t_scale[c])."""
     lib = L.load()
     rows, c = x.shape
-    assert t_out.dtype == torch.bfloat16 and t_scale.dtype == torch.float32
+    assert is_half(t_out.dtype) and t_scale.dtype == torch.float32
     L.check(lib.vfm_layernorm_bwd_scaled(L.ptr(dy), L.dt_of(dy), _ld(dy), L.ptr(x), _ld(x), L.ptr(w), L.ptr(stats), L.ptr(dx),
                                          _ld(dx), int(accumulate_dx), L.ptr(t_out), _ld(t_out), L.ptr(t_scale), rows, c,
                                          L.stream()), "vfm_layernorm_bwd_scaled")
@@ -342,7 +343,7 @@ def split3(x, pattern, trans=False, cache=False):
     rows, K = (x.shape[1], x.shape[0]) if trans else (x.shape[0], x.shape[1])
     sr, sc = (x.stride(1), x.stride(0)) if trans else (x.stride(0), x.stride(1))
     kp = (K + 63) // 64 * 64
-    out = torch.empty(rows, 3 * kp, dtype=torch.bfloat16, device=x.device)
+    out = torch.empty(rows, 3 * kp, dtype=L.half_dtype(), device=x.device)
     L.check(L.load().vfm_split3(L.ptr(x), sr, sc, L.ptr(out), out.stride(0), rows, K, pattern, L.stream()), "vfm_split3")
     if cache:
         try:
@@ -405,7 +406,7 @@ def gemm(a, b, c, *, alpha=1.0, bias=None, bias_mod=0, colscale=None, residual=N
         d.batch, d.stride_a, d.stride_b, d.stride_c = a.shape[0], a.stride(0), b.stride(0), c.stride(0)
     else:
         d.batch = 1
-    fin = PROFILE("gemm", 2.0 * M * N * K * d.batch, REGION[-1]) if (PROFILE is not None and a.dtype == torch.bfloat16) else None
+    fin = PROFILE("gemm", 2.0 * M * N * K * d.batch, REGION[-1]) if (PROFILE is not None and is_half(a.dtype)) else None
     L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
     if fin is not None:
         fin()
@@ -568,7 +569,7 @@ def attn_fwd(q, k, v, o, lse, B, H, d, nq_main, nq_extra, nk_main, nk_extra, sca
         return o
     a = _attn_desc(q, k, v, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, lse)
     fin = None
-    if PROFILE is not None and q.dtype == torch.bfloat16:   # QK^T + PV: 4 B H Nq Nk d
+    if PROFILE is not None and is_half(q.dtype):   # QK^T + PV: 4 B H Nq Nk d
         fin = PROFILE("attn_fwd", 4.0 * B * H * (nq_main + nq_extra) * (nk_main + nk_extra) * d, REGION[-1])
     L.check(lib.vfm_attn_fwd(C.byref(a), L.stream()), "vfm_attn_fwd")
     if fin is not None:
@@ -589,7 +590,7 @@ def attn_bwd(q, k, v, o, lse, dout, dq, dk, dv, B, H, d, nq_main, nq_extra, nk_m
         delta = _attn_bwd_ws[key] = torch.zeros(B * H * (nq_main + nq_extra) + B * H * 192, dtype=torch.float32, device=q.device)
     a.delta = L.ptr(delta)
     fin = None
-    if PROFILE is not None and q.dtype == torch.bfloat16:   # algorithmic: S, dP, dV, dK, dQ = five products = 10 B H Nq Nk d
+    if PROFILE is not None and is_half(q.dtype):   # algorithmic: S, dP, dV, dK, dQ = five products = 10 B H Nq Nk d
         fin = PROFILE("attn_bwd", 10.0 * B * H * (nq_main + nq_extra) * (nk_main + nk_extra) * d, REGION[-1])
     L.check(lib.vfm_attn_bwd(C.byref(a), L.stream()), "vfm_attn_bwd")
     if fin is not None:
@@ -606,7 +607,7 @@ def sam_relpos_table(rel_pos, S, out):
 def sam_attn_flash_fwd(qkv, bias, tbl_h, tbl_w, out, nimg, G, S, H, d, scale):
     """One-launch SAM attention forward (inference): qkv [M, 3*H*d] bf16 -> out [M, H*d] bf16."""
     lib = L.load()
-    assert qkv.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and tbl_h.dtype == torch.bfloat16 and tbl_h.is_contiguous()
+    assert is_half(qkv.dtype) and is_half(out.dtype) and is_half(tbl_h.dtype) and tbl_h.is_contiguous()
     fin = None
     if PROFILE is not None:   # algorithmic FLOPs: q.k and p.v over the S*S keys of every window token (bias products not counted)
         nws = 1 if S == 32 else (G + S - 1) // S
@@ -622,14 +623,14 @@ def sam_attn_flash_stats(nimg, G, S, H, dev):
     """Buffers the training forward leaves for the backward: lse [rows] fp32, qext [rows, 2*SP] bf16 (rows = window-heads x 256 / 1024)."""
     nws = 1 if S == 32 else (G + S - 1) // S
     rows = nimg * nws * nws * H * (256 if S == 14 else 1024)
-    return (torch.empty(rows, dtype=torch.float32, device=dev), torch.empty(rows, 2 * (16 if S == 14 else 32), dtype=torch.bfloat16, device=dev))
+    return (torch.empty(rows, dtype=torch.float32, device=dev), torch.empty(rows, 2 * (16 if S == 14 else 32), dtype=L.half_dtype(), device=dev))
 
 
 def sam_attn_flash_fwd_train(qkv, bias, tbl_h, tbl_w, out, lse, qext, nimg, G, S, H, d, scale):
     """sam_attn_flash_fwd that also writes the per-query log2-sum-exp and the bias columns of the query operand."""
     lib = L.load()
-    assert qkv.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and tbl_h.dtype == torch.bfloat16 and tbl_h.is_contiguous()
-    assert lse.dtype == torch.float32 and qext.dtype == torch.bfloat16 and qext.is_contiguous()
+    assert is_half(qkv.dtype) and is_half(out.dtype) and is_half(tbl_h.dtype) and tbl_h.is_contiguous()
+    assert lse.dtype == torch.float32 and is_half(qext.dtype) and qext.is_contiguous()
     L.check(lib.vfm_sam_attn_flash_fwd_train(L.ptr(qkv), _ld(qkv), L.ptr(bias), L.ptr(tbl_h), L.ptr(tbl_w), L.ptr(out), _ld(out), nimg, G, S, H, d,
                                              float(scale), L.ptr(lse), L.ptr(qext), L.stream()), "vfm_sam_attn_flash_fwd_train")
     return out
@@ -638,7 +639,7 @@ def sam_attn_flash_fwd_train(qkv, bias, tbl_h, tbl_w, out, lse, qext, nimg, G, S
 def sam_attn_flash_bwd(qkv, bias, tbl_h, tbl_w, out, dout, lse, qext, dqkv, nimg, G, S, H, d, scale):
     """d(out) [M, H*d] -> dqkv [M, 3*H*d] (bf16, every element written) in two launches (csrc/sam_flash_bwd.hip)."""
     lib = L.load()
-    assert all(t.dtype == torch.bfloat16 for t in (qkv, out, dout, dqkv, qext)) and _ld(out) == _ld(dout)
+    assert all(is_half(t.dtype) for t in (qkv, out, dout, dqkv, qext)) and _ld(out) == _ld(dout)
     dsum = torch.empty_like(lse)
     L.check(lib.vfm_sam_attn_flash_bwd(L.ptr(qkv), _ld(qkv), L.ptr(bias), L.ptr(tbl_h), L.ptr(tbl_w), L.ptr(out), L.ptr(dout), _ld(out), L.ptr(lse),
                                        L.ptr(qext), L.ptr(dsum), L.ptr(dqkv), _ld(dqkv), nimg, G, S, H, d, float(scale), L.stream()),

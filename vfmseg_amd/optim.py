@@ -201,15 +201,21 @@ class AmpOptimWrapper(OptimWrapper):
     step, x2 after `growth_interval` = 2000 consecutive good ones).  A number or a dict(init_scale=, growth_factor=,
     backoff_factor=, growth_interval=) is accepted as in mmengine.
 
-    Autocast dtype: the reference autocasts to fp16 (CUDA default).  This library's low-precision mode is bf16 (MFMA bf16 GEMMs /
-    attention with fp32 accumulation and an fp32 residual stream, vfmseg_amd.precision); fp16 kernels are not offered, so `dtype`
-    other than None / 'bfloat16' raises.  With bf16 the scale never has to back off in practice; the machinery is kept because
-    configs and checkpoints carry it.  The un-scale costs nothing: 1/scale rides on the fused AdamW kernel's grad_scale."""
+    Autocast dtype (`dtype`, as in mmengine): None / 'float16' = fp16, the CUDA autocast default and what the reference's `--amp`
+    runs in - here the precision mode "fp16" (libvfmseg_hip_f16.so: the same kernels with fp16 storage and the fp16 MFMA, fp32
+    accumulation, residual stream, statistics and losses); 'bfloat16' = the bf16 mode, where the scale never has to back off in
+    practice.  The wrapper records the dtype (`self.dtype`, `self.mode`); the Runner / tools/train.py put the engine into that mode
+    (the role of mmengine's optim_context autocast).  The un-scale costs nothing: 1/scale rides on the fused AdamW kernel's grad_scale."""
+
+    _DTYPES = {None: torch.float16, "float16": torch.float16, "fp16": torch.float16, "half": torch.float16, torch.float16: torch.float16,
+               "bfloat16": torch.bfloat16, "bf16": torch.bfloat16, torch.bfloat16: torch.bfloat16}
 
     def __init__(self, optimizer, scheduler=None, grad_sync=None, loss_scale="dynamic", dtype=None):
         super().__init__(optimizer, scheduler, grad_sync)
-        if dtype not in (None, "bfloat16", "bf16", torch.bfloat16):
-            raise NotImplementedError("AmpOptimWrapper: autocast dtype %r is not offered on this backend (bf16 only)" % (dtype,))
+        if dtype not in self._DTYPES:
+            raise NotImplementedError("AmpOptimWrapper: autocast dtype %r (float16 and bfloat16 are the ones torch.autocast offers on a GPU)" % (dtype,))
+        self.dtype = self._DTYPES[dtype]
+        self.mode = "fp16" if self.dtype == torch.float16 else "bf16"
         self.growth_factor, self.backoff_factor, self.growth_interval = 2.0, 0.5, 2000
         self.dynamic = True
         if loss_scale == "dynamic":
@@ -239,16 +245,21 @@ class AmpOptimWrapper(OptimWrapper):
         else:
             self.optimizer.step(lr, grad_scale=getattr(self.grad_sync, "post_scale", 1.0) / self.scale, zero_grad=True)
         self.optimizer.zero_grad()
-        if self.dynamic:   # GradScaler.update
-            if found_inf:
-                self.scale *= self.backoff_factor
-                self.growth_tracker = 0
-            else:
-                self.growth_tracker += 1
-                if self.growth_tracker == self.growth_interval:
-                    self.scale *= self.growth_factor
-                    self.growth_tracker = 0
+        self._update_scale(found_inf)
         self.iter += 1
+
+    def _update_scale(self, found_inf):
+        """torch GradScaler.update(): x backoff after a skipped step, x growth after growth_interval consecutive good ones."""
+        if not self.dynamic:
+            return
+        if found_inf:
+            self.scale *= self.backoff_factor
+            self.growth_tracker = 0
+        else:
+            self.growth_tracker += 1
+            if self.growth_tracker == self.growth_interval:
+                self.scale *= self.growth_factor
+                self.growth_tracker = 0
 
     def state_dict(self):
         return dict(iter=self.iter, loss_scaler=dict(scale=self.scale, growth_factor=self.growth_factor, backoff_factor=self.backoff_factor,

@@ -8,8 +8,14 @@ bf16x3 - the f32 configuration (fp32 tensors, exact-fp32 attention / norms / los
         GEMM over split operands ([hi | hi | lo] x [hi | lo | hi], K' = 3 K, fp32 accumulate; ops.gemm / vfm_split3): 16 significant bits
         per operand instead of 24 - products to ~2^-16 relative, three orders inside north_star's 1e-3 - at a third of the bf16 GEMM
         rate instead of the fp32 MFMA's 1/16.  The in-tolerance mode with a usable speed.
+fp16  - the bf16 configuration with IEEE fp16 in place of bf16 everywhere (libvfmseg_hip_f16.so: fp16 storage, v_mfma_f32_32x32x16_f16,
+        fp32 accumulation / residual stream / statistics / losses): what the reference's `--amp` computes in (tools/train.py:87-102 ->
+        mmengine AmpOptimWrapper: torch.autocast(fp16) + GradScaler).  Needs the dynamic loss scale (optim.AmpOptimWrapper): fp16
+        gradients under- and overflow where bf16 ones do not.
 """
 import torch
+
+from . import lib as _L
 
 _compute = torch.bfloat16
 _split3 = False
@@ -22,9 +28,10 @@ def set_compute_dtype(dt):
         dt = "f32"
     if isinstance(dt, str):
         dt = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "f32": torch.float32, "fp32": torch.float32,
-              "float32": torch.float32}[dt]
-    assert dt in (torch.bfloat16, torch.float32)
+              "float32": torch.float32, "fp16": torch.float16, "f16": torch.float16, "float16": torch.float16}[dt]
+    assert dt in (torch.bfloat16, torch.float32, torch.float16)
     _compute = dt
+    _L.set_half(torch.float16 if dt == torch.float16 else torch.bfloat16)
 
 
 def compute_dtype():
@@ -32,7 +39,13 @@ def compute_dtype():
 
 
 def is_bf16():
-    return _compute == torch.bfloat16
+    """True in the 16-bit MFMA configurations (bf16, or fp16 with the twin library)."""
+    return _compute in (torch.bfloat16, torch.float16)
+
+
+def is_half(dt):
+    """dt is a 16-bit MFMA operand type (bf16 / fp16)."""
+    return dt == torch.bfloat16 or dt == torch.float16
 
 
 def split3():
@@ -41,4 +54,4 @@ def split3():
 
 
 def mode_name():
-    return "bf16x3" if _split3 else ("bf16" if _compute == torch.bfloat16 else "f32")
+    return "bf16x3" if _split3 else {torch.bfloat16: "bf16", torch.float16: "fp16", torch.float32: "f32"}[_compute]

@@ -77,6 +77,9 @@ class Runner:
         ow_cfg = dict(cfg.get("optim_wrapper", {}))
         ctor = OPTIM_WRAPPER_CONSTRUCTORS.get(ow_cfg.get("constructor", "PEFTOptimWrapperConstructor")) or PEFTOptimWrapperConstructor
         ow = ctor(ow_cfg, ow_cfg.get("paramwise_cfg"))(model, cfg.get("param_scheduler"))
+        if getattr(ow, "mode", None) is not None:   # AmpOptimWrapper: the autocast dtype is the engine's precision mode (fp16 unless the config says bfloat16)
+            from .precision import set_compute_dtype
+            set_compute_dtype(ow.mode)
         parallel.attach(model, ow)
         dl = dict(cfg.get("train_dataloader", {}) or {})
         ds = dl.get("dataset")

@@ -15,6 +15,7 @@ import os
 import torch
 import torch.nn as nn
 
+from .precision import is_half
 from . import ops
 from .backbones import BACKWARD_EVENTS, R_PAD, LoraLinear, Packed, _BackboneFn, _Lin, _PatchEmbed, _pack_at, _refresh_sites, _wgrad_small_t
 from .precision import compute_dtype
@@ -138,7 +139,7 @@ class SamEngine:
                 for r_ in (rh, rw):
                     t_ = torch.zeros(max(JP, 2 * S - 1), d, dtype=torch.float32, device=dev)
                     t_[:2 * S - 1] = r_[idx_q, idx_k]
-                    tb = torch.zeros(t_.shape, dtype=torch.bfloat16, device=dev)
+                    tb = torch.zeros(t_.shape, dtype=cd, device=dev)
                     ops.cast(t_, tb)
                     tbl.append(tb)
                 Lp = dict(
@@ -171,7 +172,7 @@ class SamEngine:
         """-> token-major attention output [nimg*G*G, H*d] (+ the probabilities [nb, NP, NP] when keep=True: rows / columns
         beyond the S*S window tokens are zero, so P can later serve in place as a [K, N] GEMM operand)"""
         S = Lp["S"]
-        if (cd == torch.bfloat16 and d == 80 and (S == 14 or (S == 32 and G == 32))
+        if (is_half(cd) and d == 80 and (S == 14 or (S == 32 and G == 32))
                 and os.environ.get("VFMSEG_SAM_FLASH", "1") != "0"):
             # one flash-style launch, no score matrix (csrc/sam_flash.hip); training keeps lse + the bias columns for sam_flash_bwd.hip
             ao = torch.empty(nimg * G * G, H * d, dtype=cd, device=dev)
@@ -279,7 +280,7 @@ class SamEngine:
             st1 = torch.empty(M, 2, dtype=torch.float32, device=dev) if keep else None
             xd = mask = None
             q = blk.attn.qkv if lora else None
-            if keep and q.p > 0 and cd == torch.bfloat16 and D % 256 == 0:
+            if keep and q.p > 0 and is_half(cd) and D % 256 == 0:
                 mask = torch.empty(M, D, dtype=cd, device=dev)
                 xd = torch.empty(M, D, dtype=cd, device=dev)
                 ops.layernorm_dropout_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1, xd, mask, q.p, seed, offset=rng0 + li * M * D)
