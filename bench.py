@@ -33,7 +33,7 @@ PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md "Peak B
 PEAK_HBM_GBS = 8000.0
 
 
-def build(device, batch, seed=0, workload="ms1024", depth=None):
+def build(device, batch, seed=0, workload="ms1024", depth=None, amp=False):
     _heavy()
     import vfmseg_amd  # noqa: F401  (registers the model classes)
     from vfmseg_amd import presets
@@ -54,7 +54,10 @@ def build(device, batch, seed=0, workload="ms1024", depth=None):
     model = model.to(device)
     model.train()
     oc = presets.optim_cfg()
-    ow = PEFTOptimWrapperConstructor(oc["optim_wrapper"])(model, oc["param_scheduler"])
+    ocw = oc["optim_wrapper"]
+    if amp:   # --dtype fp16: the step the reference's `--amp` runs (fp16 autocast + dynamic loss scale, tools/train.py:87-102)
+        ocw = dict(ocw, type="AmpOptimWrapper", loss_scale="dynamic")
+    ow = PEFTOptimWrapperConstructor(ocw)(model, oc["param_scheduler"])
     return model, ow
 
 
@@ -172,7 +175,7 @@ def eval_leg(device, timer, iters=5):
     return res
 
 
-def parity_leg(device, batch, steps=3, iters=2):
+def parity_leg(device, batch, steps=3, iters=2, modes=("bf16x3", "f32")):
     """The two modes whose results meet north_star's tolerance (logits <= 1e-3 rel, argmax mismatches only on near-ties against the
     reference's fp32 CPU path: tests/test_model_gpu.py::test_ms_inference_matches_reference_golden[f32|bf16x3],
     test_train_step_matches_reference_goldens[f32|bf16x3]) on the same two workloads as the bf16 headline:
@@ -185,12 +188,12 @@ def parity_leg(device, batch, steps=3, iters=2):
     from vfmseg_amd.registry import MODELS
     from vfmseg_amd.synth import synth_image, synth_like
     out = {"what": "in-tolerance modes (the configurations the 1e-3 / argmax parity tests run in), same workloads as the bf16 lines"}
-    for mode in ("bf16x3", "f32"):
+    for mode in modes:
         res = {}
         set_compute_dtype(mode)
         try:
             print(f"[bench] parity-mode leg: {mode} train step", file=sys.stderr, flush=True)
-            model, ow = build(device, batch)
+            model, ow = build(device, batch, amp=(mode == "fp16"))
             data = make_batch(batch, 0, 0, device)
             for _ in range(2):
                 model.train_step(data, ow)
@@ -417,7 +420,7 @@ def main():
         k, v = kv.split("=")
         _ops.tune(k, int(v))
 
-    model, ow = build(device, a.batch, workload=a.workload, depth=a.depth)
+    model, ow = build(device, a.batch, workload=a.workload, depth=a.depth, amp=(a.dtype == "fp16"))
     parallel.attach(model, ow)
     from vfmseg_amd import functional as Fh
     Fh.manual_seed(1234 + rank)
@@ -525,6 +528,11 @@ def main():
                 out["parity_mode"] = parity_leg(device, a.batch)
             except Exception as e:
                 out["parity_mode"] = {"error": repr(e)}
+            try:   # the reference's `--amp` step: fp16 autocast (the fp16 twin library) + dynamic loss scale, same workloads
+                out["amp_fp16"] = dict(parity_leg(device, a.batch, steps=10, iters=5, modes=("fp16",))["fp16"],
+                                       what="tools/train.py --amp: fp16 storage + v_mfma_f32_32x32x16_f16 (libvfmseg_hip_f16.so), AmpOptimWrapper")
+            except Exception as e:
+                out["amp_fp16"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline and a.workload == "ms1024":
             try:
                 out["cpu_baseline"] = cpu_baseline()

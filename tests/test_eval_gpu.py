@@ -149,7 +149,8 @@ def test_lr_and_msfull_slide_modes_match_oracle():
 
 
 # (bf16 bounds = 3x the measured values: logits 8.6e-3, mismatches 8.3e-3, margin 3.2e-3 - profiles/r03_parity_gpu_suite.log)
-@pytest.mark.parametrize("prec,ltol,mtol", [("f32", 1e-3, 2e-4), ("bf16x3", 1e-3, 2e-4), ("bf16", 2.6e-2, 2.5e-2)])
+@pytest.mark.parametrize("prec,ltol,mtol", [("f32", 1e-3, 2e-4), ("bf16x3", 1e-3, 2e-4), ("bf16", 2.6e-2, 2.5e-2),
+                                                ("fp16", 5e-3, 5e-3)])
 def test_slide_modes_match_reference_goldens(golden_dir, prec, ltol, mtol):
     """lr_slide_inference / hr_slide_inference / msfull_slide_inference at full depth on the HIP path against the reference's OWN
     MsVFMEncoderDecoder.inference output in those modes (tests/golden/slide_modes.npz; Ms_VFM_encoder_decoder.py:278-332), msfull with
@@ -177,7 +178,7 @@ def test_slide_modes_match_reference_goldens(golden_dir, prec, ltol, mtol):
             worst = float(margin[diff].max()) if diff.any() else 0.0
             print(f"[parity] {mode} {prec}: logits rel err {max(e1, e2):.2e}, argmax mismatches {diff.mean():.2e}, largest top-2 margin among them {worst:.2e}")
             assert max(e1, e2) < ltol and diff.mean() < mtol
-            assert worst < (1e-4 if prec != "bf16" else 1e-2)   # every flipped pixel is a near-tie at that mode's precision
+            assert worst < {"bf16": 1e-2, "fp16": 2e-3}.get(prec, 1e-4)   # every flipped pixel is a near-tie at that mode's precision
     finally:
         set_compute_dtype("bf16")
 
@@ -217,7 +218,7 @@ def _colour_coded(seed, size=1024):
     return img.contiguous(), lab
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16", "fp16"])
 def test_miou_after_training_within_0p1_of_oracle(mode):
     """Round-2 verdict: the +-0.1 mIoU target was only tested at random-init weights (mIoU 2.3 % on both sides).  Here a depth-4 model is
     first trained for 60 optimiser steps (product train_step, bf16, lr 1e-3) on three colour-coded 1024^2 samples; the trained weights

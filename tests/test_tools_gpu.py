@@ -75,3 +75,27 @@ def test_predict_tta_is_the_mean_of_the_views_softmax(tmp_path):
         assert torch.equal(got.pred_sem_seg.data, want.argmax(0, keepdim=True))
     finally:
         set_compute_dtype("bf16")
+
+
+def test_train_py_amp_runs_in_fp16_with_a_loss_scale(tmp_path):
+    """tools/train.py --amp (tools/train.py:87-102 there: OptimWrapper -> AmpOptimWrapper, loss_scale='dynamic', fp16 autocast): the
+    real entry point switches the wrapper, the engine runs on the fp16 twin library, the checkpoint carries the loss scaler."""
+    p = tmp_path / "cfg.py"
+    p.write_text(
+        "from vfmseg_amd import presets as _p\n"
+        "model = _p.dinov2_ms_masked(depth=4)\n"
+        "model['backbone']['backbone']['out_indices'] = [0, 1, 2, 3]\n"
+        "_o = _p.optim_cfg()\n"
+        "optim_wrapper = _o['optim_wrapper']\n"
+        "param_scheduler = _o['param_scheduler']\n"
+        "train_dataloader = dict(batch_size=1)\n"
+        "default_hooks = dict(logger=dict(interval=2), checkpoint=dict(interval=4))\n")
+    wd = tmp_path / "wd"
+    r = subprocess.run([sys.executable, "tools/train.py", str(p), "--amp", "--data", "synthetic", "--max-iters", "4", "--work-dir", str(wd)],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "precision mode fp16" in r.stdout
+    ck = torch.load(wd / "iter_4.pth", map_location="cpu", weights_only=False)
+    assert ck["optim_wrapper"]["loss_scaler"]["scale"] == 65536.0 and ck["optim_wrapper"]["iter"] == 4
+    losses = [float(x) for x in __import__("re").findall(r"decode_lr\.loss_ce'?[=: ]+([0-9.]+)", r.stdout)]
+    assert losses and all(np.isfinite(losses)), r.stdout[-1500:]

@@ -156,7 +156,18 @@ class _PackCache:
             e["stamp"] = self._stamp([r() for r in e["refs"]])
 
 
-PACKS = _PackCache()
+class _PackCaches:
+    """One cache per library (bf16 / fp16 twin): a refresh re-packs every live entry of ITS cache with the active library's kernels,
+    and entries of the other 16-bit type (models of the other precision mode that are still alive) must not be touched by it."""
+
+    def __init__(self):
+        self.by_lib = {False: _PackCache(), True: _PackCache()}
+
+    def get(self, weights, layouts, dims, Kp, K, cd):
+        return self.by_lib[cd == torch.float16].get(weights, layouts, dims, Kp, K, cd)
+
+
+PACKS = _PackCaches()
 
 
 def direct_grad_target(p):
