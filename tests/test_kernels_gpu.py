@@ -372,7 +372,7 @@ def test_gemm_bf16(M, N, K):
     assert relerr(cw[:, :N], a.double() @ b.double().t()) < 2e-5 and cw[:, N:].abs().sum() == 0
 
 
-@pytest.mark.parametrize("cfg", [17, 16, 30, 31, 32, 33, 34, 35, 36, 10])
+@pytest.mark.parametrize("cfg", [17, 16, 30, 31, 32, 33, 34, 35, 36, 39, 40, 10])
 @pytest.mark.parametrize("M,N,K", [(4100, 1024, 1024), (300, 520, 320), (1024, 2048, 448), (256, 256, 4096), (512, 512, 128)])
 def test_gemm_bf16_configs_fast_epilogues(cfg, M, N, K):
     """Every tile configuration incl. the ping-pong kernels (30: 256x256, 31: 128x128) and the 64-wide-K-tile 256x256 kernels
@@ -500,7 +500,7 @@ def test_gemm_bf16_persistent_two_accumulators(cfg, M, N, K):
         assert relerr(c1.float(), c2.float().double()) < 1e-2
 
 
-@pytest.mark.parametrize("cfg", [-1, 17, 32, 33, 34])  # (35 / 36 need K >= 256)
+@pytest.mark.parametrize("cfg", [-1, 17, 32, 33, 34, 39, 40])  # (35 / 36 need K >= 256)
 def test_gemm_bf16_batched_ragged(cfg):
     """Batched bf16 GEMMs (SAM's per-window products) with ragged M / N, a batch stride wider than the matrix, a bf16 residual
     and the scalar (N % 4 != 0) epilogue, through the default dispatch and the ring kernels; K = 128 and 192 are the shortest

@@ -18,6 +18,13 @@ CASES = [  # (label, M, N, K, kind)
     ("N1024 K4096 bias", 4096, 1024, 4096, "bias"),
     ("N1024 K1024 bias", 4096, 1024, 1024, "bias"),
 ]
+EVAL_CASES = [  # SHAPES=eval: the GEMMs of one 1024^2 prediction (DINOv2-L ms_slide: nine 512^2 windows in one batch, then the 512 x 1024 LR pass; SAM-H slide)
+    ("HR qkv", 9225, 3072, 1024, "bias"), ("HR proj", 9225, 1024, 1024, "bias"), ("HR fc1 gelu", 9225, 4096, 1024, "gelu"), ("HR fc2", 9225, 1024, 4096, "bias"),
+    ("LR qkv", 2049, 3072, 1024, "bias"), ("LR proj", 2049, 1024, 1024, "bias"), ("LR fc1 gelu", 2049, 4096, 1024, "gelu"), ("LR fc2", 2049, 1024, 4096, "bias"),
+    ("SAM qkv", 9216, 3840, 1280, "bias"), ("SAM proj", 9216, 1280, 1280, "bias"), ("SAM fc1 gelu", 9216, 5120, 1280, "gelu"), ("SAM fc2", 9216, 1280, 5120, "bias"),
+]
+if os.environ.get("SHAPES") == "eval":
+    CASES = EVAL_CASES
 if os.environ.get("CASES"):
     CASES = [CASES[int(i)] for i in os.environ["CASES"].split(",")]
 

@@ -327,6 +327,11 @@ long g_nt_bytes = 0;   // vfm_tune("gemm_nt_mb"): outputs of at least this many 
 // kernel 133.1, 256 x 256 8-wave ring kernel (gemm_use_pp bit 4) 134.5 - the form with the fewest operand bytes per flop wins once its
 // epilogue is the cheap eight-column one; hiding half of the epilogue under the next sub-tile's loop does not pay
 static int g_use_ps = 0;
+// 192 x 256 tiles (gemm_w4.hip form 7, config 40) for the large-M GEMMs of the 1024^2 predictions (nine windows = 9216 rows) wherever they
+// fill the 256 CUs' rounds better than 256 x 256 tiles do.  tools/bench_gemm_step.py SHAPES=eval (profiles/r03_gemm_eval_shapes.log):
+// DINOv2 fc2 / proj / fc1 98.1 -> 83.8 / 33.2 -> 29.8 / 100.5 -> 94.8 us, SAM-H qkv / proj / fc2 106.3 -> 89.8 / 42.0 -> 37.0 / 127.5 -> 109.7 us;
+// bit 1: 256 x 256 tiles for the shapes they fill to >= 80 % (DINOv2 qkv [9216 x 3072]: 69.3 -> 64.1 us).  vfm_tune gemm_use_192.
+static int g_use_192 = 3;
 static int g_deep_sep_k = 0;   // K from which one-tile-per-CU launches WITH tail rows take the seven-chunk ring and leave the tail rows to a skinny
                                // launch of their own (vfm_tune gemm_deep_sep_k; 0 = never)
 static int g_deep_tail_k = 0;  // K from which one-tile-per-CU launches WITH tail rows take the seven-chunk ring, the tail rows riding
@@ -386,6 +391,10 @@ extern "C" int vfm_tune(const char* key, int value) {
   }
   if (key && strcmp(key, "gemm_use_pp") == 0) {
     g_use_pp = value;
+    return VFM_OK;
+  }
+  if (key && strcmp(key, "gemm_use_192") == 0) {
+    g_use_192 = value;
     return VFM_OK;
   }
   if (key && strcmp(key, "gemm_batch_tiles") == 0) {
@@ -496,7 +505,15 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
     const long t256 = (long)cdiv(d->M, 256) * cdiv(d->N, 256);
     const bool span31 = (d->M + 128) * d->sa_m < (1l << 31) && (d->N + 128) * d->sb_n < (1l << 31);
     const bool span33 = (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31);
+    // fill of the CUs' rounds by whole tiles (one block per CU for the 256-column forms)
+    const long t192 = (long)cdiv(d->M, 192) * cdiv(d->N, 256);
+    const double eff192 = (double)t192 / (256.0 * cdiv(t192, 256)), eff256 = (double)t256 / (256.0 * cdiv(t256, 256));
+    const bool big_m = d->M >= 8192 && d->N >= 1024 && d->K >= 1024 && nbatch == 1 && span33 && !(g_use_pp & 64);
     if (d->N <= 32) cfg = 10;                                        // 64x64 tiles: many rows, few columns
+    else if ((g_use_192 & 1) && big_m && eff192 >= eff256 + 0.08)
+      cfg = 40;  // 192 x 256 tiles: [9216 x 1024 / 1280]: 192 / 240 tiles instead of 144 / 180; [9216 x 3840 / 4096]: 720 / 768 of 768 slots
+    else if ((g_use_192 & 2) && big_m && d->N >= 2048 && t256 > 256 && eff256 >= 0.8 && eff256 < 0.9)
+      cfg = 33;  // [9216 x 3072]: 432 tiles of 256 x 256 = 84 % of two rounds (the 128 x 128 form: 1728 tiles, 3.4 rounds of 512 slots)
     else if ((g_use_ps & 1) && d->N >= 2048 && t256 >= 224 && t256 % 256 == 0 && d->K >= 1024 && vfm_gemm_ps_ok(d, 2))
       cfg = 37;  // whole rounds of 256 x 256 regions with a bf16 store-heavy epilogue (fc1 forward, fc2 input gradient [4096 x 4096 x 1024]):
                  // one persistent block per CU, the first half's epilogue under the second half's K loop
@@ -588,6 +605,12 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
                 "vfm_gemm(bf16): the 4-wave 256x256 kernel needs K >= 128 and operands spanning < 4 GiB");
       VFM_CHECK(cfg < 35 || d->K >= 256, VFM_E_UNSUPPORTED, "vfm_gemm(bf16): the deep-ring 128x128 kernels need K >= 256");
       fd = vfm_gemm_launch_w4(d, s, vec, tail, cfg == 32 ? 4 : (cfg == 33 ? 8 : (cfg == 34 ? 2 : (cfg == 35 ? 3 : 5))));
+      break;
+    case 39:   // 192 x 256 tiles, 4 waves (gemm_w4.hip form 6)
+    case 40:   // 192 x 256 tiles, 8 waves (form 7)
+      VFM_CHECK(d->K >= 128 && d->K % 64 == 0 && (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31), VFM_E_UNSUPPORTED,
+                "vfm_gemm(bf16): the 192x256 kernel needs K >= 128 and operands spanning < 4 GiB");
+      fd = vfm_gemm_launch_w4(d, s, vec, tail, cfg == 39 ? 6 : 7);
       break;
     case 37:
     case 38:

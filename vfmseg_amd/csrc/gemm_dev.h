@@ -544,6 +544,7 @@ __device__ __forceinline__ void epi_scalar(const EpiParams& e, long zoff, f32x16
 struct SkinnyTail {
   const bf16_t* A; long lda; long M; int nblk; EpiParams e;
 };
+template <int NW = 8>
 __device__ __forceinline__ void skinny_tile(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ Bz, long ldb, long M, long N,
                                             long K, long n0, const EpiParams& e, long zoff, char* smem) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -561,7 +562,7 @@ __device__ __forceinline__ void skinny_tile(const bf16_t* __restrict__ A, long l
     bsrc[i] = Bz + bn * ldb + lch * 8;
   }
   const long nchunk = K / 128;                       // K % 128 may be 64: handled by the remainder chunk below
-  const long per = (nchunk + 7) / 8;
+  const long per = (nchunk + NW - 1) / NW;   // NW waves split K
   const long c_beg = wave * per, c_end = (c_beg + per < nchunk) ? c_beg + per : nchunk;
   f32x16 acc;
 #pragma unroll
@@ -590,7 +591,7 @@ __device__ __forceinline__ void skinny_tile(const bf16_t* __restrict__ A, long l
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
-  if ((K % 128) != 0 && wave == 7) {  // trailing 64-wide half chunk (K % 64 == 0 is guaranteed by the caller)
+  if ((K % 128) != 0 && wave == NW - 1) {  // trailing 64-wide half chunk (K % 64 == 0 is guaranteed by the caller)
     const long k0 = nchunk * 128;
     long bn = n0 + fr;
     if (bn > N - 1) bn = N - 1;
@@ -602,17 +603,17 @@ __device__ __forceinline__ void skinny_tile(const bf16_t* __restrict__ A, long l
     }
   }
   __syncthreads();  // every wave is done with its staging slice: the partial sums reuse that memory
-  float* part = reinterpret_cast<float*>(smem);  // [8][32][33]
+  float* part = reinterpret_cast<float*>(smem);  // [NW][32][33]
 #pragma unroll
   for (int r = 0; r < 16; ++r) part[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 33 + fr] = acc[r];
   __syncthreads();
-  for (int i = tid; i < 32 * 32; i += 512) {
+  for (int i = tid; i < 32 * 32; i += NW * 64) {
     const int row = i >> 5, col = i & 31;
     const long m = row, n = n0 + col;
     if (m < M && n < N) {
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) v += part[(w * 32 + row) * 33 + col];
+      for (int w = 0; w < NW; ++w) v += part[(w * 32 + row) * 33 + col];
       epi_store(e, zoff, m, n, v);
     }
   }

@@ -52,17 +52,24 @@ template <bool VEC, int MI, int NI, int WM_W, int WN_W, int P = 2, int DBG = 0, 
 __global__ void __launch_bounds__(WM_W* WN_W * 64)
     k_gemm_w4(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, long M, long N, long K, long stride_a,
               long stride_b, long stride_c, int tiles_m, int tiles_n, EpiParams e, SkinnyTail sk) {
-  constexpr int T = WM_W * MI * 32;
-  static_assert(T == WN_W * NI * 32 && MI % 2 == 0, "square block tile, wave tile of 64-row halves");
+  // block tile TM x TN (rows of A x rows of B); square in every form but the 192 x 256 one (<6, 2, 1, 4>: M = 9216 x N = 1280 / 1024
+  // GEMMs of the 1024^2 predictions, where 256 x 256 tiles fill 180 / 144 of the 256 CUs and 128 x 128 tiles take two rounds)
+  constexpr int TM = WM_W * MI * 32, TN = WN_W * NI * 32, T = TM > TN ? TM : TN;
+  // (MI odd - the 8-wave 192 x 256 form <3, 2, 2, 4> - : the epilogue takes the last 32-row block on its own, and a wave's pieces of
+  // an A chunk split 2 + 1 over the two k-steps that issue them)
+  static_assert(TM == TN || !CLSIN, "the tail-row-in-block form is written for square tiles");
   constexpr int WAVES = WM_W * WN_W, NCH = 2 * P + 1;
-  constexpr int CH = T * 128;                        // bytes per chunk (T rows x one 128-B K-tile row)
-  constexpr int PPC = T / 8 / WAVES, PPS = PPC / 2;  // DMA pieces per wave: per chunk, per k-step
-  static_assert(PPC >= 2 && PPC % 2 == 0, "a wave moves whole halves of a chunk");
-  constexpr int NMF = MI * NI, NRD = MI + NI, NOPS = NRD + PPS;  // per k-step: MFMAs, fragment reads, memory ops
+  constexpr int CH = T * 128;                        // bytes per ring slot: the larger chunk (rows x one 128-B K-tile row)
+  constexpr int PPC_A = TM / 8 / WAVES, PPC_B = TN / 8 / WAVES;   // DMA pieces per wave and chunk
+  constexpr int PH_A[2] = {(PPC_A + 1) / 2, PPC_A / 2}, PH_B[2] = {(PPC_B + 1) / 2, PPC_B / 2};   // ... in the first / second half (k-step) of a chunk
+  constexpr int PPC = PPC_B, PPS = PH_B[0], PPCX = PPC_A > PPC_B ? PPC_A : PPC_B;
+  static_assert(PPC_A >= 2 && PPC_B >= 2 && (TM % (8 * WAVES)) == 0 && (TN % (8 * WAVES)) == 0, "every wave moves pieces of both halves of a chunk");
+  static_assert(!CLSIN || (PPC_B % 2 == 0), "CLSIN counts equal halves");
+  constexpr int NMF = MI * NI, NRD = MI + NI;  // per k-step: MFMAs, fragment reads (+ the DMA pieces of the chunk half issued in it)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if constexpr (WAVES == 8 && NCH * CH >= 65536 && !CLSIN) {  // the tail rows of M run as extra blocks at the end of the grid
+  if constexpr (NCH * CH >= 65536 && !CLSIN) {  // the tail rows of M run as extra blocks at the end of the grid
     if (sk.nblk > 0 && (int)blockIdx.x >= tiles_m * tiles_n) {
-      skinny_tile(sk.A, sk.lda, B, ldb, sk.M, N, K, (long)((int)blockIdx.x - tiles_m * tiles_n) * 32, sk.e, 0, smem);
+      skinny_tile<WAVES>(sk.A, sk.lda, B, ldb, sk.M, N, K, (long)((int)blockIdx.x - tiles_m * tiles_n) * 32, sk.e, 0, smem);
       return;
     }
   }
@@ -83,45 +90,49 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   const int gsz = min(tiles_m - first_m, GM);
   const int tm = first_m + (bid % (GM * tiles_n)) % gsz;
   const int tn = (bid % (GM * tiles_n)) / gsz;
-  const long m0 = (long)tm * T, n0 = (long)tn * T;
+  const long m0 = (long)tm * TM, n0 = (long)tn * TN;
   const long z = blockIdx.y;
   const bf16_t* Ab = A + z * stride_a;
   const bf16_t* Bb = B + z * stride_b;
 
   // ---- per-lane DMA sources (32-bit byte offsets from the scalar matrix base; the dispatcher checks the span < 4 GiB)
-  unsigned soff[2][PPC];  // [0: B, 1: A][piece]
+  unsigned soff[2][PPCX];  // [0: B, 1: A][piece]
 #pragma unroll
-  for (int j = 0; j < PPC; ++j) {
-    const int r = (wave * PPC + j) * 8 + (lane >> 3);
+  for (int j = 0; j < PPC_B; ++j) {
+    const int r = (wave * PPC_B + j) * 8 + (lane >> 3);
     const int sw = ((lane & 7) ^ ((r >> 1) & 7)) << 3;
-    long gm = m0 + r, gn = n0 + r;
-    if (gm > M - 1) gm = M - 1;
+    long gn = n0 + r;
     if (gn > N - 1) gn = N - 1;
     soff[0][j] = (unsigned)((gn * ldb + sw) * 2);
+  }
+#pragma unroll
+  for (int j = 0; j < PPC_A; ++j) {
+    const int r = (wave * PPC_A + j) * 8 + (lane >> 3);
+    const int sw = ((lane & 7) ^ ((r >> 1) & 7)) << 3;
+    long gm = m0 + r;
+    if (gm > M - 1) gm = M - 1;
     soff[1][j] = (unsigned)((gm * lda + sw) * 2);
   }
   auto dma = [&](auto Cc, auto Jc, int u, int pos) {  // piece J of chunk type C (0 B, 1 A) of K-tile u -> chunk slot pos
     constexpr int c = decltype(Cc)::value, j = decltype(Jc)::value;
-    char* dst = smem + pos * CH + (wave * PPC + j) * 1024;
+    char* dst = smem + pos * CH + (wave * (c ? PPC_A : PPC_B) + j) * 1024;
     const unsigned long long bv = (unsigned long long)(c ? Ab : Bb) + (unsigned long long)u * 128;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)bv), hi = __builtin_amdgcn_readfirstlane((unsigned)(bv >> 32));
     const char* base = (const char*)(((unsigned long long)hi << 32) | lo);  // pinned to SGPRs
     glds16(base + soff[c][j], dst);
   };
   auto dma_half = [&](auto Cc, auto Hc, int u, int pos) {  // half H of this wave's pieces of a chunk
-    constexpr int j0 = decltype(Hc)::value * PPS;
-    static_for<PPS>([&](auto Jc) { dma(Cc, IC<j0 + decltype(Jc)::value>{}, u, pos); });
+    constexpr int c = decltype(Cc)::value, hh = decltype(Hc)::value, pps = c ? PH_A[hh] : PH_B[hh], j0 = hh * (c ? PH_A[0] : PH_B[0]);
+    static_for<pps>([&](auto Jc) { dma(Cc, IC<j0 + decltype(Jc)::value>{}, u, pos); });
   };
 
-  f32x16 acc[MI / 2][2][NI];  // [half h][i][j]: rows wm*MI*32 + (2h+i)*32, columns wn*NI*32 + j*32
+  f32x16 acc[MI][NI];  // [i][j]: rows wm*MI*32 + i*32, columns wn*NI*32 + j*32
 #pragma unroll
-  for (int h = 0; h < MI / 2; ++h)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[h][i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int fr = lane & 31, fh = lane >> 5;
   // fragment read offsets inside a chunk (bytes): row * 128 + swizzled 16-B piece; [s] = k-step inside the K-tile
@@ -178,8 +189,9 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   // one k-step: NMF MFMAs on buffer CUR; spread between them the fragment reads of the next k-step (READ: k-step rs of the
   // chunks at slots pb / pa) and PPS DMA pieces (ISSUE: half H of chunk type CH of K-tile u into slot dpos)
   auto kstep = [&](auto CURc, auto READc, auto ISSUEc, auto CHc, auto Hc, int pb_slot, int pa_slot, auto RSc, int u, int dpos, int cls_off = 0) {
-    constexpr int cur = decltype(CURc)::value, nxt = cur ^ 1, ch = decltype(CHc)::value, j0 = decltype(Hc)::value * PPS;
-    constexpr int rs = decltype(RSc)::value;
+    constexpr int cur = decltype(CURc)::value, nxt = cur ^ 1, ch = decltype(CHc)::value, hh = decltype(Hc)::value;
+    constexpr int pps = ch ? PH_A[hh] : PH_B[hh], j0 = hh * (ch ? PH_A[0] : PH_B[0]);
+    constexpr int rs = decltype(RSc)::value, NOPS = NRD + pps;   // memory ops of this k-step
     constexpr bool READ = decltype(READc)::value, ISSUE = decltype(ISSUEc)::value;
     const char* pa = smem + pa_slot * CH + ra[rs];
     const char* pb = smem + pb_slot * CH + rb[rs];
@@ -195,7 +207,7 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
     };
     static_for<NMF>([&](auto Mc) {
       constexpr int m = decltype(Mc)::value, i4 = m / NI, j = m % NI;
-      acc[i4 >> 1][i4 & 1][j] = VFM_MFMA16(fa[cur][i4], fb[cur][j], acc[i4 >> 1][i4 & 1][j]);
+      acc[i4][j] = VFM_MFMA16(fa[cur][i4], fb[cur][j], acc[i4][j]);
       // memory op k goes behind MFMA floor(k * NMF / NOPS): one per gap where there are more MFMAs than ops
       static_for<NOPS>([&](auto Kc) {
         if constexpr (decltype(Kc)::value * NMF / NOPS == m) memop(Kc);
@@ -224,11 +236,13 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
     if constexpr (!LAST) {
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
       constexpr int live = X == 0 ? 2 * P - 3 : (2 * P - 4 - 2 * (X - 1) > 0 ? 2 * P - 4 - 2 * (X - 1) : 0);  // whole chunks in flight
+      // ... X = 0: chunks 2v+4 .. 2v+2P (P-1 of B, P-2 of A); afterwards whole (B, A) pairs up to the last chunk
+      constexpr int live_pieces = X == 0 ? (P - 1) * PPC_B + (P - 2) * PPC_A : (live / 2) * (PPC_A + PPC_B);
       // CLS: the tail-row piece of this iteration sits between the chunk pieces; when the window of pieces that may stay in
       // flight reaches back past it, it is part of the window (else it is older than the window and completes with it)
       constexpr int after = X == 0 ? 3 * PPS : (X == 1 ? PPS : 0);   // chunk pieces issued behind the tail-row piece in this iteration
       constexpr int extra = (CLS && live * PPC > after) ? 1 : 0;
-      wait_vmcnt<live * PPC + extra>();
+      wait_vmcnt<live_pieces + extra>();
       __builtin_amdgcn_s_barrier();
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -245,7 +259,7 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
     dma_half(IC<(c & 1)>{}, IC<0>{}, c >> 1, c), dma_half(IC<(c & 1)>{}, IC<1>{}, c >> 1, c);
   });
   dma_half(IC<1>{}, IC<0>{}, P - 1, 2 * P - 1);
-  wait_vmcnt<(2 * P - 3) * PPC + PPS>();
+  wait_vmcnt<(P - 1) * PPC_B + (P - 2) * PPC_A + PH_A[0]>();   // K-tile 0 (chunks 0, 1) landed; chunks 2 .. 2P-2 and half of 2P-1 (A) in flight
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -279,15 +293,13 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   if constexpr (DBG & 1) return;
   if constexpr (DBG & 4) {   // diagnostic: no epilogue, but the accumulators stay live (the MFMAs are not dead code)
 #pragma unroll
-    for (int h = 0; h < MI / 2; ++h)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
+      for (int j = 0; j < NI; ++j) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (a "v" constraint does not exist for the host pass: the instantiation would silently vanish)
-          asm volatile("" ::"v"(acc[h][i][j]));
+        asm volatile("" ::"v"(acc[i][j]));
 #endif
-        }
+      }
     return;
   }
   __syncthreads();
@@ -295,9 +307,15 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   const long mw = m0 + wm * MI * 32, nw = n0 + wn * NI * 32;
   static_for<MI / 2>([&](auto Hc) {
     constexpr int h = decltype(Hc)::value;
-    if constexpr (VEC) epi_wave_tile<2, NI, 2>(e, zoff, acc[h], img, lane, mw + h * 64, nw, M, N);
-    else epi_scalar<2, NI, 2>(e, zoff, acc[h], img, lane, mw + h * 64, nw, M, N);
+    f32x16(&a2)[2][NI] = *reinterpret_cast<f32x16(*)[2][NI]>(&acc[2 * h]);   // blocks 2h, 2h+1: one 64-row half
+    if constexpr (VEC) epi_wave_tile<2, NI, 2>(e, zoff, a2, img, lane, mw + h * 64, nw, M, N);
+    else epi_scalar<2, NI, 2>(e, zoff, a2, img, lane, mw + h * 64, nw, M, N);
   });
+  if constexpr (MI % 2 == 1) {   // the last 32-row block of an odd wave tile
+    f32x16(&a1)[1][NI] = *reinterpret_cast<f32x16(*)[1][NI]>(&acc[MI - 1]);
+    if constexpr (VEC) epi_wave_tile<1, NI, 1>(e, zoff, a1, img, lane, mw + (MI - 1) * 32, nw, M, N);
+    else epi_scalar<1, NI, 1>(e, zoff, a1, img, lane, mw + (MI - 1) * 32, nw, M, N);
+  }
   if constexpr (CLSIN) {
     // tail rows: accumulator register r of lane (fr, fh) is row (r & 3) + 8 (r >> 2) + 4 fh, column nw + fr; all eight waves
     // computed them (no branch in the loop), the wm == 0 waves store
@@ -314,9 +332,9 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
 extern int g_pp_dbg;
 template <bool VEC, int MI, int NI, int WM_W, int WN_W, int P, int DBG, bool CLSIN = false>
 static bool launch_w4_t(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail) {
-  constexpr int T = WM_W * MI * 32, WAVES = WM_W * WN_W;
+  constexpr int TM = WM_W * MI * 32, TN = WN_W * NI * 32, T = TM > TN ? TM : TN, WAVES = WM_W * WN_W;
   constexpr int RING = (2 * P + 1) * T * 128 + (CLSIN ? 8 * 1024 : 0), EPI = WAVES * 64 * (NI * 32 + 4) * 4, SMEM = RING > EPI ? RING : EPI;
-  const int tiles_m = cdiv(d->M, T), tiles_n = cdiv(d->N, T);
+  const int tiles_m = cdiv(d->M, TM), tiles_n = cdiv(d->N, TN);
   const long batch = d->batch > 0 ? d->batch : 1;
   static bool attr = false;
   if (!attr) {
@@ -325,21 +343,23 @@ static bool launch_w4_t(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_de
   }
   SkinnyTail sk;
   sk.nblk = 0;
-  const bool fold = tail && batch == 1 && WAVES == 8 && RING >= 65536 && (!CLSIN || (tail->M <= 8 && tail->sa_k == 1));
+  const bool fold = tail && batch == 1 && RING >= 65536 && (!CLSIN || (tail->M <= 8 && tail->sa_k == 1));
   if (fold) sk.A = (const bf16_t*)tail->A, sk.lda = tail->sa_m, sk.M = tail->M, sk.nblk = cdiv(tail->N, 32), sk.e = make_epi(tail);
   hipLaunchKernelGGL((k_gemm_w4<VEC, MI, NI, WM_W, WN_W, P, DBG, CLSIN>), dim3(tiles_m * tiles_n + (CLSIN ? 0 : sk.nblk), (unsigned)batch), dim3(WAVES * 64), SMEM, s,
                      (const bf16_t*)d->A, d->sa_m, (const bf16_t*)d->B, d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c,
                      tiles_m, tiles_n, make_epi(d), sk);
   return fold || !tail;
 }
-// form: 4 = 256x256 / 4 waves, 8 = 256x256 / 8 waves, 2 = 128x128 / 8 waves (two blocks per CU), 3 / 5 = 128x128 with the
-// seven- / nine-chunk ring (one block per CU).  Returns whether the tail rows
-// were folded into the launch (8-wave forms; otherwise the caller runs the skinny kernel).
+// form: 4 = 256x256 / 4 waves, 8 = 256x256 / 8 waves, 6 = 192x256 / 4 waves, 7 = 192x256 / 8 waves, 2 = 128x128 / 8 waves (two blocks per CU), 3 / 5 = 128x128
+// with the seven- / nine-chunk ring (one block per CU).  Returns whether the tail rows were folded into the launch (otherwise
+// the caller runs the skinny kernel).
 bool vfm_gemm_launch_w4(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail, int form) {
   if (form == 4) {
     if (!vec) return launch_w4_t<false, 4, 4, 2, 2, 2, 0>(d, s, tail);
     return g_pp_dbg == 1 ? launch_w4_t<true, 4, 4, 2, 2, 2, 1>(d, s, tail) : launch_w4_t<true, 4, 4, 2, 2, 2, 0>(d, s, tail);
   }
+  if (form == 7) return vec ? launch_w4_t<true, 3, 2, 2, 4, 2, 0>(d, s, tail) : launch_w4_t<false, 3, 2, 2, 4, 2, 0>(d, s, tail);
+  if (form == 6) return vec ? launch_w4_t<true, 6, 2, 1, 4, 2, 0>(d, s, tail) : launch_w4_t<false, 6, 2, 1, 4, 2, 0>(d, s, tail);
   if (form == 8) {
     if (!vec) return launch_w4_t<false, 4, 2, 2, 4, 2, 0>(d, s, tail);
     if (g_pp_dbg == 4) return launch_w4_t<true, 4, 2, 2, 4, 2, 4>(d, s, tail);
