@@ -26,7 +26,7 @@ def main():
         k, v = kv.split("=")
         ops.tune(k, int(v))
         print("tune", k, v)
-    for label, B, H, n, ex in (("backbone 4x16x(1024+1)", 4, 16, 1024, 1), ("decoder 2x8x1024", 2, 8, 1024, 0), ("eval 9x16x(1024+1)", 9, 16, 1024, 1)):
+    for label, B, H, n, ex in (("backbone 4x16x(1024+1)", 4, 16, 1024, 1), ("decoder 2x8x1024", 2, 8, 1024, 0), ("eval 9x16x(1024+1)", 9, 16, 1024, 1), ("eval coarse 1x16x(2048+1)", 1, 16, 2048, 1)):
         d = 64
         rows = B * n + B * ex
         qkv = torch.randn(rows, 3 * H * d, device=dev).bfloat16()
