@@ -195,7 +195,7 @@ def parity_leg(device, batch, steps=3, iters=2, modes=("bf16x3", "f32")):
             print(f"[bench] parity-mode leg: {mode} train step", file=sys.stderr, flush=True)
             model, ow = build(device, batch, amp=(mode == "fp16"))
             data = make_batch(batch, 0, 0, device)
-            for _ in range(2):
+            for _ in range(2 if steps < 10 else 4):
                 model.train_step(data, ow)
             torch.cuda.synchronize()
             t0 = time.perf_counter()

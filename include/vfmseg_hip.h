@@ -344,6 +344,17 @@ int vfm_confusion_hist(const uint8_t* pred, const void* label, int label_dt, lon
 int vfm_adamw(float* p, float* g, float* m, float* v, long n, const long* seg_start, const float* seg_lr_mult,
               const float* seg_wd, int n_seg, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
               int zero_grad, int vec4, void* stream);
+/* ... for loss-scaled training (mmengine AmpOptimWrapper / torch GradScaler, tools/train.py:87-102) with the scaler's state on the DEVICE, so
+ * that the host never waits for a backward pass:  *skip != 0 (the step's gradients hold an inf / NaN) leaves p / m / v untouched (g is still
+ * cleared when zero_grad != 0);  amp_state = float[4] {loss scale, growth tracker, optimiser steps taken, steps skipped}: when given, the
+ * gradients are multiplied by grad_scale / amp_state[0] and the bias corrections use step amp_state[2] + 1 (`step` is ignored).
+ * Both may be NULL (= vfm_adamw).  vfm_amp_update is GradScaler.update() on that state: after a skipped step the scale is multiplied by
+ * `backoff` and the tracker cleared; after a good one the step count and the tracker advance and every `interval` good steps the scale is
+ * multiplied by `growth` (dynamic == 0: the scale stays, the counters still move). */
+int vfm_adamw_guarded(float* p, float* g, float* m, float* v, long n, const long* seg_start, const float* seg_lr_mult,
+                      const float* seg_wd, int n_seg, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                      int zero_grad, int vec4, const int* skip, const float* amp_state, void* stream);
+int vfm_amp_update(const int* flag, float* amp_state, float growth, float backoff, int interval, int dynamic, void* stream);
 
 #ifdef __cplusplus
 }

@@ -209,3 +209,49 @@ def test_fp16_amp_overflow_backs_the_scale_off_like_the_emulated_reference():
     log, r32, r16 = logs[0]
     for k in ("decode_lr.loss_ce", "decode_hr.loss_ce"):
         assert abs(float(log[k]) - r32[k]) < 2e-3 * abs(r32[k])
+
+
+def test_device_side_loss_scaler_follows_gradscaler():
+    """The scaler state kept on the device (vfm_adamw_guarded + vfm_amp_update: no host wait per step) against torch.amp.GradScaler
+    driving torch.optim.AdamW over the same sequence of good and overflowing gradients: scale, growth tracker, skipped steps, AdamW's
+    step count (bias correction) and the parameters themselves."""
+    import vfmseg_amd  # noqa: F401
+    from vfmseg_amd.optim import AmpOptimWrapper, FusedAdamW
+    from vfmseg_amd.precision import set_compute_dtype
+    set_compute_dtype("bf16")
+    torch.manual_seed(0)
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.randn(64, 32))
+            self.b = torch.nn.Parameter(torch.randn(32))
+
+    mod = M().cuda()
+    ref = M()
+    ref.load_state_dict({k: v.cpu() for k, v in mod.state_dict().items()})
+    opt = FusedAdamW(mod, 1e-2, 0.05, (0.9, 0.999), 1e-8, None)
+    ow = AmpOptimWrapper(opt, None, None, loss_scale=dict(init_scale=1024.0, growth_interval=3))
+    topt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8)
+    scaler = torch.amp.GradScaler("cpu", init_scale=1024.0, growth_interval=3)
+    seq = [0, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 1, 0]
+    gen = torch.Generator().manual_seed(5)
+    for i, bad in enumerate(seq):
+        x = torch.randn(64, 32, generator=gen)
+        y = torch.randn(32, generator=gen)
+        if bad:
+            x[i % 64, i % 32] = float("inf") if i % 2 else float("nan")
+        loss = (mod.w * x.cuda()).sum() + (mod.b * y.cuda()).sum()
+        ow.update_params(loss)
+        topt.zero_grad()
+        scaler.scale((ref.w * x).sum() + (ref.b * y).sum()).backward()
+        scaler.step(topt)
+        scaler.update()
+    assert ow._stale                                  # nothing was read back during the loop
+    assert ow.scale == scaler.get_scale() and ow.growth_tracker == int(scaler._growth_tracker.item())
+    assert ow.skipped == sum(seq) and ow.iter == len(seq) and opt.step_count == len(seq) - sum(seq)
+    for k, v in ref.state_dict().items():
+        got = mod.state_dict()[k].cpu()
+        assert torch.allclose(got, v, rtol=2e-5, atol=2e-6), (k, (got - v).abs().max().item())
+    sd = ow.state_dict()
+    assert sd["loss_scaler"]["scale"] == scaler.get_scale() and sd["iter"] == len(seq)

@@ -78,8 +78,14 @@ class _StubOpt:
         self.gflat = torch.zeros(n)
         self.param_groups = [dict(lr=0.0)]
         self.steps = []
+        self.step_count = 0
 
-    def step(self, lr=None, grad_scale=1.0, zero_grad=False):
+    def step(self, lr=None, grad_scale=1.0, zero_grad=False, skip_flag=None):
+        self.step_count += 1
+        if skip_flag is not None and int(skip_flag.item()):   # vfm_adamw_guarded: parameters and moments untouched, gradients cleared
+            if zero_grad:
+                self.gflat.zero_()
+            return
         self.steps.append(float(grad_scale))
         self.w -= 0.1 * self.gflat * grad_scale
         if zero_grad:

@@ -699,8 +699,21 @@ template <bool VEC>
 __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
                                                const long* __restrict__ seg_start, const float* __restrict__ seg_lr,
                                                const float* __restrict__ seg_wd, int n_seg, float lr, float b1, float b2, float eps, float bc1,
-                                               float bc2_sqrt, float gscale, int zero_grad) {
+                                               float bc2_sqrt, float gscale, int zero_grad, const int* __restrict__ skip,
+                                               const float* __restrict__ amp_state) {
   extern __shared__ long s_start[];
+  // amp_state (device, AmpOptimWrapper): [0] loss scale, [2] optimiser steps taken so far.  With it the un-scale factor and the bias
+  // corrections are formed here, so neither the scale nor the step count has to be known on the host when the launch is enqueued.
+  if (amp_state != nullptr) {
+    gscale = gscale / amp_state[0];
+    const float st = amp_state[2] + 1.f;
+    bc1 = 1.f - powf(b1, st);
+    bc2_sqrt = sqrtf(1.f - powf(b2, st));
+  }
+  // loss-scaled training (AmpOptimWrapper): a step whose gradients hold an inf / NaN leaves parameters and moments alone.  The flag is
+  // read on the device, so the host does not have to wait for the backward pass before it can enqueue this launch.
+  const bool skipped = skip != nullptr && *skip != 0;
+  if (skipped && !zero_grad) return;
   for (int i = threadIdx.x; i < n_seg; i += 256) s_start[i] = seg_start[i];
   __syncthreads();
   constexpr int W = VEC ? 4 : 1;
@@ -712,6 +725,11 @@ __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ p, float* __r
       const int mid = (lo + hi + 1) >> 1;
       if (s_start[mid] <= i) lo = mid;
       else hi = mid - 1;
+    }
+    if (skipped) {   // only the gradient clear of the fused zero_grad
+      if constexpr (VEC) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+      else g[i] = 0.f;
+      continue;
     }
     const float lr_i = lr * seg_lr[lo], decay = 1.f - lr_i * seg_wd[lo], step = lr_i / bc1;
     float gg[W], pp[W], mm[W], vv[W];
@@ -746,6 +764,31 @@ __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ p, float* __r
 extern "C" int vfm_adamw(float* p, float* g, float* m, float* v, long n, const long* seg_start, const float* seg_lr_mult,
                          const float* seg_wd, int n_seg, float lr, float beta1, float beta2, float eps, int step,
                          float grad_scale, int zero_grad, int vec4, void* stream) {
+  return vfm_adamw_guarded(p, g, m, v, n, seg_start, seg_lr_mult, seg_wd, n_seg, lr, beta1, beta2, eps, step, grad_scale, zero_grad, vec4, nullptr, nullptr,
+                           stream);
+}
+// one thread: torch GradScaler.update() + the optimiser's step count, on the device
+__global__ void k_amp_update(const int* __restrict__ flag, float* __restrict__ st, float growth, float backoff, int interval, int dynamic) {
+  if (*flag != 0) {
+    st[3] += 1.f;                       // skipped steps
+    if (dynamic) st[0] *= backoff, st[1] = 0.f;
+  } else {
+    st[2] += 1.f;                       // optimiser steps taken
+    if (dynamic) {
+      st[1] += 1.f;
+      if ((int)st[1] == interval) st[0] *= growth, st[1] = 0.f;
+    }
+  }
+}
+extern "C" int vfm_amp_update(const int* flag, float* amp_state, float growth, float backoff, int interval, int dynamic, void* stream) {
+  VFM_CHECK(flag && amp_state && interval >= 1, VFM_E_INVAL, "vfm_amp_update: arguments");
+  hipLaunchKernelGGL(k_amp_update, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, amp_state, growth, backoff, interval, dynamic);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+extern "C" int vfm_adamw_guarded(float* p, float* g, float* m, float* v, long n, const long* seg_start, const float* seg_lr_mult,
+                                 const float* seg_wd, int n_seg, float lr, float beta1, float beta2, float eps, int step,
+                                 float grad_scale, int zero_grad, int vec4, const int* skip, const float* amp_state, void* stream) {
   VFM_CHECK(n_seg >= 1 && n_seg <= 8192 && step >= 1, VFM_E_INVAL, "vfm_adamw: n_seg/step");
   if (n == 0) return VFM_OK;
   const float bc1 = 1.f - powf(beta1, (float)step);
@@ -757,10 +800,10 @@ extern "C" int vfm_adamw(float* p, float* g, float* m, float* v, long n, const l
   const size_t lds = (size_t)n_seg * sizeof(long);
   if (vec)
     hipLaunchKernelGGL(k_adamw<true>, dim3(grid), dim3(256), lds, (hipStream_t)stream, p, g, m, v, n, seg_start, seg_lr_mult, seg_wd, n_seg,
-                       lr, beta1, beta2, eps, bc1, bc2s, grad_scale, zero_grad);
+                       lr, beta1, beta2, eps, bc1, bc2s, grad_scale, zero_grad, skip, amp_state);
   else
     hipLaunchKernelGGL(k_adamw<false>, dim3(grid), dim3(256), lds, (hipStream_t)stream, p, g, m, v, n, seg_start, seg_lr_mult, seg_wd, n_seg,
-                       lr, beta1, beta2, eps, bc1, bc2s, grad_scale, zero_grad);
+                       lr, beta1, beta2, eps, bc1, bc2s, grad_scale, zero_grad, skip, amp_state);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
 }

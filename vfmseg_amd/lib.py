@@ -115,6 +115,8 @@ SIGNATURES = {
     "vfm_slide_finalize": [vp, vp, vp, ci, ci, ci, ci, vp],
     "vfm_confusion_hist": [vp, vp, ci, cl, ci, ci, vp, vp],
     "vfm_adamw": [vp, vp, vp, vp, cl, vp, vp, vp, ci, cf, cf, cf, cf, ci, cf, ci, ci, vp],
+    "vfm_adamw_guarded": [vp, vp, vp, vp, cl, vp, vp, vp, ci, cf, cf, cf, cf, ci, cf, ci, ci, vp, vp, vp],
+    "vfm_amp_update": [vp, vp, cf, cf, ci, ci, vp],
 }
 
 _lib = None          # the ACTIVE library (what load() returns)

@@ -839,8 +839,18 @@ def confusion_hist(pred_u8, label, hist, num_classes, ignore_index=255):
     return hist
 
 
-def adamw(p, g, m, v, seg_start, seg_lr_mult, seg_wd, lr, betas, eps, step, grad_scale=1.0, zero_grad=False, vec4=False):
+def adamw(p, g, m, v, seg_start, seg_lr_mult, seg_wd, lr, betas, eps, step, grad_scale=1.0, zero_grad=False, vec4=False, skip=None, amp_state=None):
+    """skip: int32 device tensor [1]; non-zero = leave parameters and moments alone (loss-scaled training: the step's gradients overflowed).
+    amp_state: fp32 device tensor [4] {loss scale, growth tracker, steps taken, steps skipped}: un-scale and bias corrections from it."""
     lib = L.load()
-    L.check(lib.vfm_adamw(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(seg_start), L.ptr(seg_lr_mult),
-                          L.ptr(seg_wd), seg_start.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), int(step),
-                          float(grad_scale), int(bool(zero_grad)), int(bool(vec4)), L.stream()), "vfm_adamw")
+    assert skip is None or (skip.dtype == torch.int32 and skip.numel() == 1)
+    assert amp_state is None or (amp_state.dtype == torch.float32 and amp_state.numel() == 4 and amp_state.is_contiguous())
+    L.check(lib.vfm_adamw_guarded(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(seg_start), L.ptr(seg_lr_mult),
+                                  L.ptr(seg_wd), seg_start.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps), max(int(step), 1),
+                                  float(grad_scale), int(bool(zero_grad)), int(bool(vec4)), L.ptr(skip), L.ptr(amp_state), L.stream()), "vfm_adamw")
+
+
+def amp_update(flag, amp_state, growth, backoff, interval, dynamic):
+    """GradScaler.update() + the optimiser's step count on the device (vfm_amp_update)."""
+    L.check(L.load().vfm_amp_update(L.ptr(flag), L.ptr(amp_state), float(growth), float(backoff), int(interval), int(bool(dynamic)), L.stream()),
+            "vfm_amp_update")

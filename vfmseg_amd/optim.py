@@ -131,14 +131,18 @@ class FusedAdamW:
             cuts[-1][2] = a + dict(zip(self.names, [p.numel() for p in self.params]))[nm]
         return [tuple(c) for c in cuts]
 
-    def step(self, lr=None, grad_scale=1.0, zero_grad=False):
-        """zero_grad=True clears the flat gradient buffer in the same pass (OptimWrapper.update_params: step, then zero_grad)."""
-        self.step_count += 1
+    def step(self, lr=None, grad_scale=1.0, zero_grad=False, skip_flag=None, amp_state=None):
+        """zero_grad=True clears the flat gradient buffer in the same pass (OptimWrapper.update_params: step, then zero_grad).
+        skip_flag / amp_state (AmpOptimWrapper, device tensors): a non-zero flag makes the launch a no-op on parameters and moments;
+        with amp_state the loss scale and the step count of the bias corrections are read on the device and `step_count` is the
+        wrapper's to maintain (AmpOptimWrapper.sync)."""
+        if amp_state is None:
+            self.step_count += 1
         PARAM_EPOCH[0] += 1  # the fused kernel rewrites the parameters behind torch's version counters
         lr = self.lr if lr is None else lr
         self.param_groups[0]["lr"] = lr
         ops.adamw(self.flat, self.gflat, self.m, self.v, self.seg_start, self.seg_lr, self.seg_wd, lr, self.betas, self.eps,
-                  self.step_count, grad_scale, zero_grad=zero_grad, vec4=True)   # offsets are multiples of 16 floats
+                  self.step_count, grad_scale, zero_grad=zero_grad, vec4=True, skip=skip_flag, amp_state=amp_state)   # offsets are multiples of 16 floats
         self._grads_cleared = bool(zero_grad)
 
     def zero_grad(self):
@@ -216,6 +220,8 @@ class AmpOptimWrapper(OptimWrapper):
             raise NotImplementedError("AmpOptimWrapper: autocast dtype %r (float16 and bfloat16 are the ones torch.autocast offers on a GPU)" % (dtype,))
         self.dtype = self._DTYPES[dtype]
         self.mode = "fp16" if self.dtype == torch.float16 else "bf16"
+        self._tracker, self._skipped = 0, 0
+        self._state, self._stale = None, False   # device-side scaler state (built at the first GPU update_params)
         self.growth_factor, self.backoff_factor, self.growth_interval = 2.0, 0.5, 2000
         self.dynamic = True
         if loss_scale == "dynamic":
@@ -229,39 +235,106 @@ class AmpOptimWrapper(OptimWrapper):
             self.scale, self.dynamic = float(loss_scale), False
         else:
             raise TypeError("loss_scale must be 'dynamic', a number or a dict, got %r" % (loss_scale,))
-        self.growth_tracker = 0
-        self.skipped = 0
 
     def update_params(self, loss):
-        self._backward(loss * self.scale)
+        """GradScaler.scale(loss).backward(); unscale_; step (skipped on inf / NaN); update.
+        On the GPU the scaler's state {scale, growth tracker, optimiser steps, skipped steps} lives in a 4-float DEVICE tensor: the loss
+        is multiplied by the device scale, the overflow flag is formed on the device, the fused AdamW launch reads flag, scale and step
+        count there (vfm_adamw_guarded) and vfm_amp_update applies GradScaler.update() - the host never waits for the backward pass
+        (torch's GradScaler.step pays a found_inf.item() per step with a non-fused optimiser: the host then cannot run ahead of the
+        GPU, which cost ~1 ms of a 15.3-ms step here).  `scale`, `skipped`, `growth_tracker` and optimizer.step_count are read back
+        on demand (sync())."""
+        g = self.optimizer.gflat
+        if not g.is_cuda:                    # host path (CPU tensors: tests of the schedule against torch's GradScaler)
+            self._backward(loss * self._scale)
+            if self.grad_sync is not None:
+                self.grad_sync()
+            found_inf = not bool(torch.isfinite(g.sum()).item())
+            flag = torch.tensor([int(found_inf)], dtype=torch.int32)
+            lr = self.scheduler.lr(self.iter) if self.scheduler is not None else None
+            self.optimizer.step(lr, grad_scale=getattr(self.grad_sync, "post_scale", 1.0) / self._scale, zero_grad=True, skip_flag=flag)
+            self.optimizer.zero_grad()
+            if found_inf:
+                self._skipped += 1
+                self.optimizer.step_count -= 1   # torch's AdamW does not count a skipped step (bias correction)
+            self._update_scale(found_inf)
+            self.iter += 1
+            return
+        if self._state is None:
+            self._state = torch.tensor([self._scale, float(self._tracker), float(self.optimizer.step_count), float(self._skipped)],
+                                       dtype=torch.float32, device=g.device)
+        self._backward(loss * self._state[0])
         if self.grad_sync is not None:
             self.grad_sync()
         # after the all-reduce every rank sees the same sums, hence the same decision (an inf / NaN survives the reduction)
-        found_inf = not bool(torch.isfinite(self.optimizer.gflat.sum()).item())
+        flag = (~torch.isfinite(g.sum())).to(torch.int32).reshape(1)
         lr = self.scheduler.lr(self.iter) if self.scheduler is not None else None
-        if found_inf:
-            self.skipped += 1
-            self.optimizer._grads_cleared = False
-        else:
-            self.optimizer.step(lr, grad_scale=getattr(self.grad_sync, "post_scale", 1.0) / self.scale, zero_grad=True)
+        self.optimizer.step(lr, grad_scale=getattr(self.grad_sync, "post_scale", 1.0), zero_grad=True, skip_flag=flag, amp_state=self._state)
         self.optimizer.zero_grad()
-        self._update_scale(found_inf)
+        ops.amp_update(flag, self._state, self.growth_factor, self.backoff_factor, self.growth_interval, self.dynamic)
+        self._stale = True
         self.iter += 1
+
+    def sync(self):
+        """Read the device-side scaler state back (one host wait): scale, growth tracker, skipped steps, optimizer.step_count."""
+        if self._stale:
+            st = self._state.cpu().tolist()
+            self._scale, self._tracker, self._skipped = float(st[0]), int(st[1]), int(st[3])
+            self.optimizer.step_count = int(st[2])
+            self._stale = False
+
+    def _push(self):
+        """The host copies changed (load_state_dict, a scale set by hand): the device tensor is rebuilt at the next update_params."""
+        self._state, self._stale = None, False
+
+    @property
+    def scale(self):
+        self.sync()
+        return self._scale
+
+    @scale.setter
+    def scale(self, v):
+        self.sync()
+        self._scale = float(v)
+        self._push()
+
+    @property
+    def skipped(self):
+        self.sync()
+        return self._skipped
+
+    @skipped.setter
+    def skipped(self, v):
+        self.sync()
+        self._skipped = int(v)
+        self._push()
+
+    @property
+    def growth_tracker(self):
+        self.sync()
+        return self._tracker
+
+    @growth_tracker.setter
+    def growth_tracker(self, v):
+        self.sync()
+        self._tracker = int(v)
+        self._push()
 
     def _update_scale(self, found_inf):
         """torch GradScaler.update(): x backoff after a skipped step, x growth after growth_interval consecutive good ones."""
         if not self.dynamic:
             return
         if found_inf:
-            self.scale *= self.backoff_factor
-            self.growth_tracker = 0
+            self._scale *= self.backoff_factor
+            self._tracker = 0
         else:
-            self.growth_tracker += 1
-            if self.growth_tracker == self.growth_interval:
-                self.scale *= self.growth_factor
-                self.growth_tracker = 0
+            self._tracker += 1
+            if self._tracker == self.growth_interval:
+                self._scale *= self.growth_factor
+                self._tracker = 0
 
     def state_dict(self):
+        self.sync()
         return dict(iter=self.iter, loss_scaler=dict(scale=self.scale, growth_factor=self.growth_factor, backoff_factor=self.backoff_factor,
                                                      growth_interval=self.growth_interval, _growth_tracker=self.growth_tracker))
 
@@ -270,6 +343,7 @@ class AmpOptimWrapper(OptimWrapper):
         ls = sd.get("loss_scaler")
         if ls:
             self.scale, self.growth_tracker = float(ls["scale"]), int(ls.get("_growth_tracker", 0))
+        self._push()   # (the optimiser's step count may have been reloaded too: the device state is rebuilt from the host copies)
 
 
 @OPTIM_WRAPPER_CONSTRUCTORS.register_module()

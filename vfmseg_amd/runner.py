@@ -125,6 +125,7 @@ class Runner:
         np.random stream, the dropout / query-mask counter, the loader position) so that a resumed run continues the same
         sample and mask sequence - and a `last_checkpoint` pointer file next to it.  Ranks > 0: save_rank_state."""
         sd = {k: v.detach().cpu() for k, v in self.model.state_dict().items()}
+        getattr(self.ow, "sync", lambda: None)()   # AmpOptimWrapper: the last step's overflow verdict (AdamW step count, loss scale)
         torch.save(dict(state_dict=sd, meta=self._rng_state(), optimizer=self.ow.optimizer.state_dict(), optim_wrapper=self.ow.state_dict()), path)
         with open(os.path.join(os.path.dirname(path) or ".", "last_checkpoint"), "w") as f:
             f.write(os.path.abspath(path))
