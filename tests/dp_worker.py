@@ -3,7 +3,7 @@ MsVFMEncoderDecoder through the product's DP plumbing (parallel.attach: paramete
 side stream launched from backward, SyncBN moment / gradient exchange) and writes rank 0's results.
 
     RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the env (gloo: the ranks share the one GPU of the test box)
-    argv: OUT.pt MODE(f32|bf16) [BACKEND(gloo|nccl)]   (nccl: only with WORLD_SIZE=1 and VFMSEG_DIST_SINGLE=1 on a one-GPU box)
+    argv: OUT.pt MODE(f32|bf16|fp16amp) [BACKEND(gloo|nccl)]   (nccl: only with WORLD_SIZE=1 and VFMSEG_DIST_SINGLE=1 on a one-GPU box)
 
 world 1 trains on the global batch [s0, s1]; world 2 gives sample r to rank r - what DDP + SyncBatchNorm make equivalent
 (configs/_base_/default_runtime.py:5, rein/models/heads/linear_head.py:44)."""
@@ -31,7 +31,8 @@ def main():
     rank, world, _ = parallel.init_from_env(backend)
     torch.cuda.set_device(0)
     L.set_device_index(0)
-    set_compute_dtype(mode)
+    amp = mode == "fp16amp"   # the reference's `--amp` under DP: AmpOptimWrapper (fp16 autocast, loss scale) + gradient all-reduce
+    set_compute_dtype("fp16" if amp else mode)
     depth = 4
     cfg = presets.dinov2_ms_masked(depth=depth)
     cfg["backbone"]["backbone"]["out_indices"] = [0, 1, 2, 3]
@@ -47,7 +48,8 @@ def main():
         if hasattr(m, "p") and isinstance(getattr(m, "p"), float):
             m.p = 0.0
     oc = presets.optim_cfg()
-    ow = PEFTOptimWrapperConstructor(oc["optim_wrapper"])(model, oc["param_scheduler"])
+    ocw = dict(oc["optim_wrapper"], type="AmpOptimWrapper", loss_scale="dynamic") if amp else oc["optim_wrapper"]
+    ow = PEFTOptimWrapperConstructor(ocw)(model, oc["param_scheduler"])
     events = []
     gs = parallel.attach(model, ow)
     if gs is not None:   # record when each bucket is launched relative to backward (overlap order)
@@ -75,6 +77,8 @@ def main():
             rec /= world
         logs.append(rec)
     torch.cuda.synchronize()
+    if amp:
+        assert ow.skipped == 0 and ow.scale == 65536.0 and ow.optimizer.step_count == 2
     if rank == 0:
         state = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if "lora_" in k or not k.startswith("backbone.")}
         torch.save(dict(state=state, logs=torch.stack(logs), events=events, world=world), out_path)

@@ -46,7 +46,7 @@ def _run(world, out, mode, backend="gloo", single=False):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode,ptol,ltol", [("f32", 2e-3, 1e-5)])
+@pytest.mark.parametrize("mode,ptol,ltol", [("f32", 2e-3, 1e-5), ("fp16amp", 1.5e-2, 2e-3)])
 def test_two_ranks_equal_one_rank_with_the_global_batch(tmp_path, mode, ptol, ltol):
     one = _run(1, str(tmp_path / "w1.pt"), mode)
     two = _run(2, str(tmp_path / "w2.pt"), mode)
