@@ -322,6 +322,19 @@ int vfm_conf_gate(const float* logits, int B, int C, int H, int W, int y0, int x
  * (slide accumulate, Ms_VFM_encoder_decoder.py:453-459) */
 int vfm_slide_accumulate(const float* crop, int crop_nchw, int B, int h, int w, int C, float* preds, float* count,
                          int H, int W, int y0, int x0, int hc, int wc, void* stream);
+/* The same merge as ONE gather pass: preds[b,c,y,x] = (sum over the windows j that hold (y,x), in table order, of the bilinear sample of
+ * window j's logits) / (their number).  preds is only written (no zero fill, no count map, no finalize pass); same per-sample
+ * arithmetic and summation order as vfm_slide_accumulate + vfm_slide_finalize.  wins: HOST array of nwin <= 16 descriptors; C <= 32. */
+typedef struct vfm_slide_win {
+  const float* crop; /* window logits: NHWC [B,h,w,C] (nchw = 0) or NCHW [B,C,h,w] (nchw = 1), device pointer */
+  int nchw, h, w;    /* layout and resolution of the window logits */
+  int y0, x0, hc, wc;/* where the window sits in the [H,W] map and its size there */
+} vfm_slide_win;
+int vfm_slide_gather(const vfm_slide_win* wins, int nwin, int B, int C, float* preds, int H, int W, void* stream);
+/* vfm_conf_gate for nwin <= 16 windows at once: boxes = HOST int[nwin*4] {y0, x0, hc, wc}; counts int32 [nwin] zeroed by the caller.  The
+ * predicate is evaluated once per pixel and counted for every window that holds it (Ms_VFM_encoder_decoder.py:446-448 per window). */
+int vfm_conf_gate_windows(const float* logits, int B, int C, int H, int W, const int* boxes, int nwin, float thr, int32_t* counts,
+                          void* stream);
 /* seg = preds / count ; pred = argmax_c  (NCHW) */
 int vfm_slide_finalize(float* preds, const float* count, uint8_t* argmax, int B, int C, int H, int W, void* stream);
 

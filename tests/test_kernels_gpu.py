@@ -811,6 +811,37 @@ def test_inference_helpers():
     assert torch.equal(am.cpu().long(), (pr / cr).argmax(1))
 
 
+def test_slide_gather_and_gate_windows_equal_the_per_window_ops():
+    """vfm_slide_gather (one gather pass over the output map) against vfm_slide_accumulate per window + vfm_slide_finalize, and
+    vfm_conf_gate_windows (all gates in one pass) against vfm_conf_gate per window: mixed low-res NHWC / full-res NCHW windows,
+    overlapping 3 x 3 grid as in the 1024^2 predictions, B = 2."""
+    B, C, H, W, hc, wc = 2, 19, 320, 448, 160, 192
+    boxes = [(y0, x0, hc, wc) for y0 in (0, 96, 160) for x0 in (0, 128, 256)]
+    wins = []
+    for j, bx in enumerate(boxes):
+        if j % 3 == 1:   # a window that kept its coarse logits: NCHW at window resolution
+            wins.append((rnd(B, C, hc, wc, seed=300 + j).to(DEV), True, bx))
+        else:            # refined window: NHWC low-res logits, upsampled x4
+            wins.append((rnd(B, hc // 4, wc // 4, C, seed=300 + j).to(DEV), False, bx))
+    preds0 = torch.zeros(B, C, H, W, device=DEV)
+    count = torch.zeros(B, 1, H, W, device=DEV)
+    for t, nchw, bx in wins:
+        h, w = (t.shape[2], t.shape[3]) if nchw else (t.shape[1], t.shape[2])
+        ops.slide_accumulate(t, nchw, B, h, w, C, preds0, count, bx)
+    ops.slide_finalize(preds0, count)
+    preds1 = torch.full((B, C, H, W), float("nan"), device=DEV)
+    assert ops.slide_gather(wins, preds1)
+    assert torch.isfinite(preds1).all() and (preds1 - preds0).abs().max().item() <= 1e-6 * preds0.abs().max().item()
+    assert not ops.slide_gather(wins * 2, preds1)   # 18 windows: the caller falls back to the per-window path
+    seg = (rnd(B, C, H, W, seed=333) * 3).to(DEV)
+    c0 = torch.zeros(len(boxes), dtype=torch.int32, device=DEV)
+    for j, bx in enumerate(boxes):
+        ops.conf_gate_count(seg, bx, 0.5, c0[j:j + 1])
+    c1 = torch.zeros(len(boxes), dtype=torch.int32, device=DEV)
+    ops.conf_gate_windows(seg, boxes, 0.5, c1)
+    assert torch.equal(c0, c1) and 0 < int(c0.min()) and int(c0.max()) < B * hc * wc
+
+
 @pytest.mark.parametrize("vec4,zero", [(False, False), (True, True)])
 def test_adamw(vec4, zero):
     """vs torch.optim.AdamW with two parameter groups (different lr multipliers and decays), scalar and float4 forms; the

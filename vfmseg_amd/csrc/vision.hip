@@ -662,6 +662,128 @@ extern "C" int vfm_slide_accumulate(const float* crop, int crop_nchw, int B, int
   return VFM_OK;
 }
 
+// ---- the sliding-window merge in ONE pass (gather form): every output pixel sums, in window order, the bilinear samples of the windows
+// that cover it and divides by their number - what vfm_slide_accumulate (one read-modify-write pass over preds per window) followed by
+// vfm_slide_finalize computes, with preds written once and never read: for a 1024^2 image and nine 512^2 windows 80 MB of stores
+// instead of nine RMW passes of 40 MB, two fills and a 160-MB finalize.  Same per-sample arithmetic, same summation order.
+struct SlideTab {
+  vfm_slide_win w[16];
+  int n;
+};
+template <int CMAX>
+__global__ void __launch_bounds__(256) k_slide_gather(SlideTab tab, int B, int C, float* __restrict__ preds, int H, int W) {
+  const long total = (long)B * H * W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    const long t = i / W;
+    const int y = (int)(t % H);
+    const long b = t / H;
+    float acc[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) acc[c] = 0.f;
+    float cnt = 0.f;
+    for (int j = 0; j < tab.n; ++j) {
+      const vfm_slide_win wd = tab.w[j];
+      const int yy = y - wd.y0, xx = x - wd.x0;
+      if (yy < 0 || yy >= wd.hc || xx < 0 || xx >= wd.wc) continue;
+      cnt += 1.f;
+      const Lerp ly = lerp_idx(yy, (float)wd.h / (float)wd.hc, wd.h), lx = lerp_idx(xx, (float)wd.w / (float)wd.wc, wd.w);
+      if (wd.nchw) {
+        const float* p = wd.crop + (b * C) * (long)wd.h * wd.w;
+        const long plane = (long)wd.h * wd.w;
+        const long o00 = ly.i0 * wd.w + lx.i0, o01 = ly.i0 * wd.w + lx.i1, o10 = ly.i1 * wd.w + lx.i0, o11 = ly.i1 * wd.w + lx.i1;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+          if (c < C) {
+            const float* q = p + c * plane;
+            acc[c] += ly.l0 * (lx.l0 * q[o00] + lx.l1 * q[o01]) + ly.l1 * (lx.l0 * q[o10] + lx.l1 * q[o11]);
+          }
+      } else {
+        const float* p = wd.crop + b * (long)wd.h * wd.w * C;
+        const float* q00 = p + ((long)ly.i0 * wd.w + lx.i0) * C;
+        const float* q01 = p + ((long)ly.i0 * wd.w + lx.i1) * C;
+        const float* q10 = p + ((long)ly.i1 * wd.w + lx.i0) * C;
+        const float* q11 = p + ((long)ly.i1 * wd.w + lx.i1) * C;
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c)
+          if (c < C) acc[c] += ly.l0 * (lx.l0 * q00[c] + lx.l1 * q01[c]) + ly.l1 * (lx.l0 * q10[c] + lx.l1 * q11[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) preds[((b * C + c) * (long)H + y) * W + x] = acc[c] / cnt;
+  }
+}
+extern "C" int vfm_slide_gather(const vfm_slide_win* wins, int nwin, int B, int C, float* preds, int H, int W, void* stream) {
+  VFM_CHECK(wins && nwin >= 1 && nwin <= 16 && C >= 1 && C <= 32, VFM_E_UNSUPPORTED, "vfm_slide_gather: 1..16 windows, 1..32 channels");
+  SlideTab tab;
+  tab.n = nwin;
+  for (int j = 0; j < nwin; ++j) {
+    tab.w[j] = wins[j];
+    VFM_CHECK(wins[j].crop && wins[j].y0 >= 0 && wins[j].x0 >= 0 && wins[j].y0 + wins[j].hc <= H && wins[j].x0 + wins[j].wc <= W &&
+                  wins[j].h >= 1 && wins[j].w >= 1, VFM_E_SHAPE, "vfm_slide_gather: window %d", j);
+  }
+  const long total = (long)B * H * W;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_slide_gather<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, tab, B, C, preds, H, W);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
+// the confidence gates of ALL windows in one pass: max softmax > thr is evaluated once per pixel (the windows overlap: nine 512^2 windows of
+// a 1024^2 map cover every pixel 2.25 times on average) and counted for every window that holds the pixel.  Integer atomics: exact.
+struct GateTab {
+  int y0[16], x0[16], hc[16], wc[16];
+  int n;
+};
+__global__ void __launch_bounds__(256) k_conf_gate_windows(const float* __restrict__ lg, int B, int C, int H, int W, GateTab tab, float thr,
+                                                          int32_t* __restrict__ counts) {
+  const long total = (long)B * H * W;
+  int local[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) local[j] = 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    const long t = i / W;
+    const int y = (int)(t % H);
+    const long b = t / H;
+    const float* p = lg + (b * C) * (long)H * W + (long)y * W + x;
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, p[(long)c * H * W]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(p[(long)c * H * W] - m);
+    const int hit = (1.0f / se > thr) ? 1 : 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < tab.n && y >= tab.y0[j] && y < tab.y0[j] + tab.hc[j] && x >= tab.x0[j] && x < tab.x0[j] + tab.wc[j]) local[j] += hit;
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (j >= tab.n) break;
+    int v = local[j];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(counts + j, v);
+  }
+}
+extern "C" int vfm_conf_gate_windows(const float* logits, int B, int C, int H, int W, const int* boxes, int nwin, float thr, int32_t* counts,
+                                     void* stream) {
+  VFM_CHECK(logits && boxes && counts && nwin >= 1 && nwin <= 16, VFM_E_UNSUPPORTED, "vfm_conf_gate_windows: 1..16 windows");
+  GateTab tab;
+  tab.n = nwin;
+  for (int j = 0; j < nwin; ++j) {
+    tab.y0[j] = boxes[4 * j], tab.x0[j] = boxes[4 * j + 1], tab.hc[j] = boxes[4 * j + 2], tab.wc[j] = boxes[4 * j + 3];
+    VFM_CHECK(tab.y0[j] >= 0 && tab.x0[j] >= 0 && tab.y0[j] + tab.hc[j] <= H && tab.x0[j] + tab.wc[j] <= W, VFM_E_SHAPE, "vfm_conf_gate_windows: window %d", j);
+  }
+  for (int j = nwin; j < 16; ++j) tab.y0[j] = tab.x0[j] = tab.hc[j] = tab.wc[j] = 0;
+  const long total = (long)B * H * W;
+  if (total == 0) return VFM_OK;
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_conf_gate_windows, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, B, C, H, W, tab, thr, counts);
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
+}
+
 __global__ void k_slide_fin(float* __restrict__ preds, const float* __restrict__ count, uint8_t* __restrict__ am, int B, int C,
                             int H, int W) {
   const long total = (long)B * H * W;

@@ -51,6 +51,10 @@ class AttnDesc(C.Structure):
     ]
 
 
+class SlideWin(C.Structure):
+    _fields_ = [("crop", vp), ("nchw", ci), ("h", ci), ("w", ci), ("y0", ci), ("x0", ci), ("hc", ci), ("wc", ci)]
+
+
 # name -> argtypes (return type is always int); mirrors include/vfmseg_hip.h
 SIGNATURES = {
     "vfm_cast": [vp, ci, cl, vp, ci, cl, cl, cl, vp, vp],
@@ -113,6 +117,8 @@ SIGNATURES = {
     "vfm_conf_gate": [vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, vp],
     "vfm_slide_accumulate": [vp, ci, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "vfm_slide_finalize": [vp, vp, vp, ci, ci, ci, ci, vp],
+    "vfm_slide_gather": [vp, ci, ci, ci, vp, ci, ci, vp],
+    "vfm_conf_gate_windows": [vp, ci, ci, ci, ci, vp, ci, cf, vp, vp],
     "vfm_confusion_hist": [vp, vp, ci, cl, ci, ci, vp, vp],
     "vfm_adamw": [vp, vp, vp, vp, cl, vp, vp, vp, ci, cf, cf, cf, cf, ci, cf, ci, ci, vp],
     "vfm_adamw_guarded": [vp, vp, vp, vp, cl, vp, vp, vp, ci, cf, cf, cf, cf, ci, cf, ci, ci, vp, vp, vp],

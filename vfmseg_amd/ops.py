@@ -3,6 +3,7 @@
 All tensors must live on the GPU; every call is asynchronous on torch's current HIP stream.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -820,6 +821,31 @@ def slide_accumulate(crop, crop_nchw, B, h, w, Cc, preds, count, window):
     y0, x0, hc, wc = window
     L.check(lib.vfm_slide_accumulate(L.ptr(crop), int(crop_nchw), B, h, w, Cc, L.ptr(preds), L.ptr(count), H, W, y0, x0, hc, wc,
                                      L.stream()), "vfm_slide_accumulate")
+
+
+def slide_gather(wins, preds):
+    """wins: list of (logits, nchw, window=(y0, x0, hc, wc)) in accumulation order; logits NHWC [B,h,w,C] or NCHW [B,C,h,w] fp32 contiguous.
+    preds [B,C,H,W] = mean over the covering windows of their bilinear samples (vfm_slide_gather); returns False when the table does not fit
+    (more than 16 windows / 32 channels): the caller then takes the per-window accumulate path."""
+    B, Cc, H, W = preds.shape
+    if len(wins) > 16 or Cc > 32 or len(wins) == 0 or os.environ.get("VFMSEG_SLIDE_GATHER", "1") == "0":   # (env: A/B of the two paths)
+        return False
+    arr = (L.SlideWin * len(wins))()
+    for j, (t, nchw, (y0, x0, hc, wc)) in enumerate(wins):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[0] == B
+        h, w = (t.shape[2], t.shape[3]) if nchw else (t.shape[1], t.shape[2])
+        arr[j] = L.SlideWin(L.ptr(t), int(bool(nchw)), h, w, y0, x0, hc, wc)
+    L.check(L.load().vfm_slide_gather(arr, len(wins), B, Cc, L.ptr(preds), H, W, L.stream()), "vfm_slide_gather")
+    return True
+
+
+def conf_gate_windows(logits_nchw, windows, thr, counts):
+    """counts[j] += number of pixels of window j = (y0, x0, hc, wc) whose max softmax exceeds thr - all windows in one pass (<= 16)."""
+    B, Cc, H, W = logits_nchw.shape
+    flat = (L.ci * (4 * len(windows)))(*[int(v) for wdw in windows for v in wdw])
+    L.check(L.load().vfm_conf_gate_windows(L.ptr(logits_nchw), B, Cc, H, W, flat, len(windows), float(thr), L.ptr(counts), L.stream()),
+            "vfm_conf_gate_windows")
+    return counts
 
 
 def slide_finalize(preds, count, argmax=None):

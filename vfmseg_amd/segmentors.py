@@ -202,20 +202,30 @@ class EncoderDecoder(nn.Module):
     def whole_inference(self, inputs, batch_img_metas):
         return self.encode_decode(inputs, batch_img_metas)
 
+    @staticmethod
+    def _merge_windows(wins, B, C, H, W, dev):
+        """mmseg's slide merge (preds[window] += resize(window logits); count += 1; preds / count) over `wins` = [(logits, nchw, (y0, x0, hc,
+        wc))] in accumulation order: one gather pass (vfm_slide_gather), or the per-window accumulate + finalize when the table does not fit."""
+        preds = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
+        if ops.slide_gather(wins, preds):
+            return preds
+        preds.zero_()
+        count = torch.zeros(B, 1, H, W, dtype=torch.float32, device=dev)
+        for t, nchw, box in wins:
+            h, w = (t.shape[2], t.shape[3]) if nchw else (t.shape[1], t.shape[2])
+            ops.slide_accumulate(t, nchw, B, h, w, C, preds, count, box)
+        ops.slide_finalize(preds, count)
+        return preds
+
     def slide_inference(self, inputs, batch_img_metas):
         B, _, H, W = inputs.shape
-        preds = torch.zeros(B, self.out_channels, H, W, dtype=torch.float32, device=inputs.device)
-        count = torch.zeros(B, 1, H, W, dtype=torch.float32, device=inputs.device)
         # the windows are independent: ONE batched backbone + head pass over all of them (rows = window-major), then the
-        # per-window resize-and-accumulate.  Same arithmetic as mmseg's sequential loop, far better GEMM shapes.
+        # resize-and-merge of the windows.  Same arithmetic as mmseg's sequential loop, far better GEMM shapes.
         boxes = grid_boxes(H, W, self.test_cfg.crop_size, self.test_cfg.stride)
         xcat, hp, wp = self._tokens([(inputs, b) for b in boxes])
         lg = self.decode_head.forward_tokens(FeatPack(xcat, B * len(boxes), hp, wp))  # NHWC low-res, [nwin*B, h, w, C]
-        for j, (y1, y2, x1, x2) in enumerate(boxes):
-            ops.slide_accumulate(lg[j * B:(j + 1) * B], False, B, lg.shape[1], lg.shape[2], lg.shape[3], preds, count,
-                                 (y1, x1, y2 - y1, x2 - x1))
-        ops.slide_finalize(preds, count)
-        return preds
+        wins = [(lg[j * B:(j + 1) * B], False, (y1, x1, y2 - y1, x2 - x1)) for j, (y1, y2, x1, x2) in enumerate(boxes)]
+        return self._merge_windows(wins, B, self.out_channels, H, W, inputs.device)
 
     def inference(self, inputs, batch_img_metas):
         mode = self.test_cfg.get("mode", "whole")
@@ -454,13 +464,9 @@ class MsVFMEncoderDecoder(EncoderDecoder):
                              (C * hc * wc, hc * wc, wc, 1))
         xcat, hp, wp = self._tokens([(inputs, b) for b in boxes])
         lg = self.aux_decoder.forward_tokens(FeatPack(xcat, B * len(boxes), hp, wp), ctx)
-        preds = torch.zeros(B, C, H, W, dtype=torch.float32, device=dev)
-        count = torch.zeros(B, 1, H, W, dtype=torch.float32, device=dev)
-        for j, (y1, y2, x1, x2) in enumerate(boxes):
-            ops.slide_accumulate(lg[j * B:(j + 1) * B], False, B, lg.shape[1], lg.shape[2], C, preds, count, (y1, x1, hc, wc))
-            self.hr_crop_box = (y1, y2, x1, x2)
-        ops.slide_finalize(preds, count)
-        return preds
+        wins = [(lg[j * B:(j + 1) * B], False, (y1, x1, hc, wc)) for j, (y1, y2, x1, x2) in enumerate(boxes)]
+        self.hr_crop_box = boxes[-1]
+        return self._merge_windows(wins, B, C, H, W, dev)
 
     def ms_inference(self, inputs, batch_img_metas):
         """Ms_VFM_encoder_decoder.py:400-466.  Stage 0: whole-image pass at a hard-coded (512, 1024) through the
@@ -481,16 +487,17 @@ class MsVFMEncoderDecoder(EncoderDecoder):
         had_mask = getattr(dec, "mask_enable", None)
         if had_mask is not None:
             dec.mask_enable = False
-        preds = torch.zeros(B, C, H, W, dtype=torch.float32, device=dev)
-        count = torch.zeros(B, 1, H, W, dtype=torch.float32, device=dev)
         boxes = grid_boxes(H, W, self.test_cfg.crop_size, self.test_cfg.stride)
         cnt = torch.zeros(len(boxes), dtype=torch.int32, device=dev)
         self.last_refined = []
         try:
-            # all gates depend only on the coarse logits: evaluate them together (ONE device->host sync instead of one
-            # per window), then refine the selected windows in one batched backbone + VFMHead pass
-            for j, (y1, y2, x1, x2) in enumerate(boxes):
-                ops.conf_gate_count(seg, (y1, x1, y2 - y1, x2 - x1), thr, cnt[j:j + 1])
+            # all gates depend only on the coarse logits: evaluate them together (ONE pass over the map and ONE device->host sync
+            # instead of one of each per window), then refine the selected windows in one batched backbone + VFMHead pass
+            if len(boxes) <= 16:
+                ops.conf_gate_windows(seg, [(y1, x1, y2 - y1, x2 - x1) for (y1, y2, x1, x2) in boxes], thr, cnt)
+            else:
+                for j, (y1, y2, x1, x2) in enumerate(boxes):
+                    ops.conf_gate_count(seg, (y1, x1, y2 - y1, x2 - x1), thr, cnt[j:j + 1])
             fracs = [c / float(B * (b[1] - b[0]) * (b[3] - b[2])) for c, b in zip(cnt.tolist(), boxes)]
             refine = [j for j, f in enumerate(fracs) if f < conf]
             hc, wc = boxes[0][1] - boxes[0][0], boxes[0][3] - boxes[0][2]
@@ -504,16 +511,17 @@ class MsVFMEncoderDecoder(EncoderDecoder):
                 xcat, hp, wp = self._tokens([(inputs, boxes[j]) for j in refine])
                 rctx = ctx if len(refine) == len(boxes) else torch.cat([ctx[j * B:(j + 1) * B] for j in refine], 0)
                 lg = self.aux_decoder.forward_tokens(FeatPack(xcat, B * len(refine), hp, wp), rctx)   # [nref*B, hp, wp, C]
+            wins = []
             for j, (y1, y2, x1, x2) in enumerate(boxes):
                 if j in refine:
                     k = refine.index(j)
-                    ops.slide_accumulate(lg[k * B:(k + 1) * B], False, B, lg.shape[1], lg.shape[2], C, preds, count, (y1, x1, hc, wc))
+                    wins.append((lg[k * B:(k + 1) * B], False, (y1, x1, hc, wc)))
                     self.last_refined.append((y1, y2, x1, x2))
-                else:
-                    ops.slide_accumulate(ctx[j * B:(j + 1) * B], True, B, hc, wc, C, preds, count, (y1, x1, hc, wc))
+                else:   # a confident window keeps its coarse logits
+                    wins.append((ctx[j * B:(j + 1) * B], True, (y1, x1, hc, wc)))
                 self.hr_crop_box = (y1, y2, x1, x2)
+            preds = self._merge_windows(wins, B, C, H, W, dev)
         finally:
             if had_mask is not None:
                 dec.mask_enable = had_mask
-        ops.slide_finalize(preds, count)
         return preds
