@@ -319,18 +319,49 @@ class VFMHead(BaseDecodeHead):
         )
         self.transformer_decoder = MODELS.build(transformer)
 
-    def forward_tokens(self, fp, ctx_nchw):
-        """fp: HR feature pack; ctx_nchw: fp32 [B,19,Hc,Wc] coarse logits (no gradient, as in the reference)."""
+    @staticmethod
+    def ctx_windows_ok(seg, boxes, hp, wp):
+        """Can the context windows be sampled straight out of the full-size coarse map `seg` [Bimg,C,H,W] (forward_tokens ctx_windows=)?
+        The window resize (Hc -> 4 hp) and the whole-map resize (H -> H / s) must share the integer scale s and the window origins must
+        sit on the coarse grid: then both put the same taps and weights on the same pixels (align_corners=False: src = s (dst + 0.5) - 0.5)."""
+        H, W = seg.shape[2:]
+        ok = True
+        for (y1, y2, x1, x2) in boxes:
+            hc, wc = y2 - y1, x2 - x1
+            ok = ok and hc % (4 * hp) == 0 and wc % (4 * wp) == 0 and hc // (4 * hp) == wc // (4 * wp)
+            if ok:
+                s_ = hc // (4 * hp)
+                ok = y1 % s_ == 0 and x1 % s_ == 0 and H % s_ == 0 and W % s_ == 0
+        return ok and len(boxes) > 0
+
+    def forward_tokens(self, fp, ctx_nchw, ctx_windows=None):
+        """fp: HR feature pack; ctx_nchw: fp32 [B,19,Hc,Wc] coarse logits (no gradient, as in the reference) - or ctx_windows = (seg, boxes):
+        the context of pack image j * Bimg + b is window boxes[j] = (y1, y2, x1, x2) of the full-size map seg[b] (see ctx_windows_ok; saves
+        the copy of every window into a batch tensor)."""
         cd = compute_dtype()
         B, hp, wp = fp.B, fp.hp, fp.wp
         P = hp * wp
         emb, fc = self.seg_logits_embed, self.fuse_conv
-        ctx_nchw = ctx_nchw.detach().contiguous()
-        Cc, Hc, Wc = ctx_nchw.shape[1:]
+        if ctx_windows is not None:
+            seg, boxes = ctx_windows
+            seg = seg.detach()
+            assert seg.is_contiguous() and seg.dtype == torch.float32 and len(boxes) * seg.shape[0] == B
+            Bimg, Cc, H, W = seg.shape
+            dev = seg.device
+        else:
+            ctx_nchw = ctx_nchw.detach().contiguous()
+            Cc, Hc, Wc = ctx_nchw.shape[1:]
+            dev = ctx_nchw.device
         kpad = 128 if 4 * Cc <= 128 else (4 * Cc + 63) // 64 * 64
-        a1 = torch.zeros(B * 4 * P, kpad, dtype=cd, device=ctx_nchw.device)
+        a1 = torch.zeros(B * 4 * P, kpad, dtype=cd, device=dev)
         # bilinear to 4x the feature grid (VFMHead.py:63-67), emitted in 2x2-blocked order: rows = stride-2 conv patches
-        ops.resize_bilinear(ctx_nchw, True, B, Hc, Wc, Cc, a1, 2, (4 * hp, 4 * wp), out_ld=kpad)
+        if ctx_windows is not None:
+            for j, (y1, y2, x1, x2) in enumerate(boxes):
+                s_ = (y2 - y1) // (4 * hp)
+                ops.resize_bilinear(seg, True, Bimg, H, W, Cc, a1[j * Bimg * 4 * P:(j + 1) * Bimg * 4 * P], 2, (H // s_, W // s_),
+                                    window=(y1 // s_, x1 // s_, 4 * hp, 4 * wp), out_ld=kpad)
+        else:
+            ops.resize_bilinear(ctx_nchw, True, B, Hc, Wc, Cc, a1, 2, (4 * hp, 4 * wp), out_ld=kpad)
         e = Fh.linear(a1, emb[0].weight, "conv2x2s2", bias=emb[0].bias, out_dtype=torch.float32)
         e = Fh.group_norm_act(e, emb[1].weight, emb[1].bias, B, 4 * P, 32, emb[1].eps, ops.ACT_GELU, cd)
         e = Fh.linear(e.view(B * P, -1), emb[3].weight, "conv2x2s2", bias=emb[3].bias, out_dtype=torch.float32)

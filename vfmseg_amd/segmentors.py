@@ -203,6 +203,18 @@ class EncoderDecoder(nn.Module):
         return self.encode_decode(inputs, batch_img_metas)
 
     @staticmethod
+    def _window_batch(seg, boxes):
+        """[len(boxes) * B, C, hc, wc]: the windows (y1, y2, x1, x2) of the NCHW map seg, window-major, contiguous."""
+        B, C = seg.shape[:2]
+        hc, wc = boxes[0][1] - boxes[0][0], boxes[0][3] - boxes[0][2]
+        out = torch.empty(len(boxes) * B, C, hc, wc, dtype=torch.float32, device=seg.device)
+        for j, (y1, y2, x1, x2) in enumerate(boxes):
+            win = seg[:, :, y1:y2, x1:x2]
+            ops.strided_copy(win, out[j * B:(j + 1) * B], (B, C, hc, wc), (win.stride(0), win.stride(1), win.stride(2), 1),
+                             (C * hc * wc, hc * wc, wc, 1))
+        return out
+
+    @staticmethod
     def _merge_windows(wins, B, C, H, W, dev):
         """mmseg's slide merge (preds[window] += resize(window logits); count += 1; preds / count) over `wins` = [(logits, nchw, (y0, x0, hc,
         wc))] in accumulation order: one gather pass (vfm_slide_gather), or the per-window accumulate + finalize when the table does not fit."""
@@ -457,13 +469,11 @@ class MsVFMEncoderDecoder(EncoderDecoder):
         boxes = grid_boxes(H, W, self.test_cfg.crop_size, self.test_cfg.stride)
         hc, wc = boxes[0][1] - boxes[0][0], boxes[0][3] - boxes[0][2]
         assert all((b[1] - b[0], b[3] - b[2]) == (hc, wc) for b in boxes)
-        ctx = torch.empty(len(boxes) * B, C, hc, wc, dtype=torch.float32, device=dev)
-        for j, (y1, y2, x1, x2) in enumerate(boxes):
-            win = seg[:, :, y1:y2, x1:x2]
-            ops.strided_copy(win, ctx[j * B:(j + 1) * B], (B, C, hc, wc), (win.stride(0), win.stride(1), win.stride(2), 1),
-                             (C * hc * wc, hc * wc, wc, 1))
         xcat, hp, wp = self._tokens([(inputs, b) for b in boxes])
-        lg = self.aux_decoder.forward_tokens(FeatPack(xcat, B * len(boxes), hp, wp), ctx)
+        if self.aux_decoder.ctx_windows_ok(seg, boxes, hp, wp):   # the context windows are sampled straight out of the coarse map
+            lg = self.aux_decoder.forward_tokens(FeatPack(xcat, B * len(boxes), hp, wp), None, ctx_windows=(seg, boxes))
+        else:
+            lg = self.aux_decoder.forward_tokens(FeatPack(xcat, B * len(boxes), hp, wp), self._window_batch(seg, boxes))
         wins = [(lg[j * B:(j + 1) * B], False, (y1, x1, hc, wc)) for j, (y1, y2, x1, x2) in enumerate(boxes)]
         self.hr_crop_box = boxes[-1]
         return self._merge_windows(wins, B, C, H, W, dev)
@@ -502,23 +512,24 @@ class MsVFMEncoderDecoder(EncoderDecoder):
             refine = [j for j, f in enumerate(fracs) if f < conf]
             hc, wc = boxes[0][1] - boxes[0][0], boxes[0][3] - boxes[0][2]
             assert all((b[1] - b[0], b[3] - b[2]) == (hc, wc) for b in boxes)
-            ctx = torch.empty(len(boxes) * B, C, hc, wc, dtype=torch.float32, device=dev)
-            for j, (y1, y2, x1, x2) in enumerate(boxes):
-                win = seg[:, :, y1:y2, x1:x2]
-                dst = ctx[j * B:(j + 1) * B]
-                ops.strided_copy(win, dst, (B, C, hc, wc), (win.stride(0), win.stride(1), win.stride(2), 1), (C * hc * wc, hc * wc, wc, 1))
             if refine:
                 xcat, hp, wp = self._tokens([(inputs, boxes[j]) for j in refine])
-                rctx = ctx if len(refine) == len(boxes) else torch.cat([ctx[j * B:(j + 1) * B] for j in refine], 0)
-                lg = self.aux_decoder.forward_tokens(FeatPack(xcat, B * len(refine), hp, wp), rctx)   # [nref*B, hp, wp, C]
+                rboxes = [boxes[j] for j in refine]
+                if self.aux_decoder.ctx_windows_ok(seg, rboxes, hp, wp):   # context windows sampled straight out of the coarse map
+                    lg = self.aux_decoder.forward_tokens(FeatPack(xcat, B * len(refine), hp, wp), None, ctx_windows=(seg, rboxes))
+                else:
+                    lg = self.aux_decoder.forward_tokens(FeatPack(xcat, B * len(refine), hp, wp), self._window_batch(seg, rboxes))   # [nref*B, hp, wp, C]
+            keep = [j for j in range(len(boxes)) if j not in refine]
+            kctx = self._window_batch(seg, [boxes[j] for j in keep]) if keep else None   # confident windows keep their coarse logits
             wins = []
             for j, (y1, y2, x1, x2) in enumerate(boxes):
                 if j in refine:
                     k = refine.index(j)
                     wins.append((lg[k * B:(k + 1) * B], False, (y1, x1, hc, wc)))
                     self.last_refined.append((y1, y2, x1, x2))
-                else:   # a confident window keeps its coarse logits
-                    wins.append((ctx[j * B:(j + 1) * B], True, (y1, x1, hc, wc)))
+                else:
+                    k = keep.index(j)
+                    wins.append((kctx[k * B:(k + 1) * B], True, (y1, x1, hc, wc)))
                 self.hr_crop_box = (y1, y2, x1, x2)
             preds = self._merge_windows(wins, B, C, H, W, dev)
         finally:
