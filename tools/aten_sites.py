@@ -13,11 +13,30 @@ import bench
 from vfmseg_amd import functional as Fh
 
 dev = torch.device("cuda", 0)
-model, ow = bench.build(dev, 2)
-Fh.manual_seed(1)
-data = bench.make_batch(2, 0, 0, dev)
+EVAL = len(sys.argv) > 1 and sys.argv[1] == "eval"   # `python tools/aten_sites.py eval`: one 1024^2 ms_slide prediction instead of a train step
+if EVAL:
+    from vfmseg_amd import presets
+    from vfmseg_amd.registry import MODELS
+    from vfmseg_amd.synth import synth_image, synth_like
+    cfg = presets.dinov2_ms_masked()
+    cfg["test_cfg"]["conf"] = 2.0
+    model = MODELS.build(cfg)
+    model.load_state_dict(synth_like(model.state_dict()), strict=False)
+    model = model.to(dev).eval()
+    img = synth_image(1, 1024, seed=77).to(dev)
+
+    def one():
+        with torch.no_grad():
+            model.predict(img)
+else:
+    model, ow = bench.build(dev, 2)
+    Fh.manual_seed(1)
+    data = bench.make_batch(2, 0, 0, dev)
+
+    def one():
+        model.train_step(data, ow)
 for _ in range(3):
-    model.train_step(data, ow)
+    one()
 torch.cuda.synchronize()
 sites = collections.Counter()
 
@@ -53,11 +72,11 @@ def wrap_fn(name):
 
 
 METHODS = ["zero_", "fill_", "copy_", "clone", "contiguous", "add_", "mul_", "add", "mul", "sub", "float", "to", "bfloat16", "sum", "mean", "__add__",
-           "__mul__", "__gt__", "__sub__", "__truediv__", "div", "masked_fill_", "index_select", "__getitem__"]
-FNS = ["zeros", "ones", "full", "cat", "stack", "zeros_like", "ones_like", "where", "empty_like"]
+           "__mul__", "__gt__", "__sub__", "__truediv__", "div", "masked_fill_", "index_select", "__getitem__", "tolist", "item", "cpu", "cuda"]
+FNS = ["zeros", "ones", "full", "cat", "stack", "zeros_like", "ones_like", "where", "empty_like", "tensor", "as_tensor", "from_numpy"]
 saved = {m: wrap_method(m) for m in METHODS if hasattr(torch.Tensor, m)}
 savedf = {f: wrap_fn(f) for f in FNS}
-model.train_step(data, ow)
+one()
 torch.cuda.synchronize()
 for m, o in saved.items():
     setattr(torch.Tensor, m, o)
