@@ -97,7 +97,7 @@ def test_amp_wrapper_skips_a_poisoned_step():
 # CPU tensors, real fp16 tensors at the op boundaries - with the same loss scale.  fp16 results are not reproducible bit for bit
 # between two implementations (the flash kernels keep scores in fp32 where torch rounds them to fp16, sums associate differently), so
 # the bar is: the HIP fp16 run is as close to the EXACT (fp32 oracle) run as the emulated reference fp16 run is.
-def _fp16_three_steps(init_scale):
+def _fp16_three_steps(init_scale, steps=3, exact=True):
     import vfmseg_amd  # noqa: F401
     from oracle import torch_ref as R
     from oracle.amp_emul import cuda_autocast
@@ -128,7 +128,7 @@ def _fp16_three_steps(init_scale):
         assert ow.mode == "fp16" and ow.dtype == torch.float16          # mmengine: dtype None = the CUDA autocast default
         keep = torch.rand(1, 1, 32, 32, generator=torch.Generator().manual_seed(3)) > 0.2
         model.aux_decoder.transformer_decoder.fixed_keep = keep
-        boxes = [(256, 768, 128, 640), (0, 512, 512, 1024), (384, 896, 256, 768)]
+        boxes = [(256, 768, 128, 640), (0, 512, 512, 1024), (384, 896, 256, 768)][:steps]
         sd32, sd16 = ({k: v.clone() for k, v in sd0.items()} for _ in range(2))
         st32, st16 = {}, {}
         scale16, t32, t16 = init_scale, 0, 0
@@ -137,7 +137,7 @@ def _fp16_three_steps(init_scale):
             img, lab = synth_image(1, 1024, seed=60 + t), synth_label(1, 1024, seed=60 + t)
             model.fixed_crop_box = box
             log = model.train_step(dict(inputs=img.cuda(), data_samples=[SegDataSample(gt_sem_seg=lab[0])]), ow)
-            r32 = R.train_step(sd32, st32, img, lab, box, keep, t32, end=10, depth=depth, out_indices=tuple(out_idx))
+            r32 = R.train_step(sd32, st32, img, lab, box, keep, t32, end=10, depth=depth, out_indices=tuple(out_idx)) if exact else None
             t32 += 1
             with cuda_autocast(torch.float16):
                 r16 = R.train_step(sd16, st16, img, lab, box, keep, t16, end=10, depth=depth, out_indices=tuple(out_idx), loss_scale=scale16)
@@ -200,15 +200,15 @@ def test_fp16_amp_three_steps_as_close_to_fp32_as_the_emulated_reference_fp16_ru
 def test_fp16_amp_overflow_backs_the_scale_off_like_the_emulated_reference():
     """With an absurd initial scale the fp16 backward overflows (bf16 would not: test_amp_wrapper_equals_plain_wrapper): every step is
     skipped, the scale halves each time, parameters and AdamW state stay put - on the HIP path and in the emulated reference run."""
-    sd0, got, sd32, sd16, logs, ow, scale16 = _fp16_three_steps(2.0 ** 40)
-    assert ow.skipped == 3 and ow.scale == 2.0 ** 37 and ow.optimizer.step_count == 0 and ow.iter == 3
-    assert scale16 == 2.0 ** 37 and all(r16.get("skipped") for _, _, r16 in logs)
+    sd0, got, sd32, sd16, logs, ow, scale16 = _fp16_three_steps(2.0 ** 40, steps=2, exact=False)
+    assert ow.skipped == 2 and ow.scale == 2.0 ** 38 and ow.optimizer.step_count == 0 and ow.iter == 2
+    assert scale16 == 2.0 ** 38 and all(r16.get("skipped") for _, _, r16 in logs)
     for k in PROBES:
         assert torch.equal(got[k], sd0[k]) and torch.equal(sd16[k], sd0[k]), k
-    # the forward pass is unaffected by the scale: losses are those of the exact run at the SAME (unchanged) parameters
-    log, r32, r16 = logs[0]
+    # the forward pass is unaffected by the scale: the losses are those of the emulated reference run at the SAME (unchanged) parameters
+    log, _, r16 = logs[0]
     for k in ("decode_lr.loss_ce", "decode_hr.loss_ce"):
-        assert abs(float(log[k]) - r32[k]) < 2e-3 * abs(r32[k])
+        assert abs(float(log[k]) - r16[k]) < 2e-3 * abs(r16[k])
 
 
 def test_device_side_loss_scaler_follows_gradscaler():
