@@ -183,6 +183,9 @@ def test_slide_modes_match_reference_goldens(golden_dir, prec, ltol, mtol):
         set_compute_dtype("bf16")
 
 
+_ORACLE_MS = {}   # image index -> argmax of the oracle's ms_inference (fp32 CPU; the same for every precision mode of the HIP path)
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 def test_miou_within_0p1_of_oracle_on_fixed_synthetic_batch(mode):
     """north_star: "mIoU within +-0.1 of reference on a fixed synthetic batch".  Predictions of the HIP path (ms_slide_inference,
@@ -197,9 +200,10 @@ def test_miou_within_0p1_of_oracle_on_fixed_synthetic_batch(mode):
             img, lab = synth_image(1, 1024, seed=300 + i), synth_label(1, 1024, seed=300 + i)
             with torch.no_grad():
                 out = model.predict(img.cuda(), [SegDataSample(gt_sem_seg=lab[0].cuda(), metainfo=dict(seg_map_path=f"citys/{i}.png", ori_shape=(1024, 1024)))])
-                ref = R.ms_inference(sd, img, thr=model.test_cfg["threadshod"], conf=model.test_cfg["conf"], **kw)
+                if i not in _ORACLE_MS:
+                    _ORACLE_MS[i] = R.ms_inference(sd, img, thr=model.test_cfg["threadshod"], conf=model.test_cfg["conf"], **kw).argmax(1)[0]
             metric.process(None, out)
-            ref_batches.append([(ref.argmax(1)[0], lab[0, 0], f"citys/{i}.png")])
+            ref_batches.append([(_ORACLE_MS[i], lab[0, 0], f"citys/{i}.png")])
         got, want = metric.evaluate(3), R.dg_iou_metrics(ref_batches, ["citys"])
         print(f"[mIoU {mode}] HIP {got} | oracle {want}")
         for k in ("citys_mIoU", "citys_mAcc", "citys_aAcc", "mean_mIoU"):
@@ -218,6 +222,9 @@ def _colour_coded(seed, size=1024):
     return img.contiguous(), lab
 
 
+_TRAINED = {}   # the 60-step training run (bf16) and the oracle's predictions with its weights: shared by the precision modes under test
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16", "fp16"])
 def test_miou_after_training_within_0p1_of_oracle(mode):
     """Round-2 verdict: the +-0.1 mIoU target was only tested at random-init weights (mIoU 2.3 % on both sides).  Here a depth-4 model is
@@ -231,18 +238,23 @@ def test_miou_after_training_within_0p1_of_oracle(mode):
     try:
         cfg = presets.dinov2_ms_masked(depth=depth)
         cfg["backbone"]["backbone"]["out_indices"] = [0, 1, 2, 3]
-        model = MODELS.build(cfg)
-        model.load_state_dict(full_state_dict(depth=depth))
-        model = model.cuda().train()
-        oc = presets.optim_cfg()
-        oc["optim_wrapper"]["optimizer"]["lr"] = 1e-3
-        ow = PEFTOptimWrapperConstructor(oc["optim_wrapper"])(model, oc["param_scheduler"])
-        np.random.seed(5)
-        samples = [_colour_coded(400 + i) for i in range(3)]
-        for t in range(60):
-            img, lab = samples[t % 3]
-            model.train_step(dict(inputs=img.cuda(), data_samples=[SegDataSample(gt_sem_seg=lab[0])]), ow)
-        sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+        if "sd" not in _TRAINED:
+            model = MODELS.build(cfg)
+            model.load_state_dict(full_state_dict(depth=depth))
+            model = model.cuda().train()
+            oc = presets.optim_cfg()
+            oc["optim_wrapper"]["optimizer"]["lr"] = 1e-3
+            ow = PEFTOptimWrapperConstructor(oc["optim_wrapper"])(model, oc["param_scheduler"])
+            np.random.seed(5)
+            samples = [_colour_coded(400 + i) for i in range(3)]
+            for t in range(60):
+                img, lab = samples[t % 3]
+                model.train_step(dict(inputs=img.cuda(), data_samples=[SegDataSample(gt_sem_seg=lab[0])]), ow)
+            _TRAINED["sd"] = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+            _TRAINED["samples"] = samples
+            _TRAINED["ref"] = {}
+            del model, ow
+        sd, samples = _TRAINED["sd"], _TRAINED["samples"]
         set_compute_dtype(mode)
         model = MODELS.build(cfg)
         model.load_state_dict(sd)
@@ -253,10 +265,12 @@ def test_miou_after_training_within_0p1_of_oracle(mode):
         for i, (img, lab) in enumerate(samples):
             with torch.no_grad():
                 out = model.predict(img.cuda(), [SegDataSample(gt_sem_seg=lab[0].cuda(), metainfo=dict(seg_map_path=f"citys/{i}.png", ori_shape=(1024, 1024)))])
-                ref = R.ms_inference(sd, img, thr=model.test_cfg["threadshod"], conf=model.test_cfg["conf"], **kw)
+                if i not in _TRAINED["ref"]:
+                    _TRAINED["ref"][i] = R.ms_inference(sd, img, thr=model.test_cfg["threadshod"], conf=model.test_cfg["conf"], **kw).argmax(1)[0]
+            ref_am = _TRAINED["ref"][i]
             metric.process(None, out)
-            ref_batches.append([(ref.argmax(1)[0], lab[0, 0], f"citys/{i}.png")])
-            flips.append((out[0].pred_sem_seg.data[0].cpu().long() != ref.argmax(1)[0]).float().mean().item())
+            ref_batches.append([(ref_am, lab[0, 0], f"citys/{i}.png")])
+            flips.append((out[0].pred_sem_seg.data[0].cpu().long() != ref_am).float().mean().item())
         got, want = metric.evaluate(3), R.dg_iou_metrics(ref_batches, ["citys"])
         print(f"[parity] mIoU after 60 train steps, {mode}: HIP {got} | oracle {want} | argmax mismatches {max(flips):.2e}")
         assert want["citys_mIoU"] > 10.0, "the trained model must carry signal for this test to mean anything"

@@ -28,15 +28,23 @@ def _zero_dropout(m):
             mod.p = 0.0
 
 
+_MODULES = {}
+
+
 def _fulldepth(golden_dir, name, cfg, sd, img_seed, gen_seed, D, live, tol, stol, gtol, ntol, allowed_missing):
     """taps (8x8x8 slice, tail where stored, whole-tensor stats) and LoRA gradients (8x8 slices + norm over the live
     adapters) of a full-depth backbone vs the golden written by the reference's own module."""
     G = np.load(os.path.join(golden_dir, name))
-    m = MODELS.build(cfg)
-    missing, unexpected = m.load_state_dict({k[len("backbone."):]: v for k, v in sd.items()}, strict=False)
-    assert not unexpected and all(allowed_missing(k) for k in missing), (missing, unexpected)
-    m = m.cuda().train()
-    _zero_dropout(m)
+    if name not in _MODULES:   # one module per backbone for all precision modes (its engine keeps per-dtype operand packs)
+        m = MODELS.build(cfg)
+        missing, unexpected = m.load_state_dict({k[len("backbone."):]: v for k, v in (sd() if callable(sd) else sd).items()}, strict=False)
+        assert not unexpected and all(allowed_missing(k) for k in missing), (missing, unexpected)
+        m = m.cuda().train()
+        _zero_dropout(m)
+        _MODULES[name] = m
+    m = _MODULES[name]
+    for p_ in m.parameters():
+        p_.grad = None
     img = synth_image(1, 512, seed=img_seed)
     xcat, (hp, wp) = m.forward_tokens([(img.cuda(), None)])
     assert (hp, wp) == (32, 32)
@@ -88,7 +96,7 @@ def test_eva02_full_depth_vs_reference_golden(golden_dir, mode, tol, stol, gtol,
     set_compute_dtype(mode)
     try:
         cfg = dict(type="LoRABackbone", backbone=presets.eva02_backbone(), Lora_config=presets.eva02_lora_cfg(dropout=0.0))
-        _fulldepth(golden_dir, "eva02.npz", cfg, eva02_state_dict(), 31, 6, 1024, lambda n: "attn.proj.lora_" in n,
+        _fulldepth(golden_dir, "eva02.npz", cfg, eva02_state_dict, 31, 6, 1024, lambda n: "attn.proj.lora_" in n,
                    tol, stol, gtol, ntol, lambda k: "rope" in k)
     finally:
         set_compute_dtype("bf16")
@@ -102,7 +110,7 @@ def test_clip_full_depth_vs_reference_golden(golden_dir, mode, tol, stol, gtol, 
     set_compute_dtype(mode)
     try:
         cfg = dict(type="LoRABackbone", backbone=presets.clip_backbone(), Lora_config=presets.clip_lora_cfg(dropout=0.0))
-        _fulldepth(golden_dir, "clip.npz", cfg, clip_state_dict(), 51, 7, 1024, lambda n: "mlp.c_" in n,
+        _fulldepth(golden_dir, "clip.npz", cfg, clip_state_dict, 51, 7, 1024, lambda n: "mlp.c_" in n,
                    tol, stol, gtol, ntol, lambda k: ".fpn" in k)
     finally:
         set_compute_dtype("bf16")
@@ -116,7 +124,7 @@ def test_sam_full_depth_vs_reference_golden(golden_dir, mode, tol, stol, gtol, n
     set_compute_dtype(mode)
     try:
         cfg = dict(type="LoRABackbone", backbone=presets.sam_backbone(), Lora_config=presets.lora_cfg(dropout=0.0))
-        _fulldepth(golden_dir, "sam.npz", cfg, sam_state_dict(), 41, 9, 1280, lambda n: True,
+        _fulldepth(golden_dir, "sam.npz", cfg, sam_state_dict, 41, 9, 1280, lambda n: True,
                    tol, stol, gtol, ntol, lambda k: False)
     finally:
         set_compute_dtype("bf16")
