@@ -175,6 +175,51 @@ def eval_leg(device, timer, iters=5):
     return res
 
 
+def other_backbones_leg(device, batch, timer, steps=10, warmup=3):
+    """BASELINE configs[3]: EVA02-ViT-L/14 + LoRA + LinearHead + VFMHead (lora_eva02_ms_masked), the same train step as the headline
+    (synthetic 1024^2 samples -> LR + HR 512^2 passes, bs 2, bf16): images/s and the MFMA-kernel fraction of its backbone."""
+    _heavy()
+    import vfmseg_amd  # noqa: F401
+    from vfmseg_amd import functional as Fh, presets
+    from vfmseg_amd.optim import PEFTOptimWrapperConstructor
+    from vfmseg_amd.registry import MODELS
+    from vfmseg_amd.synth import synth_like
+    out = {}
+    for key, preset, label in (("eva02_ms_masked", "eva02_ms_masked", "configs[3]: EVA02-L/14 + LoRA(q,k,v,attn.proj) + LinearHead + VFMHead, 512^2 passes"),):
+        print(f"[bench] other-backbones leg: {key}", file=sys.stderr, flush=True)
+        model = MODELS.build(getattr(presets, preset)())
+        sd = {k: v for k, v in synth_like(model.state_dict()).items() if "rope." not in k}
+        model.load_state_dict(sd, strict=False)
+        model = model.to(device).train()
+        oc = presets.optim_cfg()
+        ow = PEFTOptimWrapperConstructor(oc["optim_wrapper"])(model, oc["param_scheduler"])
+        Fh.manual_seed(7)
+        data = make_batch(batch, 0, 0, device)
+        for _ in range(warmup):
+            model.train_step(data, ow)
+        torch.cuda.synchronize()
+        if timer is not None:
+            timer.reset()
+            timer.on = True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model.train_step(data, ow)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        r = {"what": label, "train_images_per_s": round(batch / dt, 2), "ms_per_step": round(dt * 1e3, 3), "steps": steps, "batch": batch, "dtype": "bf16"}
+        if timer is not None:
+            timer.on = False
+            blk = timer.summary(kinds=("gemm", "gemm_tn", "attn_fwd", "attn_bwd"), region="backbone")
+            if blk is not None:
+                r["blocks_tflops"] = round(blk["tflops"], 1)
+                r["blocks_frac"] = round(blk["tflops"] / PEAK_BF16_TFLOPS, 4)
+                r["kernel_ms_per_step_est"] = round(blk["ms"] * timer.every / steps, 3)
+        out[key] = r
+        del model, ow, data
+        torch.cuda.empty_cache()
+    return out
+
+
 def parity_leg(device, batch, steps=3, iters=2, modes=("bf16x3", "f32")):
     """The two modes whose results meet north_star's tolerance (logits <= 1e-3 rel, argmax mismatches only on near-ties against the
     reference's fp32 CPU path: tests/test_model_gpu.py::test_ms_inference_matches_reference_golden[f32|bf16x3],
@@ -244,12 +289,16 @@ def cpu_baseline(seconds_cap=40.0, model_kw=None):
     from vfmseg_amd.synth import synth_image, synth_label, synth_like
     import vfmseg_amd  # noqa: F401
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except Exception:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("VFMSEG_CPU_THREADS", "16"))))  # a GPU box grants a 16-core share
+        avail = os.cpu_count() or 1
+    # every host core this process may run on (its affinity mask), one warm-up step, one timed step.
+    # VFMSEG_CPU_THREADS is an explicit override only (stated in the output when it is in force).
+    override = os.environ.get("VFMSEG_CPU_THREADS")
+    cores = max(1, min(avail, int(override))) if override else max(1, avail)
     torch.set_num_threads(cores)
-    print(f"[bench] cpu_baseline: oracle train step on {cores} threads ...", file=sys.stderr, flush=True)
+    print(f"[bench] cpu_baseline: oracle train step on {cores} threads (affinity mask: {avail} cores"
+          + (f", VFMSEG_CPU_THREADS={override}" if override else "") + ") ...", file=sys.stderr, flush=True)
     cfg = presets.dinov2_ms_masked(**(model_kw or {}))  # model_kw: tests shrink the model, not the workload
     bb = cfg["backbone"]["backbone"]
     model = MODELS.build(cfg)
@@ -260,13 +309,19 @@ def cpu_baseline(seconds_cap=40.0, model_kw=None):
         sd[k] = sd[k].clone().requires_grad_(True)
     img, lab = synth_image(1, 1024, seed=7), synth_label(1, 1024, seed=7)
     keep = torch.rand(1, 1, 32, 32, generator=torch.Generator().manual_seed(1)) > 0.2
+    def one_step():
+        losses = R.forward_train(sd, img, lab, (256, 768, 256, 768), keep, depth=bb["depth"], heads=bb["num_heads"],
+                                 out_indices=tuple(bb.get("out_indices", (7, 11, 15, 23))))
+        grads = torch.autograd.grad(R.total_loss(losses), [sd[k] for k in tk])
+        with torch.no_grad():
+            for k, g in zip(tk, grads):
+                R.adamw_step(sd[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, 1e-4, 0.05)
+        return grads
     t0 = time.time()
-    losses = R.forward_train(sd, img, lab, (256, 768, 256, 768), keep, depth=bb["depth"], heads=bb["num_heads"],
-                             out_indices=tuple(bb.get("out_indices", (7, 11, 15, 23))))
-    grads = torch.autograd.grad(R.total_loss(losses), [sd[k] for k in tk])
-    with torch.no_grad():
-        for k, g in zip(tk, grads):
-            R.adamw_step(sd[k], g, torch.zeros_like(g), torch.zeros_like(g), 1, 1e-4, 0.05)
+    grads = one_step()                 # warm-up (thread pool start, allocator growth, first-touch of the weights)
+    t_warm = time.time() - t0
+    t0 = time.time()
+    grads = one_step()
     dt = time.time() - t0
     cpu_model = "unknown"
     try:
@@ -277,8 +332,9 @@ def cpu_baseline(seconds_cap=40.0, model_kw=None):
                     break
     except OSError:
         pass
-    out = dict(value=1.0 / dt, unit="images/s", cores=cores, cpu_model=cpu_model, host_cpus=os.cpu_count(), kind="port",
-               sample=f"1 train step (fwd+bwd+AdamW), B=1, 1024^2 -> 2x512^2 passes, fp32 torch CPU, {dt:.1f} s")
+    out = dict(value=1.0 / dt, unit="images/s", cores=cores, cpu_model=cpu_model, host_cpus=os.cpu_count(), affinity_cores=avail,
+               threads_override=override, kind="port",
+               sample=f"1 warm-up ({t_warm:.1f} s) + 1 timed train step (fwd+bwd+AdamW), B=1, 1024^2 -> 2x512^2 passes, fp32 torch CPU, {dt:.1f} s")
     if model_kw is None and os.environ.get("VFMSEG_CPU_EXTRAS", "1") != "0":
         # the other CPU timings BASELINE.md section 3 lists (bounded samples): configs[0] = DINOv2-L + LinearHead, 1x512^2, forward + CE
         # in eval mode; and ONE of the nine 512^2 crops of the SAM-H 1024^2 sliding-window inference (configs[4])
@@ -302,6 +358,27 @@ def cpu_baseline(seconds_cap=40.0, model_kw=None):
             out["sam_crop_fwd"] = dict(seconds_per_crop=round(t_sam, 2), ms_per_1024_image_est=round(9e3 * t_sam, 0),
                                        sample="configs[4]: SAM-ViT-H + LinearHead, ONE 512^2 crop forward (a 1024^2 slide = 9 crops)")
     return out
+
+
+def _pin_this_rank():
+    """Started by torchrun (the driver's form) rather than by tools/dist_launch.py: this rank pins itself - before torch and the HIP
+    runtime start their threads - to the cores the launcher would have given it (tools/dist_launch.py:rank_cpus)."""
+    if "VFMSEG_RANK_CPUS" in os.environ or os.environ.get("VFMSEG_PIN_RANKS", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dist_launch", os.path.join(ROOT, "tools", "dist_launch.py"))
+    dl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dl)
+    lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    try:
+        cpus = dl.rank_cpus(lw)[lr]
+        os.sched_setaffinity(0, cpus)
+        os.environ["VFMSEG_RANK_CPUS"] = ",".join(str(c) for c in cpus)
+        if os.environ.get("OMP_NUM_THREADS", "1") == "1":    # torchrun's default of 1 starves the (few) CPU-side torch ops
+            os.environ["OMP_NUM_THREADS"] = str(max(1, min(8, len(cpus))))
+    except (OSError, IndexError):
+        pass
 
 
 def _reserve_stdout():
@@ -395,6 +472,9 @@ def main():
         dl = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(dl)
         sys.exit(dl.launch([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], a.gpus, timeout=a.launch_timeout))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        _pin_this_rank()
+        os.environ.setdefault("NCCL_DEBUG", "VERSION")   # RCCL's version banner (rank 0; lands on stderr: fd 1 is re-pointed below)
     real_stdout = _reserve_stdout()
     _heavy()
 
@@ -440,16 +520,41 @@ def main():
     barrier()
     print(f"[bench] rank {rank}: timing {a.steps} steps", file=sys.stderr, flush=True)
     timer.on = not a.no_roofline
+    gs = getattr(ow, "grad_sync", None)
+    if gs is not None and world > 1:
+        gs.measure = True          # event pair around the join of the all-reduce stream: what backward did NOT hide
+    host_s = 0.0
     t0 = time.perf_counter()
     for _ in range(a.steps):
+        h0 = time.perf_counter()
         model.train_step(data, ow)
+        host_s += time.perf_counter() - h0
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0      # this rank's own clock, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
     timer.on = False
+    ranks = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        # per-rank diagnostics for rank 0's line: a slow or host-bound rank, an exposed all-reduce and a bad core assignment show here
+        exposed = gs.exposed_ms() if gs is not None and hasattr(gs, "exposed_ms") else float("nan")
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except Exception:
+            ncpu = -1
+        mine = torch.tensor([1e3 * dt_own / a.steps, 1e3 * host_s / a.steps, exposed / max(a.steps, 1), float(ncpu)], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        cols = list(zip(*[x.tolist() for x in allr]))
+        ranks = {"ms_per_step": [round(v, 3) for v in cols[0]], "ms_per_step_min": round(min(cols[0]), 3), "ms_per_step_max": round(max(cols[0]), 3),
+                 "host_enqueue_ms_per_step": [round(v, 3) for v in cols[1]],
+                 "exposed_allreduce_ms_per_step": [round(v, 4) for v in cols[2]],
+                 "affinity_cores": [int(v) for v in cols[3]],
+                 "what": "per rank, own clock: step time before the closing barrier; host time spent inside train_step (enqueue); time the "
+                         "compute stream waited for the gradient all-reduce stream after backward (HIP events around GradSync.finish's join)"}
     ms_per_step = dt * 1000.0 / a.steps
     value = a.batch * world * a.steps / dt
 
@@ -462,6 +567,14 @@ def main():
                                "bs=%d/GPU, full train step (fwd+bwd+allreduce+AdamW), LoRA dropout on" % a.batch,
                    "global_batch": a.batch * world, "parallelism": "dp%d" % world},
     }
+    if ranks is not None:
+        out["ranks"] = ranks
+        try:
+            out["comm"] = {"backend": torch.distributed.get_backend(), "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                           "grad_bytes_per_step": int(ow.optimizer.gflat.numel() * 4), "buckets": len(gs.buckets) if gs is not None else 0,
+                           "NCCL_DEBUG": os.environ.get("NCCL_DEBUG")}
+        except Exception as e:   # noqa: BLE001
+            out["comm"] = {"error": repr(e)}
     if a.depth is not None and a.depth != 24:
         out["metric"] = "REHEARSAL at backbone depth %d (not the headline metric): " % a.depth + out["metric"]
         out["config"]["depth"] = a.depth
@@ -523,6 +636,11 @@ def main():
                 out["eval"] = eval_leg(device, timer if not a.no_roofline else None)
             except Exception as e:
                 out["eval"] = {"error": repr(e)}
+        if world == 1 and not a.no_eval and a.workload == "ms1024" and a.dtype == "bf16" and a.depth is None:
+            try:
+                out["other_backbones"] = other_backbones_leg(device, a.batch, timer if not a.no_roofline else None)
+            except Exception as e:
+                out["other_backbones"] = {"error": repr(e)}
         if world == 1 and not a.no_parity_mode and a.workload == "ms1024" and a.dtype == "bf16" and a.depth is None:
             try:
                 out["parity_mode"] = parity_leg(device, a.batch)

@@ -123,6 +123,34 @@ def test_rare_class_sampling(tmp_path):
     assert all(int((g["data_samples"].gt_sem_seg.data == 18).sum()) > 200 for g in rare)   # min_pixels * min_crop_ratio, full-size crop
 
 
+def test_rare_class_sampling_matches_reference_golden(tmp_path, golden_dir):
+    """tests/golden/rcs.npz was written by the REFERENCE's own DGDataset / get_rcs_class_probs (rein/datasets/uda_dataset.py:16-37, 44-103,
+    imported by path: oracle/gen_golden.py --only rcs) on the toy source of tests/rcs_toy.py.  The sampling is host code whose np.random
+    call order IS the contract: class order, probabilities, the per-class file lists, the first 32 draws under np.random.seed(0), every
+    source access of the re-draw loop, and the position of the global RNG stream afterwards must all be reproduced exactly."""
+    import rcs_toy
+    G = np.load(os.path.join(golden_dir, "rcs.npz"))
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "labels"))
+    rcs_toy.write_stats(root, rcs_toy.label_maps())
+    classes, probs = D.get_rcs_class_probs(root, rcs_toy.RCS["class_temp"])
+    assert classes == G["classes"].tolist()
+    assert np.array_equal(np.asarray(probs, dtype=np.float64), G["classprob"]), "softmax((1 - freq) / T) in torch fp32, as the reference computes it"
+    ds = D.DGDataset(rcs_toy.ToySource(data_root=root), rare_class_sampling=dict(rcs_toy.RCS))
+    for c in classes:
+        assert [int(f.split("_")[0]) for f in ds.samples_with_class[c]] == G[f"files_{c}"].tolist()
+    np.random.seed(0)
+    draws, ncalls = [], []
+    for _ in range(32):
+        n0 = len(ds.source.calls)
+        smp = ds[0]
+        draws.append((smp["index"],) + tuple(smp["offset"]))
+        ncalls.append(len(ds.source.calls) - n0)
+    assert np.array_equal(np.array(draws), G["draws"]) and ncalls == G["ncalls"].tolist() and max(ncalls) == 11   # 1 + ten re-draws
+    assert np.array_equal(np.array(ds.source.calls), G["calls"])
+    assert np.array_equal(np.random.randint(0, 1 << 30, size=4), G["rng_after"])
+
+
 def test_infinite_sampler_shards_one_stream(tmp_path):
     a = D.InfiniteSampler(7, True, seed=3, rank=0, world=2)
     b = D.InfiniteSampler(7, True, seed=3, rank=1, world=2)
@@ -183,6 +211,9 @@ def test_sampler_fast_forward_continues_the_index_stream(tmp_path):
     s2.skip = 8
     it2 = iter(s2)
     assert [next(it2) for _ in range(4)] == head[8:]
+    # the skip is spent once: an iterator made later (a re-created DataLoader iterator, persistent workers) starts a stream that is not
+    # shifted a second time (round-3 advisor finding)
+    assert s2.skip == 0 and [next(iter(s2)) for _ in range(1)] == head[:1]
 
 
 def test_transforms_match_independent_implementations(golden_dir):

@@ -171,6 +171,39 @@ def test_ms_inference_bf16_vs_reference_golden(golden_dir, prec, ltol, ftol):
     assert frac < ftol and worst < ltol and drift < ftol
 
 
+@pytest.mark.parametrize("prec,ltol,ftol", [("f32", 1e-3, 2e-4), ("bf16", 4e-2, 1.5e-2)])
+def test_sam_slide_full_depth_vs_reference_golden(golden_dir, prec, ltol, ftol):
+    """BASELINE configs[4] WHOLE - what bench.py's sam_h_slide leg times: SAM-ViT-H at depth 32 + LoRA + LinearHead, `slide` (3 x 3 windows
+    of 512^2, stride 320) on a 1024^2 image, against the reference-made golden (sam_slide.npz; sam_vit.py:127-148, lora_sam_linear.py:50-54).
+    f32 claims north_star's tolerance; bf16 (the timed mode) is measured and bounded, every flipped pixel a near-tie."""
+    from tests.helpers import sam_state_dict
+    from vfmseg_amd.synth import synth_state_dict
+    import vfmseg_amd.sam  # noqa: F401
+    G = np.load(os.path.join(golden_dir, "sam_slide.npz"))
+    set_compute_dtype(prec)
+    try:
+        model = MODELS.build(presets.sam_linear())
+        sd = sam_state_dict()
+        head = {k: tuple(v.shape) if v.dtype != torch.int64 else ((), torch.int64) for k, v in model.state_dict().items() if k.startswith("decode_head.")}
+        sd.update(synth_state_dict(head))
+        model.load_state_dict(sd, strict=False)
+        model = model.cuda().eval()
+        with torch.no_grad():
+            out = model.predict(synth_image(1, 1024, seed=47).cuda())
+        logits = out[0].seg_logits.data.float().cpu()
+        e_slice = rel_err(sl(logits.unsqueeze(0)), G["logits_slice"])
+        e_sub = rel_err(logits[:, ::16, ::16], G["logits_sub16"])
+        pred = out[0].pred_sem_seg.data[0].cpu()
+        frac, worst = _margin_report(logits[:, ::4, ::4], pred[::4, ::4].long(), torch.from_numpy(G["pred_sub4"].astype(np.int64)))
+        hist = np.bincount(pred.numpy().reshape(-1), minlength=19)
+        drift = np.abs(hist - G["pred_hist"]).sum() / hist.sum()
+    finally:
+        set_compute_dtype("bf16")
+    print(f"[sam slide depth 32 {prec}] logits rel err slice {e_slice:.2e} every-16th-pixel {e_sub:.2e}; argmax mismatch {frac:.2e}, "
+          f"largest relative top-2 margin among them {worst:.2e}; class-histogram drift {drift:.2e}")
+    assert e_slice < ltol and e_sub < ltol and frac < ftol and worst < ltol and drift < max(ftol, 1e-3)
+
+
 def test_sam_slide_inference_bf16_vs_oracle():
     """BASELINE config 5 semantics in the timed dtype: SAM-H widths, depth 8, `slide` 3x3 windows, bf16 vs the fp32 oracle."""
     from tests.helpers import sam_state_dict

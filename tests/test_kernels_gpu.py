@@ -455,6 +455,28 @@ def test_gemm_split_bf16x3(M, N, K, ta, tb):
     assert e3 < 3e-5 and e3 < e1 / 50
 
 
+def test_bf16x3_weight_cache_follows_in_place_weight_edits():
+    """bf16x3 mode: functional.linear packs its weights into a persistent buffer and ops.split3 caches the split image ON that buffer.
+    An in-place edit of the parameter (load_state_dict, p.copy_, a non-fused optimiser) re-packs the buffer behind torch's version
+    counter; the split image must be rebuilt then (round-3 advisor finding: it was not)."""
+    from vfmseg_amd import functional as Fh
+    from vfmseg_amd.precision import set_compute_dtype
+    x = rnd(130, 256, seed=90).to(DEV)
+    w = torch.nn.Parameter(rnd(64, 256, seed=91).to(DEV), requires_grad=False)
+    w2 = rnd(64, 256, seed=92).to(DEV)
+    set_compute_dtype("bf16x3")
+    try:
+        y0 = Fh.linear(x, w, "linear", out_dtype=torch.float32)
+        assert relerr(y0, x.double() @ w.double().t()) < 1e-4
+        with torch.no_grad():
+            w.copy_(w2)
+        y1 = Fh.linear(x, w, "linear", out_dtype=torch.float32)
+        assert relerr(y1, x.double() @ w2.double().t()) < 1e-4
+    finally:
+        set_compute_dtype("bf16")
+
+
+
 @pytest.mark.parametrize("cfg", [37, 38])
 @pytest.mark.parametrize("M,N,K", [(4100, 4096, 1024), (512, 256, 640), (1024, 2048, 1088), (256, 256, 4096), (4356, 768, 576)])
 def test_gemm_bf16_persistent_two_accumulators(cfg, M, N, K):

@@ -132,6 +132,16 @@ def test_amp_optim_wrapper_follows_gradscaler():
     assert ow2.scale == 65536.0
     ow2.load_state_dict(sd)
     assert ow2.scale == 1024.0 and ow2.iter == 5
+    # in-process resume (Runner.resume: optimizer.load_state_dict, then the wrapper's): a wrapper that has already trained holds a
+    # device-side state with ITS step count; loading must not read that back over the count the optimiser has just restored
+    ow._state, ow._stale = torch.tensor([4096.0, 2.0, 777.0, 9.0]), True
+    opt.step_count = 5
+    ow.load_state_dict(sd)
+    assert opt.step_count == 5 and ow.scale == 1024.0 and ow.growth_tracker == 0 and ow._state is None
+    # FusedAdamW.state_dict() goes through the wrapper's sync (the stub borrows the hook the wrapper installs on its optimiser)
+    ow._state, ow._stale = torch.tensor([1024.0, 0.0, 6.0, 1.0]), True
+    opt._amp_sync()
+    assert opt.step_count == 6
     fixed = AmpOptimWrapper(_StubOpt(), None, None, loss_scale=128.0)
     fixed.update_params(_Loss(fixed.optimizer, bad))
     assert fixed.scale == 128.0 and fixed.skipped == 1   # a static scale never moves

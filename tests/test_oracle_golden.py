@@ -216,6 +216,33 @@ def test_sam_taps_and_lora_grads(golden_dir):
             assert rel_err(sl(grads[k]), G[name]) < 2e-3, k
 
 
+@pytest.mark.slow
+def test_sam_slide_full_depth(golden_dir):
+    """BASELINE configs[4] whole (SAM-ViT-H depth 32 + LoRA + LinearHead, `slide` 3 x 3 windows on a 1024^2 image): the oracle against the
+    reference's own SAMViT / LoRABackbone / LinearHead run under the restated EncoderDecoder.slide_inference (sam_slide.npz,
+    oracle.gen_golden --only sam_slide; sam_vit.py:127-148, configs/_base_/models/lora_sam_linear.py:50-54)."""
+    from tests.helpers import sam_state_dict
+    from vfmseg_amd import presets
+    from vfmseg_amd.registry import MODELS
+    from vfmseg_amd.synth import synth_state_dict
+    import vfmseg_amd.sam  # noqa: F401
+    G = _g(golden_dir, "sam_slide.npz")
+    sd = sam_state_dict()
+    model = MODELS.build(presets.sam_linear())
+    head = {k: tuple(v.shape) if v.dtype != torch.int64 else ((), torch.int64) for k, v in model.state_dict().items() if k.startswith("decode_head.")}
+    del model
+    sd.update(synth_state_dict(head))
+    stride, crop = tuple(int(v) for v in G["test_cfg_stride_crop"][:2]), tuple(int(v) for v in G["test_cfg_stride_crop"][2:])
+    with torch.no_grad():
+        lg = R.slide_inference(sd, synth_image(1, 1024, seed=47), crop, stride, backbone="sam")
+    assert rel_err(sl(lg), G["logits_slice"]) < 1e-4 and rel_err(lg[0, :, 500:504, 636:644], G["logits_center"]) < 1e-4
+    assert rel_err(lg[0, :, ::16, ::16], G["logits_sub16"]) < 1e-4
+    np.testing.assert_allclose(stats(lg), G["logits_stats"], rtol=1e-4)
+    pred = lg.argmax(dim=1)[0].numpy().astype(np.uint8)
+    assert (pred[::4, ::4] != G["pred_sub4"]).mean() < 2e-4
+    assert np.abs(np.bincount(pred.reshape(-1), minlength=19) - G["pred_hist"]).sum() < 200
+
+
 def test_optimizer_rules():
     ck = {"norm": dict(decay_mult=0.0), "query_embed": dict(lr_mult=1.0, decay_mult=0.0)}
     assert R.param_group_options("aux_decoder.transformer_decoder.norm.weight", True, custom_keys=ck) == (1e-4, 0.0)

@@ -1,7 +1,9 @@
 """The wide, store-heavy GEMMs of the train step as the step sees them: the fc1 forward (GELU + gelu' outputs: 67 MB of stores), the fc2
 input gradient (multiply by the saved gelu': 34 MB read + 34 MB written) and the qkv projection, each launch on a DIFFERENT set of
 buffers (24 sets, as 24 layers: weights and activations are not L2-warm from the previous launch), configs interleaved in one
-process on random data (cdna_hip_programming.md 5.4 rules 24 / 25).  CFGS=34,33,37 python tools/bench_gemm_step.py"""
+process on random data (cdna_hip_programming.md 5.4 rules 24 / 25).  CFGS=34,33,37 python tools/bench_gemm_step.py
+A CFGS entry "torch" is the vendor yardstick under the same conditions: torch.matmul (hipBLASLt) on the same 24 cold buffer sets, plain
+bf16 product with NO epilogue (no bias / GELU / second output) - a measuring stick only, never a dependency of the product."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,6 +19,11 @@ CASES = [  # (label, M, N, K, kind)
     ("eval fc1 gelu", 9225, 4096, 1024, "gelu"),
     ("N1024 K4096 bias", 4096, 1024, 4096, "bias"),
     ("N1024 K1024 bias", 4096, 1024, 1024, "bias"),
+    ("qkv dgrad", 4100, 1088, 3072, "bias"),
+    ("proj fwd res", 4100, 1024, 1024, "res"),
+    ("fc2 fwd res", 4100, 1024, 4096, "res"),
+    ("plain 4096x4096x1024", 4096, 4096, 1024, "plain"),
+    ("plain 4096^3", 4096, 4096, 4096, "plain"),
 ]
 EVAL_CASES = [  # SHAPES=eval: the GEMMs of one 1024^2 prediction (DINOv2-L ms_slide: nine 512^2 windows in one batch, then the 512 x 1024 LR pass; SAM-H slide)
     ("HR qkv", 9225, 3072, 1024, "bias"), ("HR proj", 9225, 1024, 1024, "bias"), ("HR fc1 gelu", 9225, 4096, 1024, "gelu"), ("HR fc2", 9225, 1024, 4096, "bias"),
@@ -41,7 +48,8 @@ def main():
             a = torch.randn(M, K, device=dev).bfloat16()
             b = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
             sets.append(dict(a=a, b=b, c=torch.empty(M, N, dtype=torch.bfloat16, device=dev), c2=torch.empty(M, N, dtype=torch.bfloat16, device=dev),
-                             aux=torch.randn(M, N, device=dev).bfloat16(), bias=torch.randn(N, device=dev)))
+                             aux=torch.randn(M, N, device=dev).bfloat16(), bias=torch.randn(N, device=dev), bt=b.t(),
+                             cf=torch.randn(M, N, device=dev) if kind == "res" else None))
 
         def run(s):
             if kind == "gelu_dgelu":
@@ -50,13 +58,32 @@ def main():
                 ops.gemm(s["a"], s["b"], s["c"], ep_mode=ops.EP_MUL, aux=s["aux"])
             elif kind == "gelu":
                 ops.gemm(s["a"], s["b"], s["c"], bias=s["bias"], ep_mode=ops.EP_GELU)
+            elif kind == "res":   # fp32 residual stream: out = res + ls * (a b^T + bias), as proj / fc2 forward
+                ops.gemm(s["a"], s["b"], s["cf"], bias=s["bias"], residual=s["cf"])
+            elif kind == "plain":
+                ops.gemm(s["a"], s["b"], s["c"])
             else:
                 ops.gemm(s["a"], s["b"], s["c"], bias=s["bias"])
+
+        def run_vendor(s):
+            torch.matmul(s["a"], s["bt"], out=s["c"])
 
         fl = 2.0 * M * N * K
         times = {c: [] for c in cfgs}
         for r in range(rounds + 1):
             for cfg in cfgs:
+                if cfg == "torch":
+                    run_vendor(sets[0])
+                    torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for s in sets:
+                        run_vendor(s)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if r > 0:
+                        times[cfg].append(e0.elapsed_time(e1) / NSET * 1e3)
+                    continue
                 ops.tune("gemm_cfg", int(cfg.split(":")[0]))
                 dbg = cfg.split(":")[1] if ":" in cfg else "0"
                 ops.tune("pp_dbg", int(dbg.rstrip("b")))

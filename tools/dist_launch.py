@@ -26,13 +26,72 @@ def free_port():
     return p
 
 
-def rank_env(rank, world, port, base=None, addr="127.0.0.1"):
+def _parse_cpulist(txt):
+    out = set()
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.update(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_local_cpus():
+    """Per GPU (PCI bus order, which is the order HIP numbers devices in when HIP_VISIBLE_DEVICES is unset): the set of host CPUs on
+    the GPU's NUMA node, from /sys/class/drm/card*/device/local_cpulist.  [] when sysfs does not say (no GPU, a container)."""
+    import glob
+    cards = []
+    for d in glob.glob("/sys/class/drm/card[0-9]*/device"):
+        try:
+            if open(os.path.join(d, "vendor")).read().strip() != "0x1002":   # AMD
+                continue
+            cpus = _parse_cpulist(open(os.path.join(d, "local_cpulist")).read())
+            cards.append((os.path.basename(os.path.realpath(d)), cpus))
+        except (OSError, ValueError):
+            continue
+    cards.sort()
+    return [c for _, c in cards]
+
+
+def rank_cpus(world, allowed=None, gpu_cpus=None):
+    """CPU set of every local rank: disjoint, each near its GPU.  A train step enqueues several hundred launches from ONE Python thread
+    per rank; two ranks time-sharing a core (or a rank migrating across NUMA nodes) makes that rank host-bound, and data-parallel
+    training runs at the pace of the slowest rank.  Ranks whose GPUs share a NUMA node split that node's allowed cores evenly; without
+    topology information (or when a node has fewer cores than ranks) the allowed cores are split evenly in order."""
+    allowed = sorted(os.sched_getaffinity(0) if allowed is None else allowed)
+    gpu_cpus = gpu_local_cpus() if gpu_cpus is None else gpu_cpus
+    out = [None] * world
+    if len(gpu_cpus) >= world:
+        groups = {}
+        for r in range(world):
+            groups.setdefault(frozenset(gpu_cpus[r]), []).append(r)
+        ok = True
+        for node, ranks in groups.items():
+            cores = [c for c in allowed if c in node]
+            per = len(cores) // len(ranks)
+            if per < 1:
+                ok = False
+                break
+            for i, r in enumerate(ranks):
+                out[r] = cores[i * per:(i + 1) * per]
+        if ok:
+            return out
+    per = len(allowed) // world
+    if per < 1:       # more ranks than cores: no pinning (sharing cannot be avoided, let the scheduler balance)
+        return [list(allowed) for _ in range(world)]
+    return [allowed[r * per:(r + 1) * per] for r in range(world)]
+
+
+def rank_env(rank, world, port, base=None, addr="127.0.0.1", cpus=None):
     env = dict(os.environ if base is None else base)
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                MASTER_ADDR=addr, MASTER_PORT=str(port))
+    ncpu = len(cpus) if cpus else max(1, (os.cpu_count() or 8) // max(world, 1))
     # one Python thread drives each GPU; a wide OpenMP pool per rank only fights the other ranks for the host cores
-    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or 8) // max(world, 1)))))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, ncpu))))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: the only form this image's driver supports (RCCL needs it)
+    if cpus:
+        env["VFMSEG_RANK_CPUS"] = ",".join(str(c) for c in cpus)   # (for the rank's own diagnostics; the mask itself is set before exec)
     return env
 
 
@@ -44,8 +103,14 @@ def launch(cmd, world, port=None, relay_stdout=None, timeout=None):
     port = port or int(os.environ.get("MASTER_PORT", 0)) or free_port()
     out = relay_stdout or sys.stdout
     procs = []
+    pin = os.environ.get("VFMSEG_PIN_RANKS", "1") != "0" and world > 1 and hasattr(os, "sched_setaffinity")
+    cpus = rank_cpus(world) if pin else [None] * world
     for r in range(world):
-        procs.append(subprocess.Popen(cmd, env=rank_env(r, world, port), stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1))
+        # the affinity mask is set in the child between fork and exec: before the interpreter, torch and the HIP runtime start
+        # their threads, which inherit it
+        pre = (lambda c=cpus[r]: os.sched_setaffinity(0, c)) if cpus[r] else None
+        procs.append(subprocess.Popen(cmd, env=rank_env(r, world, port, cpus=cpus[r]), stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1,
+                                      preexec_fn=pre))
 
     def pump(r, p):
         for line in p.stdout:

@@ -35,6 +35,11 @@ def main():
     a = ap.parse_args()
     if "LOCAL_RANK" not in os.environ:
         os.environ["LOCAL_RANK"] = str(a.local_rank)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # Evaluation here is one process (a 1024^2 prediction takes 15 ms): there is no sharded test loop and no reduction of the
+        # confusion matrix, so several ranks would each score the whole test set on the default device and print their own result.
+        raise SystemExit("tools/test.py: distributed evaluation (--launcher %s with WORLD_SIZE=%s) is not implemented; run ONE process "
+                         "(python tools/test.py CONFIG CHECKPOINT)" % (a.launcher, os.environ["WORLD_SIZE"]))
     import numpy as np
     import torch
     import vfmseg_amd  # noqa: F401
@@ -55,6 +60,7 @@ def main():
     if a.backbone:
         sd.update({"backbone." + k: v for k, v in torch.load(a.backbone, map_location="cpu").items()})
     model.load_state_dict(sd, strict=False)
+    torch.cuda.set_device(int(os.environ["LOCAL_RANK"]) % max(torch.cuda.device_count(), 1))
     model = model.cuda().eval()
     tta = None
     if a.tta:   # tools/test.py:131-134 swaps in cfg.tta_pipeline / cfg.tta_model (mmseg SegTTAModel: mean of the views' softmax)

@@ -369,6 +369,7 @@ extern "C" int vfm_tune(const char* key, int value) {
     return VFM_OK;
   }
   if (key && strcmp(key, "gemm_deep_sep_k") == 0) {
+    if (value < 0) return VFM_E_INVAL;   // (a negative value used to mean "skip the tail rows": a timing diagnostic with wrong results)
     g_deep_sep_k = value;
     return VFM_OK;
   }
@@ -552,12 +553,9 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
     // latency), so the deeper ring wins more than the tail blocks lose by waiting for a CU (they cannot share the ring's LDS)
     if (cfg == 34 && tail && t128 <= 256 && d->M % 128 == 0 && d->K >= g_deep_tail_k && g_deep_tail_k > 0) cfg = 35;
     // ... or with the tail rows in a launch of their own behind this one (they cannot share a CU with the deep ring's LDS)
-    if (cfg == 34 && tail && t128 <= 256 && d->M % 128 == 0 && d->K >= 256 && g_deep_sep_k != 0 && d->K >= (g_deep_sep_k < 0 ? -g_deep_sep_k : g_deep_sep_k)) {
-      cfg = 35;
-      tail = nullptr;
-      if (folded) *folded = g_deep_sep_k < 0;   // (negative: timing diagnostic - the tail rows are simply not computed)
-      const bool ok = vfm_gemm_launch_w4(d, s, vec, nullptr, 3);
-      (void)ok;
+    if (cfg == 34 && tail && t128 <= 256 && d->M % 128 == 0 && d->K >= 256 && g_deep_sep_k > 0 && d->K >= g_deep_sep_k) {
+      if (folded) *folded = false;   // the caller runs the skinny kernel for the tail rows
+      vfm_gemm_launch_w4(d, s, vec, nullptr, 3);
       return VFM_OK;
     }
   }

@@ -397,7 +397,10 @@ class InfiniteSampler:
         g = torch.Generator()
         g.manual_seed(self.seed)
         k = 0
-        skip = self.skip     # resume: this rank's first `skip` indices were consumed before the checkpoint
+        # resume: this rank's first `skip` indices were consumed before the checkpoint.  The skip is spent by the FIRST iterator made
+        # after fast_forward (DataLoaderIter re-creates its iterator; persistent workers iterate again): a later iterator continues
+        # a stream that is already in step with the uninterrupted run and must not skip again.
+        skip, self.skip = self.skip, 0
         while True:
             idx = torch.randperm(self.size, generator=g).tolist() if self.shuffle else list(range(self.size))
             for i in idx:

@@ -154,6 +154,9 @@ class _PackCache:
                     r0 += d[0]
         for key, e in self.entries.items():
             e["stamp"] = self._stamp([r() for r in e["refs"]])
+            # the re-pack rewrote wp behind torch's version counter: a split-bf16 image cached on it (ops.split3) is stale
+            if hasattr(e["wp"], "_vfm_split3"):
+                del e["wp"]._vfm_split3
 
 
 class _PackCaches:

@@ -154,6 +154,9 @@ class FusedAdamW:
                 p.grad = self.gflat[a:a + sz].view(p.shape)
 
     def state_dict(self):
+        sync = getattr(self, "_amp_sync", None)
+        if sync is not None:   # under AmpOptimWrapper on the GPU the step count lives in the device-side scaler state
+            sync()
         return dict(step=self.step_count, m=self.m, v=self.v, names=self.names)
 
     def load_state_dict(self, sd):
@@ -222,6 +225,7 @@ class AmpOptimWrapper(OptimWrapper):
         self.mode = "fp16" if self.dtype == torch.float16 else "bf16"
         self._tracker, self._skipped = 0, 0
         self._state, self._stale = None, False   # device-side scaler state (built at the first GPU update_params)
+        optimizer._amp_sync = self.sync          # FusedAdamW.state_dict() reads the device-side step count back through this
         self.growth_factor, self.backoff_factor, self.growth_interval = 2.0, 0.5, 2000
         self.dynamic = True
         if loss_scale == "dynamic":
@@ -339,11 +343,14 @@ class AmpOptimWrapper(OptimWrapper):
                                                      growth_interval=self.growth_interval, _growth_tracker=self.growth_tracker))
 
     def load_state_dict(self, sd):
+        # The device-side state of THIS process is dropped first, un-read: reading it back here (the `scale` / `growth_tracker`
+        # setters do) would write the old run's step count over the one Runner.resume has just restored into the optimiser.
+        self._push()
         super().load_state_dict(sd)
         ls = sd.get("loss_scaler")
         if ls:
-            self.scale, self.growth_tracker = float(ls["scale"]), int(ls.get("_growth_tracker", 0))
-        self._push()   # (the optimiser's step count may have been reloaded too: the device state is rebuilt from the host copies)
+            self._scale, self._tracker = float(ls["scale"]), int(ls.get("_growth_tracker", 0))
+        # (the device state is rebuilt from the host copies - scale, tracker, optimizer.step_count - at the next update_params)
 
 
 @OPTIM_WRAPPER_CONSTRUCTORS.register_module()

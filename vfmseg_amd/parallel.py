@@ -99,6 +99,8 @@ class GradSync:
         self.done = [False] * len(buckets)
         self.works = []
         self.post_scale = (1.0 / self.world) if self.cuda else 1.0  # consumed by OptimWrapper -> vfm_adamw grad_scale
+        self.measure = False      # bench.py --gpus N: HIP events around the join in finish() (the all-reduce time backward did not hide)
+        self._pairs = []
 
     def ready(self, i):
         if not self.active or self.done[i]:
@@ -118,7 +120,15 @@ class GradSync:
             self.ready(i)
         if self.active:
             if self.cuda:
-                torch.cuda.current_stream().wait_stream(self.stream)
+                cur = torch.cuda.current_stream()
+                if self.measure:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(cur)
+                    cur.wait_stream(self.stream)
+                    e1.record(cur)
+                    self._pairs.append((e0, e1))
+                else:
+                    cur.wait_stream(self.stream)
             else:
                 for w in self.works:
                     w.wait()
@@ -127,6 +137,12 @@ class GradSync:
         self.done = [False] * len(self.buckets)
 
     __call__ = finish
+
+    def exposed_ms(self):
+        """Sum over the measured steps of the time the compute stream stood at the join (call after a device synchronize)."""
+        ms = sum(a.elapsed_time(b) for a, b in self._pairs)
+        self._pairs = []
+        return ms
 
 
 def bn_sync_fn(group=None):
