@@ -76,10 +76,11 @@ class KernelTimer:
     the step time; a prime period cycles through every launch site over the steps).  Sums are kept per (kind, region)."""
 
     def __init__(self, every=31):
-        self.recs = []
+        self._c_every = None
+        self.recs, self.plan_recs = [], []
+        self.every = every
         self.on = False
         self.calls = 0
-        self.every = every
 
     def install(self):
         from vfmseg_amd import ops
@@ -100,21 +101,50 @@ class KernelTimer:
             return fin
 
         ops.PROFILE = hook
+        self.plan_recs = []
+        self._c_every = -1
 
     def uninstall(self):
         from vfmseg_amd import ops
         ops.PROFILE = None
+        ops.prof_config(0)
 
     def reset(self):
         self.recs, self.calls = [], 0
+        self._pull()
+        self.plan_recs = []
+
+    def _sync_c(self):
+        """The launches a launch plan issues from C (the backbone of the train step: vfm_run_plan) are sampled by the library's own
+        event sampler at the same period; it follows `on`."""
+        from vfmseg_amd import ops
+        want = self.every if self.on else 0
+        if want != self._c_every:
+            ops.prof_config(want)
+            self._c_every = want
+
+    def _pull(self):
+        from vfmseg_amd import ops
+        try:
+            self.plan_recs += [(k, "backbone", fl, ms) for k, fl, ms in ops.prof_read()]
+        except Exception:   # noqa: BLE001  (library not loaded yet)
+            pass
+
+    def __setattr__(self, k, v):
+        object.__setattr__(self, k, v)
+        if k == "on" and getattr(self, "_c_every", None) is not None:
+            self._sync_c()
 
     def summary(self, kinds=None, region=None, min_flops=0.0):
-        sel = [r for r in self.recs if (kinds is None or r[0] in kinds) and (region is None or r[1] == region) and r[2] >= min_flops]
-        if not sel:
+        self._pull()
+        ok = lambda r: (kinds is None or r[0] in kinds) and (region is None or r[1] == region) and r[2] >= min_flops   # noqa: E731
+        sel = [r for r in self.recs if ok(r)]
+        selc = [r for r in self.plan_recs if ok(r)]
+        if not sel and not selc:
             return None
-        fl = sum(r[2] for r in sel)
-        ms = sum(r[3].elapsed_time(r[4]) for r in sel)
-        return dict(flops=fl, ms=ms, launches=len(sel), tflops=fl / (ms * 1e-3) / 1e12)
+        fl = sum(r[2] for r in sel) + sum(r[2] for r in selc)
+        ms = sum(r[3].elapsed_time(r[4]) for r in sel) + sum(r[3] for r in selc)
+        return dict(flops=fl, ms=ms, launches=len(sel) + len(selc), tflops=fl / (ms * 1e-3) / 1e12)
 
 
 # forward FLOPs of the eval workloads (SURVEY 8d arithmetic): DINOv2-L 512^2 pass 722.4 G; the coarse 512x1024 pass has N = 2049

@@ -369,6 +369,44 @@ int vfm_adamw_guarded(float* p, float* g, float* m, float* v, long n, const long
                       int zero_grad, int vec4, const int* skip, const float* amp_state, void* stream);
 int vfm_amp_update(const int* flag, float* amp_state, float growth, float backoff, int interval, int dynamic, void* stream);
 
+/* ---- launch plans -------------------------------------------------------------------------------------- */
+/* A recorded sequence of the calls above, replayed in order on one stream by ONE call.  The hot path's backbone is a fixed launch
+ * sequence per step (18 launches per transformer block: rein/models/backbones/dino_v2.py:259-291 forward_features and its backward) over
+ * buffers whose addresses do not change between steps; issuing it from C costs ~3 us of host time per launch where the Python binding
+ * pays ~14 us - with eight ranks of a node each enqueuing ~800 launches per step, host time is what a data-parallel step waits for
+ * (configs/_base_/default_runtime.py:5, tools/dist_train.sh:9-17).  This is a host-side replay, not a graph capture: every launch goes
+ * through the same entry point with the same arguments as when it is issued one by one, so results are bit-identical.
+ * Per-replay scalars: `seed` and `rng_base` feed the dropout of VFM_OP_LN_DROPOUT_FWD entries (their `offset` is relative to rng_base).
+ * prof_kind / flops: the class and algorithmic FLOPs the profiling sampler (below) files the launch under (0 = not sampled). */
+enum { VFM_OP_GEMM = 0, VFM_OP_LN_FWD = 1, VFM_OP_LN_DROPOUT_FWD = 2, VFM_OP_LN_BWD_SCALED = 3, VFM_OP_ATTN_FWD = 4, VFM_OP_ATTN_BWD = 5,
+       VFM_OP_CAST = 6, VFM_OP_STRIDED_COPY = 7 };
+enum { VFM_PROF_NONE = 0, VFM_PROF_GEMM = 1, VFM_PROF_GEMM_TN = 2, VFM_PROF_ATTN_FWD = 3, VFM_PROF_ATTN_BWD = 4 };
+typedef struct vfm_plan_op {
+  int kind;
+  int prof_kind;
+  double flops;
+  union {
+    vfm_gemm_desc gemm;                                             /* vfm_gemm */
+    vfm_attn_desc attn;                                             /* vfm_attn_fwd / vfm_attn_bwd */
+    struct { const float* x; long ld_x; const float* w; const float* b; float eps; void* y; int y_dt; long ld_y; float* stats;
+             long rows, C; } ln_fwd;                                /* vfm_layernorm_fwd */
+    struct { const float* x; long ld_x; const float* w; const float* b; float eps; void* y; long ld_y; float* stats; void* y_drop;
+             long ld_yd; void* mask; long ld_mask; float p; uint64_t offset; long rows, C; } ln_drop;   /* vfm_layernorm_dropout_fwd */
+    struct { const void* dy; int dy_dt; long ld_dy; const float* x; long ld_x; const float* w; const float* stats; float* dx;
+             long ld_dx; int accumulate_dx; void* t_out; long ld_t; const float* t_scale; long rows, C; } ln_bwd;   /* vfm_layernorm_bwd_scaled */
+    struct { const void* src; int src_dt; long ld_src; void* dst; int dst_dt; long ld_dst; long rows, cols; const float* colscale; } cast;
+    struct { const void* src; int src_dt; void* dst; int dst_dt; long n[4]; long ss[4]; long ds[4]; int accumulate; } copy;   /* vfm_strided_copy */
+  } u;
+} vfm_plan_op;
+/* Runs ops[0..n) in order; stops at the first failing entry and returns its code (vfm_last_error names the index). */
+int vfm_run_plan(const vfm_plan_op* ops, int n, uint64_t seed, uint64_t rng_base, void* stream);
+/* Profiling sampler for launches issued by vfm_run_plan (the measurement hook bench.py uses for the `roofline` block: HIP events on the
+ * stream the kernels are launched on).  every > 0: each every-th entry with prof_kind != 0 is bracketed by an event pair; 0 = off.
+ * vfm_prof_read waits for the recorded events and writes up to `cap` records {prof_kind, flops, milliseconds} as three doubles each;
+ * returns the number of records (negative on error) and clears them. */
+int vfm_prof_config(int every);
+int vfm_prof_read(double* out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

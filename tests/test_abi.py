@@ -49,6 +49,27 @@ def test_python_binding_matches_header():
         assert n == len(args), (name, n, len(args))
 
 
+def test_plan_op_layout_matches_the_header(tmp_path):
+    """vfm_plan_op (launch plans) is a tagged union the Python side fills field by field: its ctypes mirror must have the C layout.
+    A C program compiled against the header prints sizeof / offsetof; no GPU needed."""
+    import subprocess
+    from vfmseg_amd import lib as L
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "vfmseg_hip.h"\nint main(void) {\n'
+                   'printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vfm_plan_op), offsetof(vfm_plan_op, flops), offsetof(vfm_plan_op, u), '
+                   'sizeof(vfm_gemm_desc), sizeof(vfm_attn_desc), offsetof(vfm_plan_op, u.ln_drop.offset), offsetof(vfm_plan_op, u.ln_drop.rows), '
+                   'offsetof(vfm_plan_op, u.ln_bwd.t_scale), offsetof(vfm_plan_op, u.cast.colscale), offsetof(vfm_plan_op, u.copy.ds), '
+                   'offsetof(vfm_plan_op, u.copy.accumulate), offsetof(vfm_plan_op, u.ln_fwd.stats));\nreturn 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    P, U = L.PlanOp, L.PlanOp.u.offset
+    want = [ctypes.sizeof(P), P.flops.offset, U, ctypes.sizeof(L.GemmDesc), ctypes.sizeof(L.AttnDesc), U + L._LnDrop.offset.offset,
+            U + L._LnDrop.rows.offset, U + L._LnBwd.t_scale.offset, U + L._CastOp.colscale.offset, U + L._CopyOp.ds.offset,
+            U + L._CopyOp.accumulate.offset, U + L._LnFwd.stats.offset]
+    assert got == want, (got, want)
+
+
 def test_ops_refuse_cpu_tensors():
     import torch
     from vfmseg_amd import lib as L, ops

@@ -315,6 +315,55 @@ def test_lora_dropout_masks_differ_between_steps():
     assert torch.equal(c, d)
 
 
+@pytest.mark.parametrize("skip_l0", ["0", "1"])
+def test_launch_plan_equals_one_by_one_path(skip_l0):
+    """The backbone's train-step launch sequence replayed by vfm_run_plan (one C call per pass over persistent buffers:
+    backbones._DinoTrainPlan) against the same sequence issued launch by launch from Python (VFMSEG_PLAN=0): the feature taps are
+    bit-identical (same kernels, arguments and order; no atomics in the forward), the LoRA gradients agree to the run-to-run noise of
+    the backward's fp32 atomics.  skip_l0 = 1 also drops the work of block 0 that feeds nothing trainable (only dT of its qkv input
+    gradient is computed): the gradients must not notice.  Two steps, so that a replay on re-used buffers is covered."""
+    from vfmseg_amd.optim import PEFTOptimWrapperConstructor
+    set_compute_dtype("bf16")
+    depth = 4
+    cfg = presets.dinov2_ms_masked(depth=depth)
+    cfg["backbone"]["backbone"]["out_indices"] = [0, 1, 2, 3]
+    model = MODELS.build(cfg)
+    model.load_state_dict(full_state_dict(depth=depth))
+    model = model.cuda().train()
+    oc = presets.optim_cfg()
+    ow = PEFTOptimWrapperConstructor(oc["optim_wrapper"])(model, None)
+    opt = ow.optimizer
+    imgs = [synth_image(2, 512, seed=81 + i).cuda() for i in range(2)]
+    outs = {}
+    try:
+        os.environ["VFMSEG_PLAN_SKIP_L0"] = skip_l0
+        for flag in ("1", "0"):
+            os.environ["VFMSEG_PLAN"] = flag
+            res = []
+            for step, img in enumerate(imgs):
+                opt.gflat.zero_()
+                xcat, _ = model.backbone.forward_tokens([(img, None)], seed=11 + step)
+                dx = torch.randn(xcat.shape, generator=torch.Generator().manual_seed(3 + step)).to(xcat.dtype).cuda()
+                xcat.backward(dx)
+                res.append((xcat.detach().clone(), opt.gflat.clone()))
+            outs[flag] = res
+            eng = model.backbone.vit.engine()
+            used = bool(eng._packed.get("plans"))
+            assert used == (flag == "1"), "VFMSEG_PLAN must select the path"
+            eng._packed.pop("plans", None)
+    finally:
+        os.environ.pop("VFMSEG_PLAN", None)
+        os.environ.pop("VFMSEG_PLAN_SKIP_L0", None)
+    lora = [(n, a, a + sz) for n, a, sz in zip(opt.names, opt.offsets[:-1], opt.sizes) if "lora_" in n]
+    assert len(lora) == 2 * depth
+    for step in range(2):
+        assert torch.equal(outs["1"][step][0], outs["0"][step][0]), "forward taps must be bit-identical"
+        for n, a, b in lora:
+            ga, gb = outs["1"][step][1][a:b], outs["0"][step][1][a:b]
+            assert gb.abs().max() > 0
+            assert rel_err(ga, gb) < 5e-3, (step, n, rel_err(ga, gb))   # (run-to-run: 1e-3..2.6e-3 on the deepest block, as in the test below)
+
+
 def test_layer_batched_lora_wgrads_equal_per_layer_path():
     """bf16 train mode with the optimiser's flat gradient buffer: the LoRA weight gradients computed by the two layer-batched
     TN GEMMs + batched scatter (DinoEngine._lora_wgrads_batched) against the per-layer split-K path, same forward (dropout on,

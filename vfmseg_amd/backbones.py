@@ -256,6 +256,149 @@ def wgrad(dy, x, grad_out, alpha=1.0, n_rows=None, accumulate=True):
     return grad_out
 
 
+# ------------------------------------------------------------------------------------------ launch plan of the train step
+class _DinoTrainPlan:
+    """The backbone's train-step launch sequence (LoRA on, 16-bit mode, fused LN + dropout) as launch plans (ops.Plan -> vfm_run_plan):
+    9 launches per block forward, 9-11 backward, over PERSISTENT layer-batched activation buffers, replayed by one C call per pass
+    instead of ~430 Python-issued launches (12.2 -> ~6 ms of host enqueue per step).  Same kernels, same arguments,
+    same order as DinoEngine.forward / .backward issue one by one: results are bit-identical (tests/test_backbone_gpu.py).
+    Buffers (3.9 GB at depth 24, bs 2: 1.4 % of the 288 GB): X[l] the fp32 residual stream entering block l, A1 = [LN1 x | T] the
+    K-extended QKV operand, XD the dropped copy, MASK the dropout multiplier, QKV, AO, LSE, XMID, A2, HPRE = gelu'(fc1 pre-activation),
+    and for backward DQKV / DA1 of every layer (the batched LoRA weight gradients read them) + DX, T, DH, DN, DAO."""
+
+    def __init__(self, eng, P, nimg, Np):
+        v = eng.vit
+        cd, dev = P["cd"], P["dev"]
+        D, H = v.embed_dim, v.num_heads
+        nL = len(v.blocks)
+        M, Mp = nimg * Np + nimg, nimg * Np
+        Lp0 = P["layers"][0]
+        kq, hid = Lp0["qkv"].k, Lp0["fc1"].n
+        q0 = v.blocks[0].attn.qkv
+        self.eng, self.P, self.nimg, self.Np, self.M, self.Mp, self.nL, self.D, self.H = eng, P, nimg, Np, M, Mp, nL, D, H
+        self.busy = False
+        e = lambda *sh, dt=cd: torch.empty(*sh, dtype=dt, device=dev)   # noqa: E731
+        f32 = torch.float32
+        self.X = e(nL + 1, M, D, dt=f32)
+        self.A1, self.XD, self.MASK = e(nL, M, kq), e(nL, M, D), e(nL, M, D)
+        self.ST1, self.ST2 = e(nL, M, 2, dt=f32), e(nL, M, 2, dt=f32)
+        self.QKV, self.AO = e(nL, M, 3 * D), e(nL, M, D)
+        self.LSE = e(nL, nimg, H, Np + 1, dt=f32)
+        self.XMID, self.A2 = e(nL, M, D, dt=f32), e(nL, M, D)
+        hld = hid + ops.ld_pad(hid, cd)
+        self.HPRE = e(nL, M, hld)[:, :, :hid]
+        self.G = e(M, hld)[:, :hid]
+        self.hid, self.kq = hid, kq
+        hd = D // H
+        scale = hd ** -0.5
+        # ---- forward
+        f = self.fwd = ops.Plan("backbone")
+        self.tap_ops = []     # (plan entry, column offset into xcat): their destination is this step's xcat
+        self.nt = len(v.out_indices)
+        xcat0 = e(Mp, self.nt * D)   # placeholder destination (patched every step)
+        for li, (blk, Lp) in enumerate(zip(v.blocks, P["layers"])):
+            q = blk.attn.qkv
+            x, a1 = self.X[li], self.A1[li]
+            f.layernorm_dropout_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], self.ST1[li], self.XD[li], self.MASK[li], q.p, li * M * D)
+            f.gemm(self.XD[li], Lp["a"], a1[:, D:D + R_PAD], alpha=q.scaling)
+            f.gemm(a1, Lp["qkv"].w, self.QKV[li], bias=Lp["qkv_b"])
+            qkv = self.QKV[li]
+            f.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], self.AO[li], self.LSE[li], nimg, H, hd, Np, 1, Np, 1, scale)
+            f.gemm(self.AO[li], Lp["proj"].w, self.XMID[li], bias=Lp["proj_b"], colscale=Lp["g1"], residual=x)
+            f.layernorm_fwd(self.XMID[li], Lp["n2w"], Lp["n2b"], 1e-6, self.A2[li], self.ST2[li])
+            f.gemm(self.A2[li], Lp["fc1"].w, self.G, bias=Lp["fc1_b"], ep_mode=ops.EP_GELU_DGELU, c2=self.HPRE[li])
+            f.gemm(self.G, Lp["fc2"].w, self.X[li + 1], bias=Lp["fc2_b"], colscale=Lp["g2"], residual=self.XMID[li])
+            for i, oi in enumerate(v.out_indices):
+                if oi == li:
+                    self.tap_ops.append((f.cast(self.X[li + 1][:Mp], xcat0[:, i * D:(i + 1) * D]), i * D))
+        self.bwd = None
+
+    def eligible_backward(self):
+        from .functional import direct_grad_target
+        v = self.eng.vit
+        return (os.environ.get("VFMSEG_LORA_WGRAD_BATCHED", "1") != "0" and
+                all(direct_grad_target(b.attn.qkv.lora_A["default"].weight) is not None and
+                    direct_grad_target(b.attn.qkv.lora_B["default"].weight) is not None for b in v.blocks))
+
+    def run_forward(self, xcat, seed, rng0):
+        esz = xcat.element_size()
+        for idx, col in self.tap_ops:
+            self.fwd.entry(idx).u.cast.dst = xcat.data_ptr() + col * esz
+        self.fwd.run(seed, rng0)
+
+    def _build_backward(self, dxcat):
+        """Two plans: blocks L-1 .. L/2 and L/2-1 .. 0 (the batched LoRA weight gradients of a half, and the DP bucket of the first half,
+        go out between them)."""
+        v, P = self.eng.vit, self.P
+        cd, dev = P["cd"], P["dev"]
+        D, H, nL, M, Mp, nimg, Np = self.D, self.H, self.nL, self.M, self.Mp, self.nimg, self.Np
+        hd = D // H
+        scale = hd ** -0.5
+        e = lambda *sh, dt=cd: torch.empty(*sh, dtype=dt, device=dev)   # noqa: E731
+        self.DX = e(M, D, dt=torch.float32)
+        self.T, self.DN, self.DAO = e(M, D), e(M, D), e(M, D)
+        self.DH = e(M, self.hid + ops.ld_pad(self.hid, cd))[:, :self.hid]
+        self.DQKV, self.DA1 = e(nL, M, 3 * D), e(nL, M, self.kq)
+        half = nL // 2
+        skip_l0 = os.environ.get("VFMSEG_PLAN_SKIP_L0", "1") != "0"
+        self.half = half
+        self.dx_sig = (tuple(dxcat.shape), tuple(dxcat.stride()), dxcat.dtype)
+        plans, self.tap_src = [], []      # tap_src: (plan number, entry, column offset into dxcat)
+
+        def add_tap(pl, pn, li):
+            for i, oi in enumerate(v.out_indices):
+                if oi == li:
+                    src = dxcat[:, i * D:(i + 1) * D]
+                    self.tap_src.append((pn, pl.strided_copy(src, self.DX, (Mp, D), (src.stride(0), 1), (D, 1), accumulate=True), i * D))
+
+        for pn, (hi, lo) in enumerate(((nL, half), (half, 0)) if half > 0 else ((nL, 0),)):
+            pl = ops.Plan("backbone")
+            for li in range(hi - 1, lo - 1, -1):
+                blk, Lp = v.blocks[li], P["layers"][li]
+                q = blk.attn.qkv
+                if li == nL - 1:
+                    add_tap(pl, pn, li)
+                    pl.cast(self.DX, self.T, Lp["g2"])
+                pl.gemm(self.T, Lp["fc2"].wt, self.DH, ep_mode=ops.EP_MUL, aux=self.HPRE[li])
+                pl.gemm(self.DH, Lp["fc1"].wt, self.DN)
+                pl.layernorm_bwd_scaled(self.DN, self.XMID[li], Lp["n2w"], self.ST2[li], self.DX, self.T, Lp["g1"], accumulate_dx=True)
+                pl.gemm(self.T, Lp["proj"].wt, self.DAO)
+                qkv, dqkv, da1 = self.QKV[li], self.DQKV[li], self.DA1[li]
+                pl.attn_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], self.AO[li], self.LSE[li], self.DAO, dqkv[:, :D], dqkv[:, D:2 * D],
+                            dqkv[:, 2 * D:], nimg, H, hd, Np, 1, Np, 1, scale)
+                if li == 0 and skip_l0:
+                    # block 0: nothing upstream of LN1 is trainable (patch embedding, position embedding and [cls] token are frozen,
+                    # lora_backbone.py:36-44), so of d[LN1 x | T] only dT - the LoRA factors' gradient operand - is needed: 64 of the 1088
+                    # columns of the qkv input gradient, no LoRA dgrad GEMM, no LN1 backward
+                    pl.gemm(dqkv, Lp["qkv"].wt[D:D + R_PAD], da1[:, D:D + R_PAD])
+                    continue
+                pl.gemm(dqkv, Lp["qkv"].wt, da1)
+                pl.gemm(da1[:, D:D + R_PAD], Lp["at"], da1[:, :D], alpha=q.scaling, residual=da1[:, :D], ep_mode=ops.EP_MUL, aux=self.MASK[li])
+                if li > 0:
+                    add_tap(pl, pn, li - 1)
+                    pl.layernorm_bwd_scaled(da1[:, :D], self.X[li], Lp["n1w"], self.ST1[li], self.DX, self.T, P["layers"][li - 1]["g2"],
+                                            accumulate_dx=True)
+                else:   # (the one-by-one path's LN1 backward of block 0; its dx is not used by anything)
+                    pl.layernorm_bwd_scaled(da1[:, :D], self.X[li], Lp["n1w"], self.ST1[li], self.DX, self.T, Lp["g2"], accumulate_dx=True)
+            plans.append((pl, lo, hi))
+        self.bwd = plans
+
+    def run_backward(self, ctx, dxcat):
+        sig = (tuple(dxcat.shape), tuple(dxcat.stride()), dxcat.dtype)
+        if self.bwd is None or self.dx_sig != sig:
+            self._build_backward(dxcat)
+        esz = dxcat.element_size()
+        for pn, idx, col in self.tap_src:
+            self.bwd[pn][0].entry(idx).u.copy.src = dxcat.data_ptr() + col * esz
+        self.DX.zero_()
+        for pl, lo, hi in self.bwd:
+            pl.run()
+            self.eng._lora_wgrads_batched(self.P, ctx, self.DA1, self.DQKV, lo, hi, self.M, self.D)
+            if BACKWARD_EVENTS["block_done"] is not None:
+                for lj in range(hi - 1, lo - 1, -1):
+                    BACKWARD_EVENTS["block_done"](lj)
+
+
 # ------------------------------------------------------------------------------------------ engine
 class DinoEngine:
     def __init__(self, vit):
@@ -375,7 +518,7 @@ class DinoEngine:
         return self._pos_cache[key]
 
     # ---- forward
-    def forward(self, jobs, training, seed):
+    def forward(self, jobs, training, seed, need_grad=False):
         v, P = self.vit, self.packed()
         cd = P["cd"]
         dev = P["dev"]
@@ -405,7 +548,8 @@ class DinoEngine:
             r0 += b
         ptok = torch.empty(Mp, D, dtype=torch.float32, device=dev)
         P["pe"].fwd(A0, ptok, bias=P["pe_b"])
-        x = torch.empty(M, D, dtype=torch.float32, device=dev)
+        plan = self._train_plan(P, nimg, Np, training, merged) if need_grad else None
+        x = plan.X[0] if plan is not None else torch.empty(M, D, dtype=torch.float32, device=dev)
         ops.assemble_tokens(ptok, P["cls"], self.pos_tokens(hp, wp), x, nimg, Np, D)
         del ptok, A0
         nt = len(v.out_indices)
@@ -416,6 +560,11 @@ class DinoEngine:
             seed, rng0 = draw_seed(seed, len(v.blocks) * M * D)
         else:
             seed, rng0 = 0, 0
+        if plan is not None:
+            plan.run_forward(xcat, seed, rng0)
+            plan.busy = True
+            ctx = dict(saved=None, plan=plan, nimg=nimg, Np=Np, M=M, Mp=Mp, P=P, training=training, A1all=plan.A1, XDall=plan.XD)
+            return xcat, (hp, wp), ctx
         # training: the K-extended QKV operands [LN(x) | T] and the dropped LN copies of ALL layers live in two layer-batched
         # buffers, so that the LoRA weight gradients of many layers can run as ONE batched GEMM each (see backward)
         nL = len(v.blocks)
@@ -482,8 +631,34 @@ class DinoEngine:
         ctx = dict(saved=saved, nimg=nimg, Np=Np, M=M, Mp=Mp, P=P, training=training, A1all=A1all, XDall=XDall)
         return xcat, (hp, wp), ctx
 
+    def _train_plan(self, P, nimg, Np, training, merged):
+        """The launch plan of this call's shape when the call is the hot one (training with gradients, LoRA with dropout on every
+        block, 16-bit mode, weight gradients into the optimiser's flat buffer) and no earlier forward still owns the plan's buffers."""
+        v = self.vit
+        if (not training or merged is not None or not self.lora_on() or not is_half(P["cd"])
+                or os.environ.get("VFMSEG_PLAN", "1") == "0" or v.embed_dim % 256 != 0):
+            return None
+        q0 = v.blocks[0].attn.qkv
+        if not all(isinstance(b.attn.qkv, LoraLinear) and b.attn.qkv.p > 0 and b.attn.qkv.p == q0.p and b.attn.qkv.scaling == q0.scaling
+                   for b in v.blocks):
+            return None
+        plans = P.setdefault("plans", {})
+        pl = plans.get((nimg, Np))
+        if pl is None:
+            pl = plans[(nimg, Np)] = _DinoTrainPlan(self, P, nimg, Np)
+        if pl.busy or not pl.eligible_backward():
+            return None
+        return pl
+
     # ---- backward: d(xcat) -> LoRA grads [dA0, dB0, dA1, dB1, ...]
     def backward(self, ctx, dxcat):
+        if ctx.get("plan") is not None:
+            plan = ctx["plan"]
+            try:
+                plan.run_backward(ctx, dxcat)
+            finally:
+                plan.busy = False
+            return [None] * (2 * len(self.vit.blocks))
         v, P = self.vit, ctx["P"]
         cd, dev = P["cd"], P["dev"]
         D, H = v.embed_dim, v.num_heads
@@ -715,7 +890,10 @@ class _BackboneFn(torch.autograd.Function):
         eng = vit.engine()
         need_grad = training and any(p.requires_grad for p in lora_params)
         with ops.region("backbone"):
-            xcat, grid, c = eng.forward(jobs, training, seed)
+            if isinstance(eng, DinoEngine):
+                xcat, grid, c = eng.forward(jobs, training, seed, need_grad=need_grad)
+            else:
+                xcat, grid, c = eng.forward(jobs, training, seed)
         if need_grad:
             ctx.eng, ctx.c = eng, c
         else:

@@ -51,6 +51,45 @@ class AttnDesc(C.Structure):
     ]
 
 
+class _LnFwd(C.Structure):
+    _fields_ = [("x", vp), ("ld_x", cl), ("w", vp), ("b", vp), ("eps", cf), ("y", vp), ("y_dt", ci), ("ld_y", cl), ("stats", vp),
+                ("rows", cl), ("C", cl)]
+
+
+class _LnDrop(C.Structure):
+    _fields_ = [("x", vp), ("ld_x", cl), ("w", vp), ("b", vp), ("eps", cf), ("y", vp), ("ld_y", cl), ("stats", vp), ("y_drop", vp),
+                ("ld_yd", cl), ("mask", vp), ("ld_mask", cl), ("p", cf), ("offset", u64), ("rows", cl), ("C", cl)]
+
+
+class _LnBwd(C.Structure):
+    _fields_ = [("dy", vp), ("dy_dt", ci), ("ld_dy", cl), ("x", vp), ("ld_x", cl), ("w", vp), ("stats", vp), ("dx", vp), ("ld_dx", cl),
+                ("accumulate_dx", ci), ("t_out", vp), ("ld_t", cl), ("t_scale", vp), ("rows", cl), ("C", cl)]
+
+
+class _CastOp(C.Structure):
+    _fields_ = [("src", vp), ("src_dt", ci), ("ld_src", cl), ("dst", vp), ("dst_dt", ci), ("ld_dst", cl), ("rows", cl), ("cols", cl),
+                ("colscale", vp)]
+
+
+class _CopyOp(C.Structure):
+    _fields_ = [("src", vp), ("src_dt", ci), ("dst", vp), ("dst_dt", ci), ("n", cl * 4), ("ss", cl * 4), ("ds", cl * 4), ("accumulate", ci)]
+
+
+class _PlanU(C.Union):
+    _fields_ = [("gemm", GemmDesc), ("attn", AttnDesc), ("ln_fwd", _LnFwd), ("ln_drop", _LnDrop), ("ln_bwd", _LnBwd), ("cast", _CastOp),
+                ("copy", _CopyOp)]
+
+
+class PlanOp(C.Structure):
+    """vfm_plan_op (include/vfmseg_hip.h, "launch plans")."""
+    _fields_ = [("kind", ci), ("prof_kind", ci), ("flops", C.c_double), ("u", _PlanU)]
+
+
+OP_GEMM, OP_LN_FWD, OP_LN_DROPOUT_FWD, OP_LN_BWD_SCALED, OP_ATTN_FWD, OP_ATTN_BWD, OP_CAST, OP_STRIDED_COPY = range(8)
+PROF_NONE, PROF_GEMM, PROF_GEMM_TN, PROF_ATTN_FWD, PROF_ATTN_BWD = range(5)
+PROF_NAMES = {PROF_GEMM: "gemm", PROF_GEMM_TN: "gemm_tn", PROF_ATTN_FWD: "attn_fwd", PROF_ATTN_BWD: "attn_bwd"}
+
+
 class SlideWin(C.Structure):
     _fields_ = [("crop", vp), ("nchw", ci), ("h", ci), ("w", ci), ("y0", ci), ("x0", ci), ("hc", ci), ("wc", ci)]
 
@@ -123,6 +162,9 @@ SIGNATURES = {
     "vfm_adamw": [vp, vp, vp, vp, cl, vp, vp, vp, ci, cf, cf, cf, cf, ci, cf, ci, ci, vp],
     "vfm_adamw_guarded": [vp, vp, vp, vp, cl, vp, vp, vp, ci, cf, cf, cf, cf, ci, cf, ci, ci, vp, vp, vp],
     "vfm_amp_update": [vp, vp, cf, cf, ci, ci, vp],
+    "vfm_run_plan": [C.POINTER(PlanOp), ci, u64, u64, vp],
+    "vfm_prof_config": [ci],
+    "vfm_prof_read": [C.POINTER(C.c_double), ci],
 }
 
 _lib = None          # the ACTIVE library (what load() returns)

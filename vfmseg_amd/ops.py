@@ -364,7 +364,19 @@ def gemm(a, b, c, *, alpha=1.0, bias=None, bias_mod=0, colscale=None, residual=N
         b3 = split3(b, 1, trans=trans_b, cache=not b.requires_grad)
         return gemm(a3, b3, c, alpha=alpha, bias=bias, bias_mod=bias_mod, colscale=colscale, residual=residual, ep_mode=ep_mode, aux=aux, c2=c2)
     lib = L.load()
-    d = L.GemmDesc()
+    d = gemm_desc(a, b, c, alpha=alpha, bias=bias, bias_mod=bias_mod, colscale=colscale, residual=residual, ep_mode=ep_mode, aux=aux, c2=c2,
+                  trans_a=trans_a, trans_b=trans_b, kb_rows=kb_rows)
+    fin = PROFILE("gemm", 2.0 * d.M * d.N * d.K * d.batch, REGION[-1]) if (PROFILE is not None and is_half(a.dtype)) else None
+    L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
+    if fin is not None:
+        fin()
+    return c
+
+
+def gemm_desc(a, b, c, *, alpha=1.0, bias=None, bias_mod=0, colscale=None, residual=None, ep_mode=EP_NONE, aux=None, c2=None,
+              trans_a=False, trans_b=False, kb_rows=0, d=None):
+    """The vfm_gemm_desc of gemm(a, b, c, ...) (filled into `d` when given: an entry of a launch plan)."""
+    d = L.GemmDesc() if d is None else d
     batched = a.dim() == 3
     a2 = a[0] if batched else a
     b2 = b[0] if batched else b
@@ -407,11 +419,126 @@ def gemm(a, b, c, *, alpha=1.0, bias=None, bias_mod=0, colscale=None, residual=N
         d.batch, d.stride_a, d.stride_b, d.stride_c = a.shape[0], a.stride(0), b.stride(0), c.stride(0)
     else:
         d.batch = 1
-    fin = PROFILE("gemm", 2.0 * M * N * K * d.batch, REGION[-1]) if (PROFILE is not None and is_half(a.dtype)) else None
-    L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
-    if fin is not None:
-        fin()
-    return c
+    return d
+
+
+class Plan:
+    """A launch plan (include/vfmseg_hip.h "launch plans"): entries are appended with the same tensor arguments the one-by-one wrappers
+    take, run() replays them through vfm_run_plan in ONE ctypes call.  The tensors are kept alive by the plan; their addresses must stay
+    what they were when the entry was appended (persistent buffers), except for fields patched through `entry(i)` before a run."""
+
+    def __init__(self, region="backbone"):
+        self.ops, self.keep, self.arr, self.region = [], [], None, region
+
+    def _new(self, kind, prof=L.PROF_NONE, flops=0.0, *tensors):
+        op = L.PlanOp()
+        op.kind, op.prof_kind, op.flops = kind, prof, float(flops)
+        self.ops.append(op)
+        self.keep.extend(t for t in tensors if t is not None)
+        self.arr = None
+        return op
+
+    def gemm(self, a, b, c, **kw):
+        op = self._new(L.OP_GEMM, L.PROF_GEMM if is_half(a.dtype) else L.PROF_NONE, 0.0, a, b, c, kw.get("bias"), kw.get("colscale"),
+                       kw.get("residual"), kw.get("aux"), kw.get("c2"))
+        d = gemm_desc(a, b, c, d=op.u.gemm, **kw)
+        op.flops = 2.0 * d.M * d.N * d.K * d.batch
+        return len(self.ops) - 1
+
+    def layernorm_fwd(self, x, w, b, eps, y, stats):
+        op = self._new(L.OP_LN_FWD, L.PROF_NONE, 0.0, x, w, b, y, stats)
+        u = op.u.ln_fwd
+        u.x, u.ld_x, u.w, u.b, u.eps, u.y, u.y_dt, u.ld_y, u.stats = L.ptr(x), _ld(x), L.ptr(w), L.ptr(b), float(eps), L.ptr(y), L.dt_of(y), _ld(y), L.ptr(stats)
+        u.rows, u.C = x.shape
+        return len(self.ops) - 1
+
+    def layernorm_dropout_fwd(self, x, w, b, eps, y, stats, y_drop, mask, p, offset):
+        """`offset` is relative to the rng_base given to run()."""
+        assert is_half(y.dtype) and is_half(y_drop.dtype) and is_half(mask.dtype)
+        op = self._new(L.OP_LN_DROPOUT_FWD, L.PROF_NONE, 0.0, x, w, b, y, stats, y_drop, mask)
+        u = op.u.ln_drop
+        u.x, u.ld_x, u.w, u.b, u.eps, u.y, u.ld_y, u.stats = L.ptr(x), _ld(x), L.ptr(w), L.ptr(b), float(eps), L.ptr(y), _ld(y), L.ptr(stats)
+        u.y_drop, u.ld_yd, u.mask, u.ld_mask, u.p, u.offset = L.ptr(y_drop), _ld(y_drop), L.ptr(mask), _ld(mask), float(p), int(offset)
+        u.rows, u.C = x.shape
+        return len(self.ops) - 1
+
+    def layernorm_bwd_scaled(self, dy, x, w, stats, dx, t_out, t_scale, accumulate_dx=False):
+        assert is_half(t_out.dtype) and t_scale.dtype == torch.float32
+        op = self._new(L.OP_LN_BWD_SCALED, L.PROF_NONE, 0.0, dy, x, w, stats, dx, t_out, t_scale)
+        u = op.u.ln_bwd
+        u.dy, u.dy_dt, u.ld_dy, u.x, u.ld_x, u.w, u.stats = L.ptr(dy), L.dt_of(dy), _ld(dy), L.ptr(x), _ld(x), L.ptr(w), L.ptr(stats)
+        u.dx, u.ld_dx, u.accumulate_dx, u.t_out, u.ld_t, u.t_scale = L.ptr(dx), _ld(dx), int(accumulate_dx), L.ptr(t_out), _ld(t_out), L.ptr(t_scale)
+        u.rows, u.C = x.shape
+        return len(self.ops) - 1
+
+    def attn_fwd(self, q, k, v, o, lse, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale):
+        fl = 4.0 * B * H * (nq_main + nq_extra) * (nk_main + nk_extra) * d
+        op = self._new(L.OP_ATTN_FWD, L.PROF_ATTN_FWD if is_half(q.dtype) else L.PROF_NONE, fl, q, k, v, o, lse)
+        C.memmove(C.byref(op.u.attn), C.byref(_attn_desc(q, k, v, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, lse)), C.sizeof(L.AttnDesc))
+        return len(self.ops) - 1
+
+    def attn_bwd(self, q, k, v, o, lse, dout, dq, dk, dv, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale):
+        fl = 10.0 * B * H * (nq_main + nq_extra) * (nk_main + nk_extra) * d
+        delta = _attn_bwd_delta(q, B, H, nq_main + nq_extra)
+        op = self._new(L.OP_ATTN_BWD, L.PROF_ATTN_BWD if is_half(q.dtype) else L.PROF_NONE, fl, q, k, v, o, lse, dout, dq, dk, dv, delta)
+        a = _attn_desc(q, k, v, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, lse)
+        a.dout, a.ld_do = L.ptr(dout), dout.stride(0)
+        a.dq, a.dk, a.dv = L.ptr(dq), L.ptr(dk), L.ptr(dv)
+        a.ld_dq, a.ld_dk, a.ld_dv = dq.stride(0), dk.stride(0), dv.stride(0)
+        a.delta = L.ptr(delta)
+        C.memmove(C.byref(op.u.attn), C.byref(a), C.sizeof(L.AttnDesc))
+        return len(self.ops) - 1
+
+    def cast(self, src, dst, colscale=None):
+        op = self._new(L.OP_CAST, L.PROF_NONE, 0.0, src, dst, colscale)
+        u = op.u.cast
+        u.src, u.src_dt, u.ld_src, u.dst, u.dst_dt, u.ld_dst = L.ptr(src), L.dt_of(src), _ld(src), L.ptr(dst), L.dt_of(dst), _ld(dst)
+        u.rows, u.cols = src.shape
+        u.colscale = L.ptr(colscale)
+        return len(self.ops) - 1
+
+    def strided_copy(self, src, dst, shape, sstr, dstr, accumulate=False):
+        op = self._new(L.OP_STRIDED_COPY, L.PROF_NONE, 0.0, src, dst)
+        u = op.u.copy
+        k = 4 - len(shape)
+        u.src, u.src_dt, u.dst, u.dst_dt = L.ptr(src), L.dt_of(src), L.ptr(dst), L.dt_of(dst)
+        for i, (n, s_, d_) in enumerate(zip([1] * k + list(shape), [0] * k + list(sstr), [0] * k + list(dstr))):
+            u.n[i], u.ss[i], u.ds[i] = n, s_, d_
+        u.accumulate = int(accumulate)
+        return len(self.ops) - 1
+
+    def _array(self):
+        if self.arr is None:
+            self.arr = (L.PlanOp * len(self.ops))()
+            for i, op in enumerate(self.ops):
+                C.memmove(C.byref(self.arr[i]), C.byref(op), C.sizeof(L.PlanOp))
+        return self.arr
+
+    def entry(self, i):
+        """The i-th entry of the array run() hands to the library (for per-run patches of pointer fields)."""
+        return self._array()[i]
+
+    def run(self, seed=0, rng_base=0, start=0, count=None):
+        arr = self._array()
+        n = len(self.ops) - start if count is None else count
+        first = C.cast(C.byref(arr, start * C.sizeof(L.PlanOp)), C.POINTER(L.PlanOp))
+        L.check(L.load().vfm_run_plan(first, n, int(seed), int(rng_base), L.stream()), "vfm_run_plan")
+
+    def __len__(self):
+        return len(self.ops)
+
+
+def prof_config(every):
+    L.check(L.load().vfm_prof_config(int(every)), "vfm_prof_config")
+
+
+def prof_read(cap=65536):
+    """[(kind name, flops, ms)] of the launches the plan sampler timed since the last read (waits for their events)."""
+    buf = (C.c_double * (3 * cap))()
+    n = L.load().vfm_prof_read(buf, cap)
+    if n < 0:
+        L.check(n, "vfm_prof_read")
+    return [(L.PROF_NAMES.get(int(buf[3 * i]), "other"), buf[3 * i + 1], buf[3 * i + 2]) for i in range(n)]
 
 
 class LoraPackTable:
@@ -558,6 +685,15 @@ def _attn_desc(q, k, v, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale,
 _attn_bwd_ws = {}
 
 
+def _attn_bwd_delta(q, B, H, nq):
+    """delta[B, H, nq] + the zero-on-entry scratch of the extra-token rows (the kernels leave it zeroed): one buffer per shape"""
+    key = (str(q.device), B, H, nq)
+    delta = _attn_bwd_ws.get(key)
+    if delta is None:
+        delta = _attn_bwd_ws[key] = torch.zeros(B * H * nq + B * H * 192, dtype=torch.float32, device=q.device)
+    return delta
+
+
 def attn_fwd(q, k, v, o, lse, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale):
     """q,k,v,o: 2-D row-major views [rows, >=H*d] (column slices of a packed qkv buffer are fine)."""
     lib = L.load()
@@ -584,12 +720,7 @@ def attn_bwd(q, k, v, o, lse, dout, dq, dk, dv, B, H, d, nq_main, nq_extra, nk_m
     a.dout, a.ld_do = L.ptr(dout), dout.stride(0)
     a.dq, a.dk, a.dv = L.ptr(dq), L.ptr(dk), L.ptr(dv)
     a.ld_dq, a.ld_dk, a.ld_dv = dq.stride(0), dk.stride(0), dv.stride(0)
-    # delta[B, H, nq] + the zero-on-entry scratch of the extra-token rows (the kernels leave it zeroed): one buffer per shape
-    key = (str(q.device), B, H, nq_main + nq_extra)
-    delta = _attn_bwd_ws.get(key)
-    if delta is None:
-        delta = _attn_bwd_ws[key] = torch.zeros(B * H * (nq_main + nq_extra) + B * H * 192, dtype=torch.float32, device=q.device)
-    a.delta = L.ptr(delta)
+    a.delta = L.ptr(_attn_bwd_delta(q, B, H, nq_main + nq_extra))
     fin = None
     if PROFILE is not None and is_half(q.dtype):   # algorithmic: S, dP, dV, dK, dQ = five products = 10 B H Nq Nk d
         fin = PROFILE("attn_bwd", 10.0 * B * H * (nq_main + nq_extra) * (nk_main + nk_extra) * d, REGION[-1])
