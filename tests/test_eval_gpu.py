@@ -150,7 +150,7 @@ def test_lr_and_msfull_slide_modes_match_oracle():
 
 # (bf16 bounds = 3x the measured values: logits 8.6e-3, mismatches 8.3e-3, margin 3.2e-3 - profiles/r03_parity_gpu_suite.log)
 @pytest.mark.parametrize("prec,ltol,mtol", [("f32", 1e-3, 2e-4), ("bf16x3", 1e-3, 2e-4), ("bf16", 2.6e-2, 2.5e-2),
-                                                ("fp16", 5e-3, 5e-3)])
+                                                ("fp16", 1e-3, 5e-3)])
 def test_slide_modes_match_reference_goldens(golden_dir, prec, ltol, mtol):
     """lr_slide_inference / hr_slide_inference / msfull_slide_inference at full depth on the HIP path against the reference's OWN
     MsVFMEncoderDecoder.inference output in those modes (tests/golden/slide_modes.npz; Ms_VFM_encoder_decoder.py:278-332), msfull with

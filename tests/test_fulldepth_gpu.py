@@ -140,7 +140,7 @@ def _margin_report(logits, pred, ref_pred):
     return frac, worst
 
 
-@pytest.mark.parametrize("prec,ltol,ftol", [("bf16", 3e-2, 1e-2), ("fp16", 6e-3, 3e-3)])
+@pytest.mark.parametrize("prec,ltol,ftol", [("bf16", 3e-2, 1e-2), ("fp16", 1e-3, 3e-3)])
 def test_ms_inference_bf16_vs_reference_golden(golden_dir, prec, ltol, ftol):
     """The TIMED (bf16) inference path - and the fp16 (`--amp` dtype) one - against the reference's own ms_inference output
     (ms_inference.npz): which windows were refined, logits error, argmax mismatch fraction; every mismatching pixel must be a
@@ -171,8 +171,7 @@ def test_ms_inference_bf16_vs_reference_golden(golden_dir, prec, ltol, ftol):
     assert frac < ftol and worst < ltol and drift < ftol
 
 
-@pytest.mark.parametrize("prec,ltol,ftol", [("f32", 1e-3, 2e-4), ("bf16", 4e-2, 1.5e-2)])
-def test_sam_slide_full_depth_vs_reference_golden(golden_dir, prec, ltol, ftol):
+def test_sam_slide_full_depth_vs_reference_golden(golden_dir):
     """BASELINE configs[4] WHOLE - what bench.py's sam_h_slide leg times: SAM-ViT-H at depth 32 + LoRA + LinearHead, `slide` (3 x 3 windows
     of 512^2, stride 320) on a 1024^2 image, against the reference-made golden (sam_slide.npz; sam_vit.py:127-148, lora_sam_linear.py:50-54).
     f32 claims north_star's tolerance; bf16 (the timed mode) is measured and bounded, every flipped pixel a near-tie."""
@@ -180,28 +179,32 @@ def test_sam_slide_full_depth_vs_reference_golden(golden_dir, prec, ltol, ftol):
     from vfmseg_amd.synth import synth_state_dict
     import vfmseg_amd.sam  # noqa: F401
     G = np.load(os.path.join(golden_dir, "sam_slide.npz"))
-    set_compute_dtype(prec)
-    try:
-        model = MODELS.build(presets.sam_linear())
-        sd = sam_state_dict()
-        head = {k: tuple(v.shape) if v.dtype != torch.int64 else ((), torch.int64) for k, v in model.state_dict().items() if k.startswith("decode_head.")}
-        sd.update(synth_state_dict(head))
-        model.load_state_dict(sd, strict=False)
-        model = model.cuda().eval()
-        with torch.no_grad():
-            out = model.predict(synth_image(1, 1024, seed=47).cuda())
-        logits = out[0].seg_logits.data.float().cpu()
-        e_slice = rel_err(sl(logits.unsqueeze(0)), G["logits_slice"])
-        e_sub = rel_err(logits[:, ::16, ::16], G["logits_sub16"])
-        pred = out[0].pred_sem_seg.data[0].cpu()
-        frac, worst = _margin_report(logits[:, ::4, ::4], pred[::4, ::4].long(), torch.from_numpy(G["pred_sub4"].astype(np.int64)))
-        hist = np.bincount(pred.numpy().reshape(-1), minlength=19)
-        drift = np.abs(hist - G["pred_hist"]).sum() / hist.sum()
-    finally:
-        set_compute_dtype("bf16")
-    print(f"[sam slide depth 32 {prec}] logits rel err slice {e_slice:.2e} every-16th-pixel {e_sub:.2e}; argmax mismatch {frac:.2e}, "
-          f"largest relative top-2 margin among them {worst:.2e}; class-histogram drift {drift:.2e}")
-    assert e_slice < ltol and e_sub < ltol and frac < ftol and worst < ltol and drift < max(ftol, 1e-3)
+    sd, img = None, synth_image(1, 1024, seed=47).cuda()
+    for prec, ltol, ftol in (("f32", 1e-3, 2e-4), ("bf16", 4e-2, 1.5e-2)):   # (one test: the two modes share the 2.5-GB state dict)
+        set_compute_dtype(prec)
+        try:
+            model = MODELS.build(presets.sam_linear())
+            if sd is None:
+                sd = sam_state_dict()
+                head = {k: tuple(v.shape) if v.dtype != torch.int64 else ((), torch.int64) for k, v in model.state_dict().items() if k.startswith("decode_head.")}
+                sd.update(synth_state_dict(head))
+            model.load_state_dict(sd, strict=False)
+            model = model.cuda().eval()
+            with torch.no_grad():
+                out = model.predict(img)
+            logits = out[0].seg_logits.data.float().cpu()
+            e_slice = rel_err(sl(logits.unsqueeze(0)), G["logits_slice"])
+            e_sub = rel_err(logits[:, ::16, ::16], G["logits_sub16"])
+            pred = out[0].pred_sem_seg.data[0].cpu()
+            frac, worst = _margin_report(logits[:, ::4, ::4], pred[::4, ::4].long(), torch.from_numpy(G["pred_sub4"].astype(np.int64)))
+            hist = np.bincount(pred.numpy().reshape(-1), minlength=19)
+            drift = np.abs(hist - G["pred_hist"]).sum() / hist.sum()
+            del model
+        finally:
+            set_compute_dtype("bf16")
+        print(f"[sam slide depth 32 {prec}] logits rel err slice {e_slice:.2e} every-16th-pixel {e_sub:.2e}; argmax mismatch {frac:.2e}, "
+              f"largest relative top-2 margin among them {worst:.2e}; class-histogram drift {drift:.2e}")
+        assert e_slice < ltol and e_sub < ltol and frac < ftol and worst < ltol and drift < max(ftol, 1e-3), prec
 
 
 def test_sam_slide_inference_bf16_vs_oracle():
@@ -315,8 +318,7 @@ def test_lora_dropout_masks_differ_between_steps():
     assert torch.equal(c, d)
 
 
-@pytest.mark.parametrize("skip_l0", ["0", "1"])
-def test_launch_plan_equals_one_by_one_path(skip_l0):
+def test_launch_plan_equals_one_by_one_path():
     """The backbone's train-step launch sequence replayed by vfm_run_plan (one C call per pass over persistent buffers:
     backbones._DinoTrainPlan) against the same sequence issued launch by launch from Python (VFMSEG_PLAN=0): the feature taps are
     bit-identical (same kernels, arguments and order; no atomics in the forward), the LoRA gradients agree to the run-to-run noise of
@@ -336,9 +338,9 @@ def test_launch_plan_equals_one_by_one_path(skip_l0):
     imgs = [synth_image(2, 512, seed=81 + i).cuda() for i in range(2)]
     outs = {}
     try:
-        os.environ["VFMSEG_PLAN_SKIP_L0"] = skip_l0
-        for flag in ("1", "0"):
-            os.environ["VFMSEG_PLAN"] = flag
+        for flag, skip_l0 in (("1", "1"), ("0", "1"), ("L0", "0")):   # plan (default), one by one, plan with block 0 computed in full
+            os.environ["VFMSEG_PLAN_SKIP_L0"] = skip_l0
+            os.environ["VFMSEG_PLAN"] = "0" if flag == "0" else "1"
             res = []
             for step, img in enumerate(imgs):
                 opt.gflat.zero_()
@@ -349,7 +351,7 @@ def test_launch_plan_equals_one_by_one_path(skip_l0):
             outs[flag] = res
             eng = model.backbone.vit.engine()
             used = bool(eng._packed.get("plans"))
-            assert used == (flag == "1"), "VFMSEG_PLAN must select the path"
+            assert used == (flag != "0"), "VFMSEG_PLAN must select the path"
             eng._packed.pop("plans", None)
     finally:
         os.environ.pop("VFMSEG_PLAN", None)
@@ -357,11 +359,12 @@ def test_launch_plan_equals_one_by_one_path(skip_l0):
     lora = [(n, a, a + sz) for n, a, sz in zip(opt.names, opt.offsets[:-1], opt.sizes) if "lora_" in n]
     assert len(lora) == 2 * depth
     for step in range(2):
-        assert torch.equal(outs["1"][step][0], outs["0"][step][0]), "forward taps must be bit-identical"
-        for n, a, b in lora:
-            ga, gb = outs["1"][step][1][a:b], outs["0"][step][1][a:b]
-            assert gb.abs().max() > 0
-            assert rel_err(ga, gb) < 5e-3, (step, n, rel_err(ga, gb))   # (run-to-run: 1e-3..2.6e-3 on the deepest block, as in the test below)
+        for flag in ("1", "L0"):
+            assert torch.equal(outs[flag][step][0], outs["0"][step][0]), "forward taps must be bit-identical"
+            for n, a, b in lora:
+                ga, gb = outs[flag][step][1][a:b], outs["0"][step][1][a:b]
+                assert gb.abs().max() > 0
+                assert rel_err(ga, gb) < 5e-3, (flag, step, n, rel_err(ga, gb))   # (run-to-run: 1e-3..2.6e-3 on the deepest block, as in the test below)
 
 
 def test_layer_batched_lora_wgrads_equal_per_layer_path():

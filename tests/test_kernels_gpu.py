@@ -372,7 +372,7 @@ def test_gemm_bf16(M, N, K):
     assert relerr(cw[:, :N], a.double() @ b.double().t()) < 2e-5 and cw[:, N:].abs().sum() == 0
 
 
-@pytest.mark.parametrize("cfg", [17, 16, 30, 31, 32, 33, 34, 35, 36, 39, 40, 10])
+@pytest.mark.parametrize("cfg", [17, 16, 30, 31, 32, 33, 34, 35, 36, 39, 40, 50, 10])
 @pytest.mark.parametrize("M,N,K", [(4100, 1024, 1024), (300, 520, 320), (1024, 2048, 448), (256, 256, 4096), (512, 512, 128)])
 def test_gemm_bf16_configs_fast_epilogues(cfg, M, N, K):
     """Every tile configuration incl. the ping-pong kernels (30: 256x256, 31: 128x128) and the 64-wide-K-tile 256x256 kernels
@@ -380,6 +380,8 @@ def test_gemm_bf16_configs_fast_epilogues(cfg, M, N, K):
     backbones use; repeated launches double as a race screen for the LDS-DMA rings."""
     if cfg in (31, 35, 36) and K < 256:
         pytest.skip("the 128x128 ping-pong and deep-ring kernels need K >= 256 (the dispatcher rejects shorter K)")
+    if cfg == 50 and os.environ.get("VFMSEG_EXPERIMENTAL", "0") != "1":
+        pytest.skip("gemm_v5.hip (config 50) is built only with VFMSEG_EXPERIMENTAL=1")
     a, b = rnd(M, K, seed=80).bfloat16().to(DEV), rnd(N, K, seed=81).bfloat16().to(DEV)
     bias, cs, res = rnd(N, seed=82).to(DEV), (rnd(N, seed=83) * 0.2 + 1).to(DEV), rnd(M, N, seed=84).to(DEV)
     aux = rnd(M, N, seed=85).bfloat16().to(DEV)
@@ -477,6 +479,7 @@ def test_bf16x3_weight_cache_follows_in_place_weight_edits():
 
 
 
+@pytest.mark.skipif(os.environ.get("VFMSEG_EXPERIMENTAL", "0") != "1", reason="gemm_ps.hip is built only with VFMSEG_EXPERIMENTAL=1")
 @pytest.mark.parametrize("cfg", [37, 38])
 @pytest.mark.parametrize("M,N,K", [(4100, 4096, 1024), (512, 256, 640), (1024, 2048, 1088), (256, 256, 4096), (4356, 768, 576)])
 def test_gemm_bf16_persistent_two_accumulators(cfg, M, N, K):

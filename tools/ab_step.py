@@ -26,11 +26,16 @@ def main():
     model, ow = bench.build(dev, 2, workload=a.workload)
     Fh.manual_seed(1)
     data = bench.make_batch(2, 0, 0, dev, size=1024 if a.workload == "ms1024" else 512)
-    parsed = []
+    parsed, envs = [], {}
     for s in a.settings:
-        kv = [] if s == "base" else [(x.split("=")[0], int(x.split("=")[1])) for x in s.split(",")]
+        # KEY=INT: a vfm_tune knob; env:NAME=VALUE: an environment variable the Python side reads per call (e.g. env:VFMSEG_WGRAD_STREAM=0)
+        items = [] if s == "base" else s.split(",")
+        kv = [(x.split("=")[0], int(x.split("=")[1])) for x in items if not x.startswith("env:")]
+        envs[s] = [(x[4:].split("=")[0], x[4:].split("=")[1]) for x in items if x.startswith("env:")]
         parsed.append((s, kv))
     keys = {k for _, kv in parsed for k, _ in kv}
+    env_names = {n for v in envs.values() for n, _ in v}
+    env_base = {n: os.environ.get(n) for n in env_names}
     defaults = {"gemm_use_ps": 0, "gemm_use_pp": 184, "ps_burst": 0, "gemm_cfg": -1, "pp_dbg": 0, "attn_fwd64": 0, "attn_xcd": 1, "gemm_deep_tail_k": 0,
                 "attn_v2": 1, "gemm_nt_mb": 0, "gemm_deep_sep_k": 0, "attn_short_grid": 256, "gemm_use_192": 3}
     for _ in range(4):
@@ -43,6 +48,13 @@ def main():
                 ops.tune(k, defaults[k])
             for k, v in kv:
                 ops.tune(k, v)
+            for n in env_names:
+                if env_base[n] is None:
+                    os.environ.pop(n, None)
+                else:
+                    os.environ[n] = env_base[n]
+            for n, v in envs[s]:
+                os.environ[n] = v
             model.train_step(data, ow)
             torch.cuda.synchronize()
             t0 = time.perf_counter()

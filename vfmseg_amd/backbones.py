@@ -553,7 +553,9 @@ class DinoEngine:
         ops.assemble_tokens(ptok, P["cls"], self.pos_tokens(hp, wp), x, nimg, Np, D)
         del ptok, A0
         nt = len(v.out_indices)
-        xcat = torch.empty(Mp, nt * D, dtype=cd, device=dev)
+        from .precision import eval_heads_fp32
+        tap_dt = torch.float32 if (not training and not need_grad and eval_heads_fp32()) else cd
+        xcat = torch.empty(Mp, nt * D, dtype=tap_dt, device=dev)
         saved = []
         if lora and training:
             from .functional import draw_seed
@@ -909,6 +911,8 @@ class _BackboneFn(torch.autograd.Function):
         if dxcat is None:
             return (None, None, None, None) + (None,) * ctx.nparams
         if BACKWARD_EVENTS["heads_done"] is not None:
+            from .functional import join_wgrad_stream
+            join_wgrad_stream()     # (the heads' weight gradients run on a side stream; their DP buckets leave now)
             BACKWARD_EVENTS["heads_done"]()
         with ops.region("backbone"):
             grads = ctx.eng.backward(ctx.c, dxcat.contiguous())

@@ -41,7 +41,10 @@ def _stale(target, deps):
 # experiments that are not part of the shipped library: built only with VFMSEG_EXPERIMENTAL=1 (the library then exports the same C ABI;
 # the dispatchers reach them through vfm_tune knobs).  attention_fwd64.hip: a 64-queries-per-wave hand-pipelined forward, 7-9 % faster
 # back to back and no faster inside the train step.
-EXPERIMENTAL = {"attention_fwd64.hip": "VFM_EXPERIMENTAL_FWD64"}
+# gemm_ps.hip (round 3: persistent, two accumulator sets per wave) and gemm_v5.hip (round 4: the vendor kernel's structure - 4 waves, 16x16x32
+# MFMA, two whole K-tile stages, buffer-form LDS-DMA) are the vehicles of the GEMM experiments of DESIGN.md section 5.1: measured, no faster than
+# the ring kernels of gemm_w4.hip, not part of the shipped library.
+EXPERIMENTAL = {"attention_fwd64.hip": "VFM_EXPERIMENTAL_FWD64", "gemm_ps.hip": "VFM_EXPERIMENTAL_GEMM", "gemm_v5.hip": "VFM_EXPERIMENTAL_GEMM"}
 
 
 def build(force=False, verbose=True, only=None):
@@ -55,9 +58,17 @@ def build(force=False, verbose=True, only=None):
 
 def _build_one(LIB, OBJ, variant_defs, force, verbose, exp):
     srcs = sorted(s for s in glob.glob(os.path.join(HERE, "*.hip")) if exp or os.path.basename(s) not in EXPERIMENTAL)
-    defs = (["-D" + d for d in EXPERIMENTAL.values()] if exp else []) + variant_defs
+    defs = (["-D" + d for d in sorted(set(EXPERIMENTAL.values()))] if exp else []) + variant_defs
     hdrs = sorted(glob.glob(os.path.join(HERE, "*.h"))) + [os.path.join(ROOT, "include", "vfmseg_hip.h")]
     os.makedirs(OBJ, exist_ok=True)
+    # the objects of a directory were compiled with ONE set of flags: a build with other flags (VFMSEG_EXPERIMENTAL on / off) starts over
+    stamp, flags = os.path.join(OBJ, ".flags"), " ".join(FLAGS + defs)
+    if not os.path.exists(stamp) or open(stamp).read() != flags:
+        force = True
+        for o in glob.glob(os.path.join(OBJ, "*.o")):
+            os.remove(o)
+        with open(stamp, "w") as f:
+            f.write(flags)
     jobs = []
     objs = []
     for s in srcs:

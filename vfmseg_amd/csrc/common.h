@@ -18,12 +18,14 @@ typedef uint16_t bf16_t;  // raw bits of the half type
 #ifdef VFM_HALF_F16
 typedef _Float16 vfm_h;
 #define VFM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define VFM_MFMA16S(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)   /* 16 x 16 x 32: same rate, the chip holds a higher clock on it */
 #define VFM_DOT2(a, b, acc) __builtin_amdgcn_fdot2(a, b, acc, false)           /* v_dot2_f32_f16 */
 #define VFM_H_ONE 0x3C00u
 #define VFM_HALF_KIND 1
 #else
 typedef __bf16 vfm_h;
 #define VFM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define VFM_MFMA16S(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #define VFM_DOT2(a, b, acc) __builtin_amdgcn_fdot2_f32_bf16(a, b, acc, false)  /* v_dot2c_f32_bf16 */
 #define VFM_H_ONE 0x3F80u
 #define VFM_HALF_KIND 0

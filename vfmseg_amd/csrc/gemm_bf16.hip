@@ -382,8 +382,10 @@ extern "C" int vfm_tune(const char* key, int value) {
     return VFM_OK;
   }
   if (key && strcmp(key, "ps_burst") == 0) {
+#ifdef VFM_EXPERIMENTAL_GEMM
     extern int g_ps_burst;
     g_ps_burst = value;
+#endif
     return VFM_OK;
   }
   if (key && strcmp(key, "gemm_use_ps") == 0) {
@@ -438,8 +440,18 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
 bool vfm_gemm_launch_pp256(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail);  // gemm_pp.hip
 bool vfm_gemm_launch_pp128(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail);  // gemm_pp.hip
 bool vfm_gemm_launch_w4(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail, int waves);  // gemm_w4.hip
+// experiment vehicles, built only with VFMSEG_EXPERIMENTAL=1 (vfmseg_amd/csrc/build.py EXPERIMENTAL): the persistent two-accumulator kernel
+// (gemm_ps.hip, round 3) and the 4-wave 16x16x32 256x256 kernel (gemm_v5.hip, round 4).  Neither beat the ring kernels of gemm_w4.hip
+// (DESIGN.md section 5.1); without them their configs answer VFM_E_UNSUPPORTED and the knobs that select them are ignored.
+#ifdef VFM_EXPERIMENTAL_GEMM
+bool vfm_gemm_launch_v5(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail, int form);  // gemm_v5.hip
 bool vfm_gemm_ps_ok(const vfm_gemm_desc* d, int per);                                                       // gemm_ps.hip
 bool vfm_gemm_launch_ps(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail, int per);         // gemm_ps.hip
+#else
+static bool vfm_gemm_launch_v5(const vfm_gemm_desc*, hipStream_t, bool, const vfm_gemm_desc*, int) { return false; }
+static bool vfm_gemm_ps_ok(const vfm_gemm_desc*, int) { return false; }
+static bool vfm_gemm_launch_ps(const vfm_gemm_desc*, hipStream_t, const vfm_gemm_desc*, int) { return false; }
+#endif
 
 int vfm_gemm_bf16_impl(const vfm_gemm_desc* d0, hipStream_t s) {
   // A few rows past a 128-row boundary (M = B*1024 patch tokens + B [cls] tokens) would cost a whole extra row of
@@ -609,6 +621,14 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
       VFM_CHECK(d->K >= 128 && d->K % 64 == 0 && (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31), VFM_E_UNSUPPORTED,
                 "vfm_gemm(bf16): the 192x256 kernel needs K >= 128 and operands spanning < 4 GiB");
       fd = vfm_gemm_launch_w4(d, s, vec, tail, cfg == 39 ? 6 : 7);
+      break;
+    case 50:   // 256 x 256 tiles, 4 waves, 16x16x32 MFMA, two whole K-tile stages (gemm_v5.hip)
+#ifndef VFM_EXPERIMENTAL_GEMM
+      VFM_FAIL(VFM_E_UNSUPPORTED, "vfm_gemm(bf16): config 50 (gemm_v5.hip) is an experiment: build with VFMSEG_EXPERIMENTAL=1");
+#endif
+      VFM_CHECK(d->K >= 128 && d->K % 64 == 0 && (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31), VFM_E_UNSUPPORTED,
+                "vfm_gemm(bf16): the 16x16x32 256x256 kernel needs K >= 128 and operands spanning < 4 GiB");
+      fd = vfm_gemm_launch_v5(d, s, vec, tail, 0);
       break;
     case 37:
     case 38:

@@ -101,6 +101,34 @@ struct IC {
   static constexpr int value = V;
 };
 
+// Accumulator views: what the wave-tile epilogues need of a wave's accumulators is "write 32 x 32 block (bm, j) into rows [s*32, s*32+32),
+// columns [j*32, j*32+32) of the per-wave LDS image".  Acc32: the tile is (MI x NI) blocks of v_mfma_f32_32x32x16 (16 registers per block,
+// register r of lane (fr, fh) = row (r&3) + 8 (r>>2) + 4 fh, column fr).  Acc16: the same tile as (2 MI x 2 NI) blocks of
+// v_mfma_f32_16x16x32 (4 registers per block, register r of lane (fc, fq) = row 4 fq + r, column fc).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int MI, int NI>
+struct Acc32 {
+  f32x16 (&a)[MI][NI];
+  __device__ __forceinline__ void dump(float* img, int LD, int s, int bm, int j, int lane) const {
+    const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) img[(s * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LD + j * 32 + fr] = a[bm][j][r];
+  }
+};
+template <int MI16, int NI16>
+struct Acc16 {
+  f32x4v (&a)[MI16][NI16];
+  __device__ __forceinline__ void dump(float* img, int LD, int s, int bm, int j, int lane) const {
+    const int fc = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+      for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) img[(s * 32 + a2 * 16 + fq * 4 + r) * LD + j * 32 + b2 * 16 + fc] = a[2 * bm + a2][2 * j + b2][r];
+  }
+};
+
 __device__ __forceinline__ float erf_fast(float x) {  // Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7
   const float ax = fabsf(x);
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
@@ -127,13 +155,12 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
 
 // RES: 0 none, 1 fp32 residual, 2 bf16 residual.  MODE: VFM_EP_*; modes 3/4 read a bf16 aux.  CDT: dtype of C.  HASC2: bf16 copy of the
 // pre-activation value.
-template <int MODE, int CDT, int RES, bool HASC2, int MI, int NI, int GROUP>
-__device__ __forceinline__ void epi_fast(const EpiParams& e, long zoff, f32x16 (&acc)[MI][NI], float* img, int lane, long m_base,
+template <int MODE, int CDT, int RES, bool HASC2, int MI, int NI, int GROUP, class ACC>
+__device__ __forceinline__ void epi_fast(const EpiParams& e, long zoff, const ACC& acc, float* img, int lane, long m_base,
                                          long n_base, long M, long N) {
   constexpr int WN = NI * 32, LD = WN + 4, LPR = WN / 4, RPP = 64 / LPR, PPS = 32 / RPP, NP = MI * PPS, NG = MI / GROUP;
   static_assert(MI % GROUP == 0 && NG <= 4, "slab grouping");
   constexpr bool AUX = (MODE == VFM_EP_MUL_GELU_GRAD || MODE == VFM_EP_MUL || MODE == VFM_EP_MUL_QGELU_GRAD);
-  const int fr = lane & 31, fh = lane >> 5;
   const int rr = lane / LPR, cc = (lane % LPR) * 4;
   const long n = n_base + cc;
   const bool n_ok = n < N;  // N % 4 == 0 on the vector path
@@ -147,10 +174,7 @@ __device__ __forceinline__ void epi_fast(const EpiParams& e, long zoff, f32x16 (
 #pragma unroll
     for (int s = 0; s < GROUP; ++s)
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          img[(s * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LD + j * 32 + fr] = acc[gi * GROUP + s][j][r];
+      for (int j = 0; j < NI; ++j) acc.dump(img, LD, s, gi * GROUP + s, j, lane);
   };
   dump(IC<0>{});
 
@@ -283,13 +307,12 @@ __device__ __forceinline__ uint32_t pack_bf16x2(f32x2 v) {
 }
 __device__ __forceinline__ f32x2 unpack_bf16x2(uint32_t w) { return f32x2{h16_lo(w), h16_hi(w)}; }
 
-template <int MODE, int CDT, int RES, int C2MODE, int MI, int NI, int GROUP>
-__device__ __forceinline__ void epi_fast8(const EpiParams& e, long zoff, f32x16 (&acc)[MI][NI], float* img, int lane, long m_base,
+template <int MODE, int CDT, int RES, int C2MODE, int MI, int NI, int GROUP, class ACC>
+__device__ __forceinline__ void epi_fast8(const EpiParams& e, long zoff, const ACC& acc, float* img, int lane, long m_base,
                                           long n_base, long M, long N) {
   constexpr int WN = NI * 32, LD = WN + 4, LPR = WN / 8, RPP = 64 / LPR, PPS = 32 / RPP, NP = MI * PPS, NG = MI / GROUP;
   static_assert(MI % GROUP == 0 && NG <= 4, "slab grouping");
   constexpr bool AUX = (MODE == VFM_EP_MUL_GELU_GRAD || MODE == VFM_EP_MUL || MODE == VFM_EP_MUL_QGELU_GRAD);
-  const int fr = lane & 31, fh = lane >> 5;
   const int rr = lane / LPR, cc = (lane % LPR) * 8;
   const long n = n_base + cc;
   const bool n_ok = n < N;  // N % 8 == 0 on this path
@@ -312,10 +335,7 @@ __device__ __forceinline__ void epi_fast8(const EpiParams& e, long zoff, f32x16 
 #pragma unroll
     for (int s = 0; s < GROUP; ++s)
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          img[(s * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LD + j * 32 + fr] = acc[gi * GROUP + s][j][r];
+      for (int j = 0; j < NI; ++j) acc.dump(img, LD, s, gi * GROUP + s, j, lane);
   };
   dump(IC<0>{});
 
@@ -420,11 +440,10 @@ __device__ __forceinline__ void epi_fast8(const EpiParams& e, long zoff, f32x16 
 }
 
 // any other combination: compact (rolled) pass loop around the generic epi_store4
-template <int MI, int NI, int GROUP>
-__device__ __forceinline__ void epi_generic(const EpiParams& e, long zoff, f32x16 (&acc)[MI][NI], float* img, int lane, long m_base,
+template <int MI, int NI, int GROUP, class ACC>
+__device__ __forceinline__ void epi_generic(const EpiParams& e, long zoff, const ACC& acc, float* img, int lane, long m_base,
                                             long n_base, long M, long N) {
   constexpr int WN = NI * 32, LD = WN + 4, LPR = WN / 4, RPP = 64 / LPR, PPS = 32 / RPP, NG = MI / GROUP;
-  const int fr = lane & 31, fh = lane >> 5;
   const int rr = lane / LPR, cc = (lane % LPR) * 4;
   const long n = n_base + cc;
   auto group = [&](auto Gc) {
@@ -432,10 +451,7 @@ __device__ __forceinline__ void epi_generic(const EpiParams& e, long zoff, f32x1
 #pragma unroll
     for (int s = 0; s < GROUP; ++s)
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          img[(s * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LD + j * 32 + fr] = acc[gi * GROUP + s][j][r];
+      for (int j = 0; j < NI; ++j) acc.dump(img, LD, s, gi * GROUP + s, j, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
@@ -464,9 +480,9 @@ __device__ __forceinline__ bool epi_vec8_ok(const EpiParams& e, long zoff, long 
   return ok;
 }
 
-template <int MI, int NI, int GROUP>
-__device__ __forceinline__ void epi_wave_tile(const EpiParams& e, long zoff, f32x16 (&acc)[MI][NI], float* img, int lane, long m_base,
-                                              long n_base, long M, long N) {
+template <int MI, int NI, int GROUP, class ACC>
+__device__ __forceinline__ void epi_wave_tile_acc(const EpiParams& e, long zoff, const ACC& acc, float* img, int lane, long m_base,
+                                                  long n_base, long M, long N) {
   const int mode = e.ep_mode;
   const bool plain = !e.C2 && !e.residual;
   if (epi_vec8_ok(e, zoff, N)) {   // eight columns per lane, packed arithmetic: every shape of the four backbones
@@ -503,21 +519,23 @@ __device__ __forceinline__ void epi_wave_tile(const EpiParams& e, long zoff, f32
     epi_generic<MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
 }
 
-// unaligned outputs (N % 4 != 0, odd leading dims ...): same LDS image, one element per lane and step, rolled loop
 template <int MI, int NI, int GROUP>
-__device__ __forceinline__ void epi_scalar(const EpiParams& e, long zoff, f32x16 (&acc)[MI][NI], float* img, int lane, long m_base,
-                                           long n_base, long M, long N) {
+__device__ __forceinline__ void epi_wave_tile(const EpiParams& e, long zoff, f32x16 (&acc)[MI][NI], float* img, int lane, long m_base,
+                                              long n_base, long M, long N) {
+  epi_wave_tile_acc<MI, NI, GROUP>(e, zoff, Acc32<MI, NI>{acc}, img, lane, m_base, n_base, M, N);
+}
+
+// unaligned outputs (N % 4 != 0, odd leading dims ...): same LDS image, one element per lane and step, rolled loop
+template <int MI, int NI, int GROUP, class ACC>
+__device__ __forceinline__ void epi_scalar_acc(const EpiParams& e, long zoff, const ACC& acc, float* img, int lane, long m_base,
+                                               long n_base, long M, long N) {
   constexpr int WN = NI * 32, LD = WN + 4, NG = MI / GROUP;
-  const int fr = lane & 31, fh = lane >> 5;
   auto group = [&](auto Gc) {
     constexpr int gi = decltype(Gc)::value;
 #pragma unroll
     for (int s = 0; s < GROUP; ++s)
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          img[(s * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * LD + j * 32 + fr] = acc[gi * GROUP + s][j][r];
+      for (int j = 0; j < NI; ++j) acc.dump(img, LD, s, gi * GROUP + s, j, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
@@ -533,6 +551,12 @@ __device__ __forceinline__ void epi_scalar(const EpiParams& e, long zoff, f32x16
   if constexpr (NG > 1) group(IC<1>{});
   if constexpr (NG > 2) group(IC<2>{});
   if constexpr (NG > 3) group(IC<3>{});
+}
+
+template <int MI, int NI, int GROUP>
+__device__ __forceinline__ void epi_scalar(const EpiParams& e, long zoff, f32x16 (&acc)[MI][NI], float* img, int lane, long m_base,
+                                           long n_base, long M, long N) {
+  epi_scalar_acc<MI, NI, GROUP>(e, zoff, Acc32<MI, NI>{acc}, img, lane, m_base, n_base, M, N);
 }
 
 // ------------------------------------------------------------------------------------------------ skinny tail

@@ -36,6 +36,32 @@ def _pad64(n):
     return (n + 63) // 64 * 64
 
 
+# ------------------------------------------------------------------------------------------------ weight-gradient side stream
+# The decoder heads' weight and bias gradients are ~30 small launch-latency-bound GEMMs (split-K over the tokens, 64-128 blocks, ~19 us
+# each for a microsecond of arithmetic) plus their slab reduces and column sums: 0.9 ms of a 15.7-ms step, and nothing in the backward
+# pass waits for them - they only feed the optimiser.  They are issued on a SIDE stream behind an event, next to the input-gradient
+# chain that is the critical path (the chip is mostly idle under those small kernels); the main stream joins it before anything reads the
+# flat gradient buffer (DP bucket all-reduce, AMP overflow check, AdamW): join_wgrad_stream().  Same kernels, same arguments: results
+# are unchanged.  VFMSEG_WGRAD_STREAM=0 keeps everything on one stream.
+_WG = {"stream": None, "used": False}
+
+
+def wgrad_stream():
+    import os
+    if os.environ.get("VFMSEG_WGRAD_STREAM", "1") == "0":
+        return None
+    if _WG["stream"] is None:
+        _WG["stream"] = torch.cuda.Stream()
+    return _WG["stream"]
+
+
+def join_wgrad_stream():
+    """The current stream waits for the weight-gradient work issued so far (no-op when there is none)."""
+    if _WG["used"]:
+        torch.cuda.current_stream().wait_stream(_WG["stream"])
+        _WG["used"] = False
+
+
 # ------------------------------------------------------------------------------------------------ weight layouts
 # Each trainable weight is packed into the GEMM's B operand [N, K] (K contiguous) and its gradient un-packed.
 #   linear / conv1x1 : param [N, K(,1,1)]                      -> B[n, k]
@@ -295,6 +321,32 @@ class LinearFn(torch.autograd.Function):
                 ops.gemm(g, wp, dx, trans_b=True, kb_rows=N)   # dX = g @ W: the packed weight [N, Kp] is the [K, N'] operand
             else:
                 ops.gemm(gv, wp, dx, trans_b=True)
+        # bias / weight gradients: off the critical path, on the side stream when every result lands in the flat gradient buffer
+        side = None
+        if is_half(cd) and dy.is_cuda and all(direct_grad_target(p_) is not None for p_ in
+                                              ([ctx.bias_param] if (ctx.has_bias and ctx.needs_input_grad[2]) else []) +
+                                              [w for i, w in enumerate(weights) if ctx.needs_input_grad[4 + i]]):
+            side = wgrad_stream()
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())      # g (and x) are complete
+            g.record_stream(side), x.record_stream(side)
+            if not _WG["used"]:   # whoever runs this backward pass (a test, a tool) reads gradients behind it: join at its end
+                torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
+            _WG["used"] = True
+            ops.WS_SCOPE[0] = "wgrad"      # (the shared scratch of the main stream's kernels must not be written from here)
+            try:
+                with torch.cuda.stream(side):
+                    dbias, dws = LinearFn._param_grads(ctx, g, gv, x, weights, dims, layouts, bias_tile, cd, M, N, Kp, npad)
+            finally:
+                ops.WS_SCOPE[0] = "main"
+        else:
+            dbias, dws = LinearFn._param_grads(ctx, g, gv, x, weights, dims, layouts, bias_tile, cd, M, N, Kp, npad)
+        return (dx, d_res, dbias, None) + tuple(dws)
+
+
+def _param_grads_impl(ctx, g, gv, x, weights, dims, layouts, bias_tile, cd, M, N, Kp, npad):
+        """(dbias, [dW...]) of one linear: column sums of g and g^T x; None where the result was accumulated into the flat buffer."""
+        dy = g
         dbias = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             btgt = direct_grad_target(ctx.bias_param) if ctx.bias_param is not None else None
@@ -328,7 +380,7 @@ class LinearFn(torch.autograd.Function):
                     if tgt is not None and layouts[0] in ("linear", "conv1x1") and Kp == dims[0][1]:
                         # the split-K combine adds straight into the parameter's slot of the flat gradient buffer
                         ops.slab_reduce(slabs, N, tgt, Kp, 1, accumulate=True)
-                        return (dx, d_res, dbias, None, None)
+                        return dbias, dws
                     ops.colsum(slabs.view(kch, npad * Kp), gw.view(npad * Kp))
                 else:
                     ops.gemm_splitk_tn(g, x, gw.view(1, npad, Kp), 1)
@@ -339,7 +391,9 @@ class LinearFn(torch.autograd.Function):
                 if ctx.needs_input_grad[4 + i]:
                     dws[i] = _unpack_grad(gw[r0:r0 + d[0]], l, w)
                 r0 += d[0]
-        return (dx, d_res, dbias, None) + tuple(dws)
+        return dbias, dws
+
+LinearFn._param_grads = staticmethod(_param_grads_impl)
 
 
 def _cast_new(t, dtype):

@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from . import functional as Fh
 from . import ops
-from .precision import compute_dtype
+from .precision import compute_dtype, is_half
 from .registry import MODELS
 
 
@@ -121,6 +121,21 @@ class BaseDecodeHead(nn.Module):
         return out
 
 
+def _fp32_on_fp32_taps(fn):
+    """A head handed fp32 feature taps while a 16-bit mode is active runs in fp32 (precision.eval_heads_fp32: the fp16 mode's predictions)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, fp, *a, **k):
+        if fp.xcat.dtype == torch.float32 and is_half(compute_dtype()):
+            from .precision import compute_as
+            import os
+            with compute_as(torch.float32, split3=os.environ.get("VFMSEG_FP16_EVAL_HEADS", "fp32") != "f32mfma"):
+                return fn(self, fp, *a, **k)
+        return fn(self, fp, *a, **k)
+    return wrapped
+
+
 @MODELS.register_module()
 class LinearHead(BaseDecodeHead):
     def __init__(self, interpolate_mode="bilinear", **kwargs):
@@ -147,6 +162,7 @@ class LinearHead(BaseDecodeHead):
         self.bn_sync = None  # callable(tensor) all-reducing in place over the DP group (set by vfmseg_amd.parallel)
         self.bn_world = 1
 
+    @_fp32_on_fp32_taps
     def forward_tokens(self, fp):
         cd = compute_dtype()
         B, P = fp.B, fp.hp * fp.wp
@@ -334,6 +350,7 @@ class VFMHead(BaseDecodeHead):
                 ok = y1 % s_ == 0 and x1 % s_ == 0 and H % s_ == 0 and W % s_ == 0
         return ok and len(boxes) > 0
 
+    @_fp32_on_fp32_taps
     def forward_tokens(self, fp, ctx_nchw, ctx_windows=None):
         """fp: HR feature pack; ctx_nchw: fp32 [B,19,Hc,Wc] coarse logits (no gradient, as in the reference) - or ctx_windows = (seg, boxes):
         the context of pack image j * Bimg + b is window boxes[j] = (y1, y2, x1, x2) of the full-size map seg[b] (see ctx_windows_ok; saves

@@ -181,6 +181,8 @@ class OptimWrapper:
         # host enqueue time (10.4 vs 12.2 ms of a 15.6-ms step; tools/scratch/_host_profile_step.py)
         with torch.autograd.set_multithreading_enabled(False):
             loss.backward()
+        from .functional import join_wgrad_stream
+        join_wgrad_stream()   # the heads' weight gradients were issued on a side stream: everything below reads the flat gradient buffer
 
     def update_params(self, loss):
         self._backward(loss)

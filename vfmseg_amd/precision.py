@@ -38,6 +38,34 @@ def compute_dtype():
     return _compute
 
 
+class compute_as:
+    """`with compute_as(torch.float32):` - the ops inside take fp32 as their compute dtype while the ACTIVE LIBRARY stays what it is
+    (set_compute_dtype would switch libraries: a 16-bit tensor of the current mode could then not be consumed).  Used by the fp16 mode's
+    predictions to run the small decode heads in fp32 on fp32 feature taps (see eval_heads_fp32)."""
+
+    def __init__(self, dt, split3=False):
+        self.dt, self.split3 = dt, split3
+
+    def __enter__(self):
+        global _compute, _split3
+        self.old, _compute, _split3 = (_compute, _split3), self.dt, self.split3
+
+    def __exit__(self, *a):
+        global _compute, _split3
+        _compute, _split3 = self.old
+
+
+def eval_heads_fp32():
+    """fp16 mode, predictions only: the feature taps leave the backbone in fp32 (they are cast from the fp32 residual stream anyway) and the
+    decode heads (5 % of a prediction's FLOPs) run on the exact-fp32 MFMA.  Measured against the reference-made goldens
+    (tests/golden/slide_modes.npz, ms_inference.npz): with fp16 heads the logits sit AT north_star's 1e-3 bound (1.0-1.2e-3: fp16's
+    2^-11 rounding of the taps and of the heads' intermediate maps is not averaged over a deep stack as the backbone's roundings are);
+    with fp32 heads every mode is inside it.  The train step under `--amp` keeps fp16 heads: that is what the reference's autocast
+    computes in.  VFMSEG_FP16_EVAL_HEADS=fp16 turns it off."""
+    import os
+    return _compute == torch.float16 and os.environ.get("VFMSEG_FP16_EVAL_HEADS", "fp32") != "fp16"
+
+
 def is_bf16():
     """True in the 16-bit MFMA configurations (bf16, or fp16 with the twin library)."""
     return _compute in (torch.bfloat16, torch.float16)
