@@ -309,6 +309,54 @@ def parity_leg(device, batch, steps=3, iters=2, modes=("bf16x3", "f32")):
     return out
 
 
+def host_core_budget():
+    """(cores in the affinity mask, cores the cgroup's CPU quota allows - the mask's size where there is no quota)."""
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    share = avail
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()[:2]
+        if q != "max":
+            share = max(1, int(float(q) / float(per) + 0.5))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:   # cgroup v1
+                q, per = int(f.read()), int(g.read())
+            if q > 0:
+                share = max(1, int(q / per + 0.5))
+        except (OSError, ValueError):
+            pass
+    return avail, min(share, avail)
+
+
+def cpu_baseline_guarded(timeout_s=150.0):
+    """cpu_baseline() in a child interpreter under a time limit: a baseline that runs away (a thread count the box cannot serve) must not
+    take the GPU numbers of the line down with it.  Falls back to 16 threads, then gives up with a stated reason."""
+    import subprocess
+    tried = []
+    for threads in (None, "16"):
+        env = dict(os.environ)
+        if threads is not None:
+            env["VFMSEG_CPU_THREADS"] = threads
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], env=env, capture_output=True, text=True,
+                               timeout=timeout_s)
+            sys.stderr.write(r.stderr[-2000:])
+            for ln in reversed(r.stdout.splitlines()):
+                if ln.startswith("{"):
+                    out = json.loads(ln)
+                    if tried:
+                        out["note"] = "; ".join(tried)
+                    return out
+            tried.append(f"threads={threads or 'all'}: rc {r.returncode}, no result")
+        except subprocess.TimeoutExpired:
+            tried.append(f"threads={threads or 'all'}: stopped after {timeout_s:.0f} s")
+    return {"value": None, "unit": "images/s", "cores": None, "kind": "port", "sample": "failed: " + "; ".join(tried)}
+
+
 def cpu_baseline(seconds_cap=40.0, model_kw=None):
     """The oracle (CPU fp32 restatement of the reference path) timed on this box's host cores: one train step
     (forward_train + backward + AdamW on the trainable tensors), B=1, 1024^2 input -> 2 x 512^2 passes."""
@@ -318,16 +366,14 @@ def cpu_baseline(seconds_cap=40.0, model_kw=None):
     from vfmseg_amd.registry import MODELS
     from vfmseg_amd.synth import synth_image, synth_label, synth_like
     import vfmseg_amd  # noqa: F401
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except Exception:
-        avail = os.cpu_count() or 1
-    # every host core this process may run on (its affinity mask), one warm-up step, one timed step.
-    # VFMSEG_CPU_THREADS is an explicit override only (stated in the output when it is in force).
+    avail, share = host_core_budget()
+    # every host core this process may USE - its affinity mask, cut to the cgroup's CPU quota where there is one (a
+    # GPU box grants a share of the host: 256 runnable threads on a 16-core quota take minutes per step) - one warm-up step, one timed
+    # step.  VFMSEG_CPU_THREADS is an explicit override only (stated in the output when it is in force).
     override = os.environ.get("VFMSEG_CPU_THREADS")
-    cores = max(1, min(avail, int(override))) if override else max(1, avail)
+    cores = max(1, min(avail, int(override))) if override else max(1, min(avail, share))
     torch.set_num_threads(cores)
-    print(f"[bench] cpu_baseline: oracle train step on {cores} threads (affinity mask: {avail} cores"
+    print(f"[bench] cpu_baseline: oracle train step on {cores} threads (affinity mask: {avail} cores, cgroup CPU share: {share}"
           + (f", VFMSEG_CPU_THREADS={override}" if override else "") + ") ...", file=sys.stderr, flush=True)
     cfg = presets.dinov2_ms_masked(**(model_kw or {}))  # model_kw: tests shrink the model, not the workload
     bb = cfg["backbone"]["backbone"]
@@ -363,7 +409,7 @@ def cpu_baseline(seconds_cap=40.0, model_kw=None):
     except OSError:
         pass
     out = dict(value=1.0 / dt, unit="images/s", cores=cores, cpu_model=cpu_model, host_cpus=os.cpu_count(), affinity_cores=avail,
-               threads_override=override, kind="port",
+               cgroup_cpu_share=share, threads_override=override, kind="port",
                sample=f"1 warm-up ({t_warm:.1f} s) + 1 timed train step (fwd+bwd+AdamW), B=1, 1024^2 -> 2x512^2 passes, fp32 torch CPU, {dt:.1f} s")
     if model_kw is None and os.environ.get("VFMSEG_CPU_EXTRAS", "1") != "0":
         # the other CPU timings BASELINE.md section 3 lists (bounded samples): configs[0] = DINOv2-L + LinearHead, 1x512^2, forward + CE
@@ -485,6 +531,7 @@ def parse_args(argv=None):
     ap.add_argument("--tune", action="append", default=[], help="kernel tuning knob KEY=INT (vfm_tune), repeatable")
     ap.add_argument("--depth", type=int, default=None, help="backbone depth for launcher / DP rehearsals (default: the config's 24; "
                                                             "any other value marks the line as not the headline metric)")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="internal: print the cpu_baseline object as one JSON line (no GPU work)")
     ap.add_argument("--rehearse-launcher", action="store_true", help="N-rank plumbing without the model (runs on CPU/gloo): see _launcher_rehearsal")
     ap.add_argument("--launch-timeout", type=float, default=None, help="launcher parent: stop all ranks after this many seconds")
     return ap.parse_args(argv)
@@ -492,6 +539,9 @@ def parse_args(argv=None):
 
 def main():
     a = parse_args()
+    if a.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()), flush=True)
+        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: this process becomes the launcher (the reference's tools/dist_train.sh:9-17 role).  It starts N
         # fresh interpreters of this file with the torchrun env, relays rank 0's JSON line and returns the worst exit code.  It has not
@@ -619,7 +669,7 @@ def main():
         g = timer.summary(kinds=("gemm",), region="backbone", min_flops=8e9) or allg
         if g is not None:
             traffic, traffic_src = None, None
-            for tj_name in ("r03_pmc_gemm_traffic.json", "r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
+            for tj_name in ("r04_pmc_gemm_traffic.json", "r03_pmc_gemm_traffic.json", "r02_pmc_gemm_traffic.json", "r01_pmc_gemm_traffic.json"):
                 tj = os.path.join(ROOT, "profiles", tj_name)
                 if os.path.exists(tj) and a.workload == "ms1024":  # PMC counters cannot be read from inside the timed run: committed rocprofv3 --pmc passes
                     with open(tj) as f:
@@ -683,7 +733,7 @@ def main():
                 out["amp_fp16"] = {"error": repr(e)}
         if world == 1 and not a.no_cpu_baseline and a.workload == "ms1024":
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline_guarded()
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}

@@ -43,6 +43,8 @@ def _pad64(n):
 # chain that is the critical path (the chip is mostly idle under those small kernels); the main stream joins it before anything reads the
 # flat gradient buffer (DP bucket all-reduce, AMP overflow check, AdamW): join_wgrad_stream().  Same kernels, same arguments: results
 # are unchanged.  VFMSEG_WGRAD_STREAM=0 keeps everything on one stream.
+# (Tried and dropped, round 4: the LR decode head's forward - hence, by autograd's stream rule, its backward - on a second stream beside the
+# detail head's backward, which does not depend on it: neutral, 15.17 vs 15.15 ms/step, profiles/r04_ab_step_head_stream.log.)
 _WG = {"stream": None, "used": False}
 
 
@@ -333,12 +335,8 @@ class LinearFn(torch.autograd.Function):
             if not _WG["used"]:   # whoever runs this backward pass (a test, a tool) reads gradients behind it: join at its end
                 torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
             _WG["used"] = True
-            ops.WS_SCOPE[0] = "wgrad"      # (the shared scratch of the main stream's kernels must not be written from here)
-            try:
-                with torch.cuda.stream(side):
-                    dbias, dws = LinearFn._param_grads(ctx, g, gv, x, weights, dims, layouts, bias_tile, cd, M, N, Kp, npad)
-            finally:
-                ops.WS_SCOPE[0] = "main"
+            with torch.cuda.stream(side):     # (ops.workspace hands every stream scratch of its own)
+                dbias, dws = LinearFn._param_grads(ctx, g, gv, x, weights, dims, layouts, bias_tile, cd, M, N, Kp, npad)
         else:
             dbias, dws = LinearFn._param_grads(ctx, g, gv, x, weights, dims, layouts, bias_tile, cd, M, N, Kp, npad)
         return (dx, d_res, dbias, None) + tuple(dws)

@@ -32,12 +32,10 @@ class region:
         REGION.pop()
 
 
-WS_SCOPE = ["main"]   # launches issued on another stream than the main one use scratch of their own (functional.wgrad_stream sets "wgrad")
-
-
 def workspace(nfloats, device, tag="default"):
-    """Grow-only fp32 scratch per (device, tag, stream scope); kernels never allocate."""
-    key = (str(device), tag, WS_SCOPE[0])
+    """Grow-only fp32 scratch per (device, tag, STREAM); kernels never allocate.  Per stream: the decoder heads' weight gradients run on a
+    side stream (functional.wgrad_stream) - kernels that may run concurrently must not share scratch."""
+    key = (str(device), tag, L.stream())
     t = _ws_cache.get(key)
     if t is None or t.numel() < nfloats:
         t = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)
