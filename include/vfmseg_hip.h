@@ -218,6 +218,14 @@ int vfm_attn_bwd(const vfm_attn_desc* d, void* stream);
  * computed as hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation, softmax and output in fp32: the exact-fp32 attention of the
  * parity configuration (rein/models/backbones/dino_layers/attention.py:73-89 in fp32) to ~1e-5 at MFMA speed.  lse as vfm_attn_fwd. */
 int vfm_attn_fwd_x3(const vfm_attn_desc* d, long lo_off, void* stream);
+/* ... and its backward: q / k / v / o / dout and dq / dk / dv fp32 (dt = VFM_F32), lse from the forward, delta as vfm_attn_bwd (only its
+ * first B*H*nq floats are used).  q3 / k3 / v3 (bf16 [rows, ld3]) and do3 (bf16 [rows, ld_do3]) = the vfm_split3(pattern 1) images of q / k / v / dout, hi
+ * half of head h at columns h*64.., lo half at lo_off (lo_off_do3) + h*64.. (q3 / k3 / v3 may be column offsets into ONE split of a packed qkv buffer): the streamed operands of the two kernels (dQ streams K, V; dK/dV streams Q, dO); the
+ * stationary rows are read in fp32 and split in registers, P and dS are split from the fp32 accumulators.  Five products, each as
+ * hi*hi + hi*lo + lo*hi on the bf16 MFMA: the exact-fp32 attention backward of the parity configuration
+ * (rein/models/backbones/dino_layers/attention.py:73-89 under autograd, in fp32) to ~1e-5 at MFMA speed. */
+int vfm_attn_bwd_x3(const vfm_attn_desc* d, const void* q3, const void* k3, const void* v3, long ld3, long lo_off, const void* do3,
+                    long ld_do3, long lo_off_do3, void* stream);
 
 /* ---- SAM (ViTDet) windowed attention with decomposed relative-position bias (sam_vit.py:273-430) --------------
  * The bias q.Rh[qh,kh] + q.Rw[qw,kw] is folded into augmented operands so the attention is batched GEMMs + softmax:

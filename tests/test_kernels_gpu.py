@@ -668,6 +668,56 @@ def test_attention_split_bf16x3_forward(nq_extra, nk_extra, nq, nk, B, H):
     assert e < 5e-5 and el < 2e-5 * max(1.0, ref_lse.abs().max().item()) + 1e-4   # (spiked keys: |lse| ~ 30)
 
 
+@pytest.mark.parametrize("nq_extra,nk_extra,nq,nk,B,H", [(1, 1, 200, 200, 2, 3), (0, 0, 130, 70, 2, 3), (1, 1, 1024, 1024, 2, 4), (0, 0, 256, 320, 1, 8)])
+def test_attention_split_bf16x3_backward(nq_extra, nk_extra, nq, nk, B, H):
+    """vfm_attn_bwd_x3 (bf16x3 mode: fp32 q / k / v / o / dout -> fp32 dq / dk / dv, the five products as hi*hi + hi*lo + lo*hi on the bf16
+    MFMA) against float64 autograd of softmax attention: ~1e-5 (the plain bf16 backward sits at ~1e-2).  q, k, v as column slices of one
+    packed buffer (as the backbones pass them), gradients written into column slices of a packed gradient buffer; ragged tails, the extra
+    token as the last row of every sequence."""
+    from vfmseg_amd.precision import set_compute_dtype
+    d, hd = 64, H * 64
+    same = nq == nk and nq_extra == nk_extra
+    q = rnd(B * nq + B * nq_extra, hd, seed=52)
+    k = rnd(B * nk + B * nk_extra, hd, seed=53)
+    k[B * nk // 2: B * nk // 2 + 5] *= 3.0
+    v = rnd(B * nk + B * nk_extra, hd, seed=54)
+    do = rnd(B * nq + B * nq_extra, hd, seed=55)
+
+    def gather(t, n, ne):
+        main = t[: B * n].reshape(B, n, H, d)
+        if ne:
+            main = torch.cat([main, t[B * n:].reshape(B, 1, H, d)], 1)
+        return main.permute(0, 2, 1, 3).double()
+
+    def scatter(g, n, ne):   # [B, H, n + ne, d] -> token-major [rows, hd] in the cls-last order
+        g = g.permute(0, 2, 1, 3)
+        return torch.cat([g[:, :n].reshape(B * n, hd), g[:, n:].reshape(B * ne, hd)], 0) if ne else g.reshape(B * n, hd)
+
+    qq, kk, vv = (gather(t, n, ne).requires_grad_(True) for t, n, ne in ((q, nq, nq_extra), (k, nk, nk_extra), (v, nk, nk_extra)))
+    sc = (qq @ kk.transpose(-1, -2)) * d ** -0.5
+    out = sc.softmax(-1) @ vv
+    out.backward(gather(do, nq, nq_extra))
+    ref = [scatter(qq.grad, nq, nq_extra), scatter(kk.grad, nk, nk_extra), scatter(vv.grad, nk, nk_extra)]
+    o_tok = scatter(out.detach(), nq, nq_extra).float().to(DEV)
+    lse = torch.logsumexp(sc.detach(), -1).float().to(DEV).contiguous()
+    if same:
+        packed = torch.cat([q, k, v], 1).to(DEV)
+        qd, kd, vd = packed[:, :hd], packed[:, hd:2 * hd], packed[:, 2 * hd:]
+        grads = torch.full(packed.shape, float("nan"), device=DEV)
+        dq, dk, dv = grads[:, :hd], grads[:, hd:2 * hd], grads[:, 2 * hd:]
+    else:
+        qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+        dq, dk, dv = (torch.full(t.shape, float("nan"), device=DEV) for t in (q, k, v))
+    set_compute_dtype("bf16x3")
+    try:
+        ops.attn_bwd(qd, kd, vd, o_tok, lse, do.to(DEV), dq, dk, dv, B, H, d, nq, nq_extra, nk, nk_extra, d ** -0.5)
+    finally:
+        set_compute_dtype("bf16")
+    errs = [relerr(a, b) for a, b in zip((dq, dk, dv), ref)]
+    print(f"[parity] split-bf16 attention bwd nq {nq}+{nq_extra} nk {nk}+{nk_extra}: dq / dk / dv rel err {errs[0]:.2e} / {errs[1]:.2e} / {errs[2]:.2e}")
+    assert max(errs) < 1e-4
+
+
 @pytest.mark.skipif(os.environ.get("VFMSEG_EXPERIMENTAL", "0") != "1", reason="attention_fwd64.hip is built only with VFMSEG_EXPERIMENTAL=1")
 def test_attention_fwd64_experimental():
     # the 64-queries-per-wave forward (vfm_tune attn_fwd64, off by default) against the regular kernel on the backbone shape

@@ -133,6 +133,7 @@ SIGNATURES = {
     "vfm_attn_fwd": [C.POINTER(AttnDesc), vp],
     "vfm_attn_fwd_x3": [C.POINTER(AttnDesc), cl, vp],
     "vfm_attn_bwd": [C.POINTER(AttnDesc), vp],
+    "vfm_attn_bwd_x3": [C.POINTER(AttnDesc), vp, vp, vp, cl, cl, vp, cl, cl, vp],
     "vfm_sam_relpos_table": [vp, ci, ci, ci, vp, vp],
     "vfm_sam_attn_prep": [vp, ci, cl, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp],
     "vfm_softmax_rows": [vp, cl, vp, ci, cl, cl, ci, ci, vp],

@@ -683,6 +683,30 @@ def _attn_desc(q, k, v, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale,
     return a
 
 
+def _qkv_split3(q, k, v, hd):
+    """q, k, v fp32 [rows, hd] that are the three column thirds of ONE packed [rows, 3 hd] buffer (self-attention: the QKV projection's
+    output) -> the vfm_split3(pattern 1) image of the whole buffer, bf16 [rows, 9 hd]: hi of q / k / v at columns 0 / hd / 2 hd, lo at
+    3 hd + the same.  Kept on the buffer object (views share their base) so that the backward reuses the forward's split; None when the
+    operands are not laid out that way."""
+    base = q._base if q._base is not None else None
+    if (base is None or k._base is not base or v._base is not base or q.stride(1) != 1 or q.stride(0) != 3 * hd or k.stride(0) != 3 * hd
+            or v.stride(0) != 3 * hd or k.storage_offset() - q.storage_offset() != hd or v.storage_offset() - q.storage_offset() != 2 * hd
+            or q.storage_offset() % (3 * hd) != 0):
+        return None
+    rows = q.shape[0]
+    hit = getattr(base, "_vfm_qkv3", None)
+    key = (base._version, q.storage_offset(), rows)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    whole = q.as_strided((rows, 3 * hd), (3 * hd, 1), q.storage_offset())
+    full = split3(whole, 1)
+    try:
+        base._vfm_qkv3 = (key, full)
+    except AttributeError:
+        pass
+    return full
+
+
 _attn_bwd_ws = {}
 
 
@@ -700,10 +724,14 @@ def attn_fwd(q, k, v, o, lse, B, H, d, nq_main, nq_extra, nk_main, nk_extra, sca
     lib = L.load()
     if q.dtype == torch.float32 and d == 64 and _split3_on() and k.shape[1] == H * d and v.shape[1] == H * d:
         # bf16x3 mode: K and V as split bf16 operands ([hi | lo | hi] per row), Q split in the kernel, fp32 softmax and output
-        k3, v3 = split3(k, 1), split3(v, 1)
+        full = _qkv_split3(q, k, v, H * d)
+        if full is not None:
+            k3, v3, lo = full[:, H * d:], full[:, 2 * H * d:], 3 * H * d
+        else:
+            k3, v3, lo = split3(k, 1), split3(v, 1), H * d
         a = _attn_desc(q, k3, v3, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, lse)
         a.dt = L.dt_of(q)
-        L.check(lib.vfm_attn_fwd_x3(C.byref(a), H * d, L.stream()), "vfm_attn_fwd_x3")
+        L.check(lib.vfm_attn_fwd_x3(C.byref(a), lo, L.stream()), "vfm_attn_fwd_x3")
         return o
     a = _attn_desc(q, k, v, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, lse)
     fin = None
@@ -722,6 +750,19 @@ def attn_bwd(q, k, v, o, lse, dout, dq, dk, dv, B, H, d, nq_main, nq_extra, nk_m
     a.dq, a.dk, a.dv = L.ptr(dq), L.ptr(dk), L.ptr(dv)
     a.ld_dq, a.ld_dk, a.ld_dv = dq.stride(0), dk.stride(0), dv.stride(0)
     a.delta = L.ptr(_attn_bwd_delta(q, B, H, nq_main + nq_extra))
+    if (q.dtype == torch.float32 and d == 64 and _split3_on() and q.shape[1] == H * d and k.shape[1] == H * d and v.shape[1] == H * d
+            and dout.shape[1] == H * d and dq.dtype == torch.float32):
+        # bf16x3 mode: the five products on split-bf16 operands (streamed operands arrive split; stationary rows, P and dS are split in the kernels)
+        g3 = split3(dout, 1)
+        full = _qkv_split3(q, k, v, H * d)
+        if full is not None:       # q / k / v are the column thirds of one packed buffer: ONE split (kept from the forward) serves all three
+            q3, k3, v3, lo = full[:, :H * d], full[:, H * d:], full[:, 2 * H * d:], 3 * H * d
+        else:
+            q3, k3, v3, lo = split3(q, 1), split3(k, 1), split3(v, 1), H * d
+            assert q3.stride(0) == k3.stride(0) == v3.stride(0)
+        L.check(lib.vfm_attn_bwd_x3(C.byref(a), L.ptr(q3), L.ptr(k3), L.ptr(v3), q3.stride(0), lo, L.ptr(g3), g3.stride(0), H * d, L.stream()),
+                "vfm_attn_bwd_x3")
+        return
     fin = None
     if PROFILE is not None and is_half(q.dtype):   # algorithmic: S, dP, dV, dK, dQ = five products = 10 B H Nq Nk d
         fin = PROFILE("attn_bwd", 10.0 * B * H * (nq_main + nq_extra) * (nk_main + nk_extra) * d, REGION[-1])
