@@ -81,6 +81,24 @@ def test_launcher_pins_every_rank_to_its_own_cores(tmp_path):
     assert DL._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
 
 
+def test_cpu_baseline_thread_budget_follows_the_cgroup_quota():
+    """bench.py's cpu_baseline uses the cores this process may USE: the affinity mask cut to the cgroup CPU quota (a GPU box shows 256 CPUs and
+    grants 16: 256 runnable threads there take minutes per oracle step and once took the whole bench line down with them)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_budget", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    avail, share = bench.host_core_budget()
+    assert 1 <= share <= avail == len(os.sched_getaffinity(0))
+    for path, conv in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),):
+        if os.path.exists(path):
+            q = conv(open(path).read())
+            assert share == (avail if q is None else min(avail, max(1, int(q + 0.5))))
+    if os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") and not os.path.exists("/sys/fs/cgroup/cpu.max"):
+        q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        assert share == (avail if q <= 0 else min(avail, max(1, int(q / per + 0.5))))
+
+
 def test_dist_train_sh_keeps_the_reference_argument_order():
     txt = open(os.path.join(ROOT, "tools", "dist_train.sh")).read()
     assert "CONFIG=$1" in txt and "GPUS=$2" in txt and "--launcher pytorch" in txt and '"${@:3}"' in txt

@@ -608,7 +608,7 @@ class DinoEngine:
                 Lp["qkv"].fwd(a1, qkv, bias=Lp["qkv_b"])
             ao = torch.empty(M, D, dtype=cd, device=dev)
             lse = torch.empty(nimg, H, Np + 1, dtype=torch.float32, device=dev)
-            ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ao, lse, nimg, H, hd, Np, 1, Np, 1, scale)
+            ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ao, lse, nimg, H, hd, Np, 1, Np, 1, scale, keep_split=training)
             xm = torch.empty(M, D, dtype=torch.float32, device=dev)
             Lp["proj"].fwd(ao, xm, bias=Lp["proj_b"], colscale=Lp["g1"], residual=x)
             a2 = torch.empty(M, D, dtype=cd, device=dev)

@@ -544,7 +544,8 @@ class SelfAttnFn(torch.autograd.Function):
         inner = H * d
         o = torch.empty(B * N, inner, dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
-        ops.attn_fwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], o, lse, B, H, d, N, 0, N, 0, d ** -0.5)
+        ops.attn_fwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], o, lse, B, H, d, N, 0, N, 0, d ** -0.5,
+                     keep_split=ctx.needs_input_grad[0])
         ctx.save_for_backward(qkv, o, lse)
         ctx.cfg = (B, N, H, d)
         return o

@@ -719,12 +719,13 @@ def _attn_bwd_delta(q, B, H, nq):
     return delta
 
 
-def attn_fwd(q, k, v, o, lse, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale):
-    """q,k,v,o: 2-D row-major views [rows, >=H*d] (column slices of a packed qkv buffer are fine)."""
+def attn_fwd(q, k, v, o, lse, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, keep_split=False):
+    """q,k,v,o: 2-D row-major views [rows, >=H*d] (column slices of a packed qkv buffer are fine).  keep_split (bf16x3 mode): a backward
+    pass will follow - split the whole packed qkv buffer once and keep the image for it (a prediction splits only k and v)."""
     lib = L.load()
     if q.dtype == torch.float32 and d == 64 and _split3_on() and k.shape[1] == H * d and v.shape[1] == H * d:
         # bf16x3 mode: K and V as split bf16 operands ([hi | lo | hi] per row), Q split in the kernel, fp32 softmax and output
-        full = _qkv_split3(q, k, v, H * d)
+        full = _qkv_split3(q, k, v, H * d) if keep_split else None
         if full is not None:
             k3, v3, lo = full[:, H * d:], full[:, 2 * H * d:], 3 * H * d
         else:
