@@ -939,6 +939,49 @@ def test_adamw(vec4, zero):
     assert relerr(pd, torch.cat([q1, q2]).detach()) < 1e-5
 
 
+def test_launch_plan_replays_the_same_launches_and_samples_them():
+    """ops.Plan / vfm_run_plan: a recorded GEMM -> LayerNorm -> cast -> accumulate-copy sequence gives bit-identical results to the same calls
+    issued one by one, twice in a row; a partial replay (start / count) runs just those entries; an unknown entry kind fails with its index;
+    the library's event sampler (vfm_prof_config / vfm_prof_read) times the sampled GEMM entries."""
+    from vfmseg_amd import lib as L
+    a, b = rnd(300, 256, seed=120).bfloat16().to(DEV), rnd(192, 256, seed=121).bfloat16().to(DEV)
+    bias, w, g = rnd(192, seed=122).to(DEV), (rnd(192, seed=123) * 0.1 + 1).to(DEV), rnd(192, seed=124).to(DEV)
+
+    def bufs():
+        return dict(c=torch.full((300, 192), float("nan"), device=DEV), y=torch.empty(300, 192, dtype=torch.bfloat16, device=DEV),
+                    st=torch.empty(300, 2, device=DEV), z=torch.empty(300, 192, device=DEV), acc=torch.ones(300, 192, device=DEV))
+    r = bufs()
+    ops.gemm(a, b, r["c"], bias=bias)
+    ops.layernorm_fwd(r["c"], w, g, 1e-6, r["y"], r["st"])
+    ops.cast(r["y"], r["z"], w)
+    ops.strided_copy(r["z"], r["acc"], (300, 192), (192, 1), (192, 1), accumulate=True)
+    p = bufs()
+    pl = ops.Plan()
+    pl.gemm(a, b, p["c"], bias=bias)
+    pl.layernorm_fwd(p["c"], w, g, 1e-6, p["y"], p["st"])
+    i_cast = pl.cast(p["y"], p["z"], w)
+    pl.strided_copy(p["z"], p["acc"], (300, 192), (192, 1), (192, 1), accumulate=True)
+    assert len(pl) == 4
+    ops.prof_config(1)
+    try:
+        pl.run()
+        recs = ops.prof_read()
+    finally:
+        ops.prof_config(0)
+    assert [k for k, _, _ in recs] == ["gemm"] and recs[0][1] == 2.0 * 300 * 192 * 256 and recs[0][2] > 0
+    for k in ("c", "y", "st", "z", "acc"):
+        assert torch.equal(p[k], r[k]), k
+    pl.run(start=i_cast, count=1)                       # only the cast again: nothing else moves
+    assert torch.equal(p["acc"], r["acc"]) and torch.equal(p["z"], r["z"])
+    pl.run()                                            # a second full replay accumulates once more
+    assert torch.equal(p["acc"], r["acc"] + r["z"])
+    bad = ops.Plan()
+    bad.cast(p["y"], p["z"])
+    bad.entry(0).kind = 99
+    with pytest.raises(L.HipError, match="entry 0"):
+        bad.run()
+
+
 def test_checkpoint_converters():
     """vfmseg_amd.convert (HIP resize kernels) vs the F.interpolate calls of the reference's tools/convert_models/*."""
     from vfmseg_amd import convert
