@@ -25,7 +25,10 @@
 extern "C" {
 #endif
 
-enum { VFM_F32 = 0, VFM_BF16 = 1, VFM_U8 = 2, VFM_I64 = 3 };
+enum { VFM_F32 = 0, VFM_BF16 = 1, VFM_U8 = 2, VFM_I64 = 3,
+       VFM_SPLIT3 = 4 /* only as vfm_gemm's c_dt (bf16 inputs): C is the split-bf16 image of the result - bf16 [M, >= 3 c_plane], hi at column n,
+                         hi again at c_plane + n, lo = bf16(v - hi) at 2 c_plane + n (vfm_split3 pattern 0): the A operand of the next GEMM of the
+                         bf16x3 mode, written by the producer instead of by a vfm_split3 pass */ };
 enum { VFM_OK = 0, VFM_E_INVAL = -1, VFM_E_SHAPE = -2, VFM_E_ALIGN = -3, VFM_E_HIP = -4, VFM_E_UNSUPPORTED = -5 };
 /* GEMM epilogue modes */
 enum { VFM_EP_NONE = 0, VFM_EP_GELU = 1, VFM_EP_RELU = 2, VFM_EP_MUL_GELU_GRAD = 3, VFM_EP_MUL = 4,
@@ -118,6 +121,12 @@ int vfm_mask_token_bwd(const float* dout, const uint8_t* keep, float* dx, float*
  * output y2 = y * mask2 (LoRA input dropout, peft lora.Linear) ; stats = (mean, rstd) fp32 [rows,2] */
 int vfm_layernorm_fwd(const float* x, long ld_x, const float* w, const float* b, float eps, void* y, int y_dt, long ld_y,
                       float* stats, long rows, long C, void* stream);
+/* bf16x3 mode: LayerNorm whose output goes (also) out as the split-bf16 A operand of the GEMM that consumes it - y3 bf16 [rows, >= 3 plane]:
+ * hi = bf16(y) at column c, hi again at plane + c, lo = bf16(y - hi) at 2 plane + c (what vfm_split3 pattern 0 writes; plane >= C, a
+ * multiple of 64 for the GEMM) - so that no separate vfm_split3 pass reads y back.  y (fp32) may be NULL: then only the split image is
+ * written.  C in {256, 512, 1024, 1280, 2048}.  (rein/models/backbones/dino_layers/block.py:63,75 in the fp32 parity configuration.) */
+int vfm_layernorm_fwd_split3(const float* x, long ld_x, const float* w, const float* b, float eps, float* y, long ld_y, void* y3, long ld3,
+                             long plane, float* stats, long rows, long C, void* stream);
 /* LayerNorm forward fused with the LoRA-branch dropout (peft lora.Linear: lora_dropout(x)): besides y (bf16) it
  * writes mask[row, c] = 0 or 1/(1-p) (bf16; the values vfm_dropout_mask gives for element offset + row*C + c) and
  * y_drop = y * mask.  C % 256 == 0, 16-byte aligned rows. */
@@ -182,6 +191,7 @@ typedef struct vfm_gemm_desc {
   int ep_mode; const void* aux; int aux_dt; long ld_aux;
   void* C2; int c2_dt; long ldc2;
   long batch, stride_a, stride_b, stride_c;
+  long c_plane; /* c_dt == VFM_SPLIT3: columns between the planes of the split image (>= N, a multiple of 8); ldc >= 3 c_plane counts bf16 elements */
   long kb_rows; /* bf16, B given as [K,N] (sb_n == 1): number of valid rows of B (<= K; A must be zero beyond); 0 = K.  With batch > 1 a
                  * positive value counts the rows of ONE matrix that the batches slice along K (split-K); a negative value -r gives
                  * every batch r valid rows of its own (independent problems, e.g. one weight gradient per layer) */
@@ -218,6 +228,9 @@ int vfm_attn_bwd(const vfm_attn_desc* d, void* stream);
  * computed as hi*hi + hi*lo + lo*hi on the bf16 MFMA with fp32 accumulation, softmax and output in fp32: the exact-fp32 attention of the
  * parity configuration (rein/models/backbones/dino_layers/attention.py:73-89 in fp32) to ~1e-5 at MFMA speed.  lse as vfm_attn_fwd. */
 int vfm_attn_fwd_x3(const vfm_attn_desc* d, long lo_off, void* stream);
+/* ... with the output (also) as the split-bf16 A operand of the projection GEMM (o3 bf16 [rows, >= 3 plane], layout as vfm_layernorm_fwd_split3);
+ * d->o may be NULL: then only the split image is written. */
+int vfm_attn_fwd_x3_split(const vfm_attn_desc* d, long lo_off, void* o3, long ld3, long plane, void* stream);
 /* ... and its backward: q / k / v / o / dout and dq / dk / dv fp32 (dt = VFM_F32), lse from the forward, delta as vfm_attn_bwd (only its
  * first B*H*nq floats are used).  q3 / k3 / v3 (bf16 [rows, ld3]) and do3 (bf16 [rows, ld_do3]) = the vfm_split3(pattern 1) images of q / k / v / dout, hi
  * half of head h at columns h*64.., lo half at lo_off (lo_off_do3) + h*64.. (q3 / k3 / v3 may be column offsets into ONE split of a packed qkv buffer): the streamed operands of the two kernels (dQ streams K, V; dK/dV streams Q, dO); the

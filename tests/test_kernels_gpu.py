@@ -718,6 +718,66 @@ def test_attention_split_bf16x3_backward(nq_extra, nk_extra, nq, nk, B, H):
     assert max(errs) < 1e-4
 
 
+def test_bf16x3_producers_write_the_split_operand_image():
+    """bf16x3 predictions: LayerNorm and the split-bf16 attention forward hand their output to the consuming GEMM as the split image
+    [hi | hi | lo] (vfm_layernorm_fwd_split3, vfm_attn_fwd_x3_split) - bit for bit what vfm_split3 makes of the fp32 output, found by
+    ops.split3 on the tensor object; with split_out / o_split = "only" the fp32 copy is not written at all."""
+    from vfmseg_amd.precision import set_compute_dtype
+    set_compute_dtype("bf16x3")
+    try:
+        x = rnd(300, 1024, seed=130).to(DEV) * 3
+        w, b = (rnd(1024, seed=131) * 0.1 + 1).to(DEV), rnd(1024, seed=132).to(DEV)
+        y_ref, st_ref = torch.empty(300, 1024, device=DEV), torch.empty(300, 2, device=DEV)
+        ops.layernorm_fwd(x, w, b, 1e-6, y_ref, st_ref)
+        img_ref = ops.split3(y_ref, 0)
+        for mode in ("also", "only"):
+            y = torch.full((300, 1024), float("nan"), device=DEV)
+            st = torch.empty(300, 2, device=DEV)
+            ops.layernorm_fwd(x, w, b, 1e-6, y, st, split_out=mode)
+            got = ops.split3(y, 0)                     # the registered image, not a new pass
+            assert got.data_ptr() == y._vfm_split3_out[1].data_ptr()
+            assert torch.equal(got.view(torch.int16), img_ref.view(torch.int16)) and torch.equal(st, st_ref)
+            assert torch.equal(y, y_ref) if mode == "also" else bool(torch.isnan(y).all())
+        # attention: B 2, H 3, 200 + 1 tokens
+        B, H, n, d, hd = 2, 3, 200, 64, 192
+        qkv = rnd(B * n + B, 3 * hd, seed=133).to(DEV)
+        o_ref, lse_ref = torch.empty(B * n + B, hd, device=DEV), torch.empty(B, H, n + 1, device=DEV)
+        ops.attn_fwd(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], o_ref, lse_ref, B, H, d, n, 1, n, 1, d ** -0.5)
+        o_img = ops.split3(o_ref, 0)
+        for mode in ("also", "only"):
+            o = torch.full((B * n + B, hd), float("nan"), device=DEV)
+            lse = torch.empty(B, H, n + 1, device=DEV)
+            ops.attn_fwd(qkv[:, :hd], qkv[:, hd:2 * hd], qkv[:, 2 * hd:], o, lse, B, H, d, n, 1, n, 1, d ** -0.5, o_split=mode)
+            assert torch.equal(ops.split3(o, 0).view(torch.int16), o_img.view(torch.int16)) and torch.equal(lse, lse_ref)
+            assert torch.equal(o, o_ref) if mode == "also" else bool(torch.isnan(o).all())
+        # the consumer: a GEMM on the fp32 tensor object picks the image up (the fp32 values are NaN here: a fresh split would poison c)
+        wgt = rnd(64, 1024, seed=134).to(DEV)
+        c = torch.empty(300, 64, device=DEV)
+        ops.gemm(y, wgt, c)
+        assert relerr(c, y_ref.double() @ wgt.double().t()) < 3e-5
+        # a GEMM as the producer (vfm_gemm c_dt VFM_SPLIT3): fc1 + GELU of the backbone shape, a ragged M, and the plain epilogue
+        for (m, n_, k, ep) in ((1370, 4096, 1024, ops.EP_GELU), (333, 512, 256, ops.EP_NONE), (130, 64, 128, ops.EP_GELU)):
+            a, wt, bias = rnd(m, k, seed=135).to(DEV), (rnd(n_, k, seed=136) * 0.05).to(DEV), rnd(n_, seed=137).to(DEV)
+            g_ref = torch.empty(m, n_, device=DEV)
+            ops.gemm(a, wt, g_ref, bias=bias, ep_mode=ep)
+            g = torch.full((m, n_), float("nan"), device=DEV)
+            ops.gemm(a, wt, g, bias=bias, ep_mode=ep, c_split="only")
+            assert bool(torch.isnan(g).all())
+            img = ops.split3(g, 0)
+            assert img.data_ptr() == g._vfm_split3_out[1].data_ptr() and img.shape == (m, 3 * n_)
+            hi, hi2, lo = img[:, :n_].float(), img[:, n_:2 * n_].float(), img[:, 2 * n_:].float()
+            assert torch.equal(hi, hi2)
+            # hi + lo carries the fp32 result to 2^-16 relative (the vector epilogue's GELU is the 1.5e-7 erf polynomial)
+            assert float(((hi + lo) - g_ref).abs().max()) <= 2e-5 * float(g_ref.abs().max()) + 1e-6
+            out_ref, out = torch.empty(m, 64, device=DEV), torch.empty(m, 64, device=DEV)
+            w2 = rnd(64, n_, seed=138).to(DEV) * 0.05
+            ops.gemm(g_ref, w2, out_ref)
+            ops.gemm(g, w2, out)
+            assert relerr(out, out_ref) < 2e-5
+    finally:
+        set_compute_dtype("bf16")
+
+
 @pytest.mark.skipif(os.environ.get("VFMSEG_EXPERIMENTAL", "0") != "1", reason="attention_fwd64.hip is built only with VFMSEG_EXPERIMENTAL=1")
 def test_attention_fwd64_experimental():
     # the 64-queries-per-wave forward (vfm_tune attn_fwd64, off by default) against the regular kernel on the backbone shape

@@ -525,7 +525,9 @@ class DinoEngine:
         D, H, ps = v.embed_dim, v.num_heads, v.patch_size
         lora = self.lora_on()
         merged = None
-        if (lora and not training and not torch.is_grad_enabled() and is_half(cd)
+        from .precision import split3 as _x3_mode
+        x3 = _x3_mode() and not is_half(cd)
+        if (lora and not training and not torch.is_grad_enabled() and (is_half(cd) or x3)
                 and os.environ.get("VFMSEG_MERGE_LORA_EVAL", "1") != "0"):
             merged = self.merged_qkv(P)
         elif lora:
@@ -590,7 +592,9 @@ class DinoEngine:
                 xd = XDall[li] if batched else torch.empty(M, D, dtype=cd, device=dev)
                 ops.layernorm_dropout_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1, xd, mask, q.p, seed, offset=rng0 + li * M * D)
             else:
-                ops.layernorm_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1[:, :D], st1)
+                # bf16x3 predictions: outputs whose one consumer is a GEMM's A operand leave their producer as split-bf16 images
+                so = "only" if (x3 and not training and not need_grad and kq == D) else None
+                ops.layernorm_fwd(x, Lp["n1w"], Lp["n1b"], 1e-6, a1 if kq == D else a1[:, :D], st1, split_out=so)
             if lora and merged is None:
                 if not fused_drop:
                     xd, mask = a1[:, :D], None
@@ -608,12 +612,13 @@ class DinoEngine:
                 Lp["qkv"].fwd(a1, qkv, bias=Lp["qkv_b"])
             ao = torch.empty(M, D, dtype=cd, device=dev)
             lse = torch.empty(nimg, H, Np + 1, dtype=torch.float32, device=dev)
-            ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ao, lse, nimg, H, hd, Np, 1, Np, 1, scale, keep_split=training)
+            so = "only" if (x3 and not training and not need_grad) else None
+            ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], ao, lse, nimg, H, hd, Np, 1, Np, 1, scale, keep_split=training, o_split=so)
             xm = torch.empty(M, D, dtype=torch.float32, device=dev)
             Lp["proj"].fwd(ao, xm, bias=Lp["proj_b"], colscale=Lp["g1"], residual=x)
             a2 = torch.empty(M, D, dtype=cd, device=dev)
             st2 = torch.empty(M, 2, dtype=torch.float32, device=dev)
-            ops.layernorm_fwd(xm, Lp["n2w"], Lp["n2b"], 1e-6, a2, st2)
+            ops.layernorm_fwd(xm, Lp["n2w"], Lp["n2b"], 1e-6, a2, st2, split_out=so)
             hid = Lp["fc1"].n
             g = ops.empty_ld(M, hid, cd, dev)
             if training and lora:   # the forward also saves gelu'(pre-activation): what fc2's dgrad multiplies by (mlp.py:34-40)
@@ -621,7 +626,7 @@ class DinoEngine:
                 Lp["fc1"].fwd(a2, g, bias=Lp["fc1_b"], ep_mode=ops.EP_GELU_DGELU, c2=hpre)
             else:
                 hpre = None
-                Lp["fc1"].fwd(a2, g, bias=Lp["fc1_b"], ep_mode=ops.EP_GELU)
+                Lp["fc1"].fwd(a2, g, bias=Lp["fc1_b"], ep_mode=ops.EP_GELU, **({"c_split": so} if so else {}))
             xo = torch.empty(M, D, dtype=torch.float32, device=dev)
             Lp["fc2"].fwd(g, xo, bias=Lp["fc2_b"], colscale=Lp["g2"], residual=xm)
             S.update(a1=a1, st1=st1, qkv=qkv, ao=ao, lse=lse, x_mid=xm, a2=a2, st2=st2, hpre=hpre, g=g)

@@ -22,7 +22,9 @@ __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& 
   }
 }
 
-__global__ void __launch_bounds__(256, 2) k_attn_x3_fwd(AttnP p, int lo_off) {
+// o3 != null: the output is (also) written as the split-bf16 A operand of the projection GEMM that consumes it ([hi | hi | lo], planes
+// `plane` columns apart: vfm_split3 pattern 0) - the fp32 copy is skipped when p.o is null
+__global__ void __launch_bounds__(256, 2) k_attn_x3_fwd(AttnP p, int lo_off, bf16_t* o3, long ld3, long plane) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (Kh, Kl, Vh, Vl)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -144,22 +146,36 @@ __global__ void __launch_bounds__(256, 2) k_attn_x3_fwd(AttnP p, int lo_off) {
   const float mult = 1.f / l;
   if (qvalid && h == 0 && p.lse) p.lse[((long)b * p.H + hh) * nq + qi] = m * p.scale + __logf(l);
   if (qvalid) {
-    float* out = (float*)p.o + qrow * p.ldo + col0 + 4 * h;
+    float* out = p.o ? (float*)p.o + qrow * p.ldo + col0 + 4 * h : nullptr;
+    bf16_t* out3 = o3 ? o3 + qrow * ld3 + col0 + 4 * h : nullptr;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(out + 32 * j + 8 * g) =
-            make_float4(oacc[j][4 * g] * mult, oacc[j][4 * g + 1] * mult, oacc[j][4 * g + 2] * mult, oacc[j][4 * g + 3] * mult);
+      for (int g = 0; g < 4; ++g) {
+        const float v0 = oacc[j][4 * g] * mult, v1 = oacc[j][4 * g + 1] * mult, v2 = oacc[j][4 * g + 2] * mult, v3 = oacc[j][4 * g + 3] * mult;
+        if (out) *reinterpret_cast<float4*>(out + 32 * j + 8 * g) = make_float4(v0, v1, v2, v3);
+        if (out3) {
+          const bf16_t h0 = f32_to_bf16(v0), h1 = f32_to_bf16(v1), h2 = f32_to_bf16(v2), h3 = f32_to_bf16(v3);
+          const ushort4 hi = {h0, h1, h2, h3};
+          const ushort4 lo = {f32_to_bf16(v0 - bf16_to_f32(h0)), f32_to_bf16(v1 - bf16_to_f32(h1)), f32_to_bf16(v2 - bf16_to_f32(h2)),
+                              f32_to_bf16(v3 - bf16_to_f32(h3))};
+          bf16_t* q3 = out3 + 32 * j + 8 * g;
+          *reinterpret_cast<ushort4*>(q3) = hi;
+          *reinterpret_cast<ushort4*>(q3 + plane) = hi;
+          *reinterpret_cast<ushort4*>(q3 + 2 * plane) = lo;
+        }
+      }
   }
 }
 
 }  // namespace
 
-extern "C" int vfm_attn_fwd_x3(const vfm_attn_desc* d, long lo_off, void* stream) {
+static int attn_fwd_x3_impl(const vfm_attn_desc* d, long lo_off, void* o3, long ld3, long plane, void* stream) {
   auto ok = [](const void* ptr, long ld, long al) { return ((uintptr_t)ptr % 16 == 0) && (ld % al == 0); };
   VFM_CHECK(d->d == 64 && d->dt == VFM_F32, VFM_E_UNSUPPORTED, "vfm_attn_fwd_x3: head dim 64, fp32 q / o");
-  VFM_CHECK(ok(d->q, d->ldq, 4) && ok(d->o, d->ldo, 4) && ok(d->k, d->ldk, 8) && ok(d->v, d->ldv, 8) && lo_off % 8 == 0 && lo_off >= (long)d->H * 64,
+  VFM_CHECK((d->o || o3) && (!o3 || ((uintptr_t)o3 % 8 == 0 && plane >= (long)d->H * 64 && plane % 4 == 0 && ld3 >= 3 * plane && ld3 % 4 == 0)), VFM_E_ALIGN,
+            "vfm_attn_fwd_x3: o3 [rows, >= 3 plane] bf16 with plane >= H*64, 8-byte aligned (or an fp32 o)");
+  VFM_CHECK(ok(d->q, d->ldq, 4) && (!d->o || ok(d->o, d->ldo, 4)) && ok(d->k, d->ldk, 8) && ok(d->v, d->ldv, 8) && lo_off % 8 == 0 && lo_off >= (long)d->H * 64,
             VFM_E_ALIGN, "vfm_attn_fwd_x3: operands must be 16-byte aligned; k / v are split bf16 operands (hi at column h*64, lo at lo_off + h*64)");
   VFM_CHECK(d->nq_main + d->nq_extra > 0 && d->nk_main + d->nk_extra > 0, VFM_E_SHAPE, "vfm_attn_fwd_x3: empty sequence");
   const AttnP p = to_p(d);
@@ -169,7 +185,16 @@ extern "C" int vfm_attn_fwd_x3(const vfm_attn_desc* d, long lo_off, void* stream
     (void)hipFuncSetAttribute((const void*)k_attn_x3_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILE_BYTES);
     attr = true;
   }
-  hipLaunchKernelGGL(k_attn_x3_fwd, dim3(cdiv(nq, 128), d->B * d->H), dim3(256), 8 * TILE_BYTES, (hipStream_t)stream, p, (int)lo_off);
+  hipLaunchKernelGGL(k_attn_x3_fwd, dim3(cdiv(nq, 128), d->B * d->H), dim3(256), 8 * TILE_BYTES, (hipStream_t)stream, p, (int)lo_off, (bf16_t*)o3, ld3,
+                     plane);
   VFM_LAUNCH_CHECK();
   return VFM_OK;
+}
+extern "C" int vfm_attn_fwd_x3(const vfm_attn_desc* d, long lo_off, void* stream) {
+  VFM_CHECK(d && d->o, VFM_E_INVAL, "vfm_attn_fwd_x3: null output");
+  return attn_fwd_x3_impl(d, lo_off, nullptr, 0, 0, stream);
+}
+extern "C" int vfm_attn_fwd_x3_split(const vfm_attn_desc* d, long lo_off, void* o3, long ld3, long plane, void* stream) {
+  VFM_CHECK(d && o3, VFM_E_INVAL, "vfm_attn_fwd_x3_split: null split output");
+  return attn_fwd_x3_impl(d, lo_off, o3, ld3, plane, stream);
 }

@@ -67,6 +67,11 @@ extern "C" int vfm_gemm(const vfm_gemm_desc* d, void* stream) {
   VFM_CHECK(d && d->A && d->B && d->C, VFM_E_INVAL, "vfm_gemm: null operand");
   VFM_CHECK(d->M >= 0 && d->N >= 0 && d->K >= 0, VFM_E_SHAPE, "vfm_gemm: negative dim");
   VFM_CHECK(d->ldc >= d->N, VFM_E_SHAPE, "vfm_gemm: ldc < N");
+  if (d->c_dt == VFM_SPLIT3) {
+    VFM_CHECK(d->in_dt == VFM_BF16 && !d->C2 && !d->residual && d->c_plane >= d->N && d->c_plane % 8 == 0 && d->ldc >= 3 * d->c_plane && d->ldc % 8 == 0 &&
+                  (uintptr_t)d->C % 16 == 0 && d->batch <= 1,
+              VFM_E_UNSUPPORTED, "vfm_gemm: c_dt VFM_SPLIT3 needs bf16 inputs, no C2 / residual / batch, c_plane >= N (multiple of 8), ldc >= 3 c_plane, a 16-byte aligned C");
+  }
   VFM_CHECK(!(d->ep_mode == VFM_EP_MUL_GELU_GRAD || d->ep_mode == VFM_EP_MUL || d->ep_mode == VFM_EP_MUL_QGELU_GRAD) || d->aux, VFM_E_INVAL, "vfm_gemm: aux missing");
   VFM_CHECK(d->ep_mode != VFM_EP_GELU_DGELU || d->C2, VFM_E_INVAL, "vfm_gemm: VFM_EP_GELU_DGELU needs the second output C2");
   if (d->M == 0 || d->N == 0) return VFM_OK;

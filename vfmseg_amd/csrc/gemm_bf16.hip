@@ -475,7 +475,7 @@ int vfm_gemm_bf16_impl(const vfm_gemm_desc* d0, hipStream_t s) {
     dm.M = mm;
     dt.M = tail;
     auto adv = [&](const void* p, int dt_, long ld) -> const void* {
-      return p ? (const void*)((const char*)p + mm * ld * (dt_ == VFM_BF16 ? 2 : 4)) : nullptr;
+      return p ? (const void*)((const char*)p + mm * ld * (dt_ == VFM_BF16 || dt_ == VFM_SPLIT3 ? 2 : 4)) : nullptr;
     };
     dt.A = adv(d0->A, VFM_BF16, d0->sa_m);
     dt.C = (void*)adv(d0->C, d0->c_dt, d0->ldc);

@@ -81,6 +81,14 @@ __device__ __forceinline__ void epi_store4(const EpiParams& e, long zoff, long m
   if (e.c_dt == VFM_BF16) {
     ushort4 p = {f32_to_bf16(x[0]), f32_to_bf16(x[1]), f32_to_bf16(x[2]), f32_to_bf16(x[3])};
     *reinterpret_cast<ushort4*>((bf16_t*)e.C + o) = p;
+  } else if (e.c_dt == VFM_SPLIT3) {
+    const ushort4 hi = {f32_to_bf16(x[0]), f32_to_bf16(x[1]), f32_to_bf16(x[2]), f32_to_bf16(x[3])};
+    const ushort4 lo = {f32_to_bf16(x[0] - bf16_to_f32(hi.x)), f32_to_bf16(x[1] - bf16_to_f32(hi.y)), f32_to_bf16(x[2] - bf16_to_f32(hi.z)),
+                        f32_to_bf16(x[3] - bf16_to_f32(hi.w))};
+    bf16_t* cp = (bf16_t*)e.C + o;
+    *reinterpret_cast<ushort4*>(cp) = hi;
+    *reinterpret_cast<ushort4*>(cp + e.c_plane) = hi;
+    *reinterpret_cast<ushort4*>(cp + 2 * e.c_plane) = lo;
   } else {
     *reinterpret_cast<float4*>((float*)e.C + o) = make_float4(x[0], x[1], x[2], x[3]);
   }
@@ -423,6 +431,17 @@ __device__ __forceinline__ void epi_fast8(const EpiParams& e, long zoff, const A
         const long o = zoff + m * e.ldc + n;
         if constexpr (CDT == VFM_BF16) {
           st16((bf16_t*)e.C + o, pack_bf16x2(x[0]), pack_bf16x2(x[1]), pack_bf16x2(x[2]), pack_bf16x2(x[3]), e.nt);
+        } else if constexpr (CDT == VFM_SPLIT3) {   // the split-bf16 image [hi | hi | lo] of the result: three 16-byte stores
+          uint32_t hw[4], lw[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            hw[i] = pack_bf16x2(x[i]);
+            lw[i] = pack_bf16x2(x[i] - unpack_bf16x2(hw[i]));
+          }
+          bf16_t* cp = (bf16_t*)e.C + o;
+          st16(cp, hw[0], hw[1], hw[2], hw[3], 0);
+          st16(cp + e.c_plane, hw[0], hw[1], hw[2], hw[3], 0);
+          st16(cp + 2 * e.c_plane, lw[0], lw[1], lw[2], lw[3], 0);
         } else {
           float* cp = (float*)e.C + o;
           *reinterpret_cast<float4*>(cp) = make_float4(x[0].x, x[0].y, x[1].x, x[1].y);
@@ -474,6 +493,7 @@ __device__ __forceinline__ void epi_generic(const EpiParams& e, long zoff, const
 __device__ __forceinline__ bool epi_vec8_ok(const EpiParams& e, long zoff, long N) {
   auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   bool ok = (N % 8 == 0) && (e.ldc % 8 == 0) && (zoff % 8 == 0) && a16(e.C) && (!e.bias || e.bias_mod % 8 == 0);
+  if (e.c_dt == VFM_SPLIT3) ok = ok && (e.c_plane % 8 == 0);
   if (e.C2) ok = ok && e.c2_dt == VFM_BF16 && a16(e.C2) && (e.ldc2 % 8 == 0);
   if (e.aux) ok = ok && e.aux_dt == VFM_BF16 && a16(e.aux) && (e.ld_aux % 8 == 0);
   if (e.residual) ok = ok && a16(e.residual) && (e.ldr % 8 == 0);
@@ -486,6 +506,10 @@ __device__ __forceinline__ void epi_wave_tile_acc(const EpiParams& e, long zoff,
   const int mode = e.ep_mode;
   const bool plain = !e.C2 && !e.residual;
   if (epi_vec8_ok(e, zoff, N)) {   // eight columns per lane, packed arithmetic: every shape of the four backbones
+    if (mode == VFM_EP_GELU && plain && e.c_dt == VFM_SPLIT3)   // bf16x3 predictions: fc1's output straight into fc2's split A operand
+      return epi_fast8<VFM_EP_GELU, VFM_SPLIT3, 0, 0, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+    if (mode == VFM_EP_NONE && plain && e.c_dt == VFM_SPLIT3)
+      return epi_fast8<VFM_EP_NONE, VFM_SPLIT3, 0, 0, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
     if (mode == VFM_EP_NONE && plain && e.c_dt == VFM_BF16)
       return epi_fast8<VFM_EP_NONE, VFM_BF16, 0, 0, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
     if (mode == VFM_EP_NONE && !e.C2 && e.residual && e.r_dt == VFM_F32 && e.c_dt == VFM_F32)
@@ -505,7 +529,9 @@ __device__ __forceinline__ void epi_wave_tile_acc(const EpiParams& e, long zoff,
     if (mode == VFM_EP_NONE && !e.C2 && e.residual && e.r_dt == VFM_BF16 && e.c_dt == VFM_BF16)
       return epi_fast8<VFM_EP_NONE, VFM_BF16, 2, 0, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
   }
-  if (mode == VFM_EP_NONE && plain && e.c_dt == VFM_BF16)
+  if (e.c_dt == VFM_SPLIT3)
+    epi_generic<MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
+  else if (mode == VFM_EP_NONE && plain && e.c_dt == VFM_BF16)
     epi_fast<VFM_EP_NONE, VFM_BF16, 0, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);
   else if (mode == VFM_EP_NONE && plain && e.c_dt == VFM_F32)
     epi_fast<VFM_EP_NONE, VFM_F32, 0, false, MI, NI, GROUP>(e, zoff, acc, img, lane, m_base, n_base, M, N);

@@ -52,9 +52,25 @@ __global__ void k_ln_fwd(const float* __restrict__ x, long ld_x, const float* __
 struct LnDrop {
   void* yd; long ld_yd; void* mask; long ld_mask; float p, keep_scale; uint64_t seed, offset;
 };
-template <typename TO, int NV, bool DROP = false>
+// Split-bf16 image of an fp32 value (bf16x3 mode: what vfm_split3 pattern 0 writes for a GEMM's A operand): hi at column c, hi again at
+// plane + c, lo at 2 plane + c.  A producer that writes it directly saves the consumer's vfm_split3 pass (4 B read + 6 B written per value).
+struct Split3Out {
+  bf16_t* y3; long ld3; long plane;
+};
+__device__ __forceinline__ void store_split4(const Split3Out& so, long row, int c0, float4 o) {
+  const bf16_t h0 = f32_to_bf16(o.x), h1 = f32_to_bf16(o.y), h2 = f32_to_bf16(o.z), h3 = f32_to_bf16(o.w);
+  const ushort4 hi = {h0, h1, h2, h3};
+  const ushort4 lo = {f32_to_bf16(o.x - bf16_to_f32(h0)), f32_to_bf16(o.y - bf16_to_f32(h1)), f32_to_bf16(o.z - bf16_to_f32(h2)),
+                      f32_to_bf16(o.w - bf16_to_f32(h3))};
+  bf16_t* p = so.y3 + row * so.ld3 + c0;
+  *reinterpret_cast<ushort4*>(p) = hi;
+  *reinterpret_cast<ushort4*>(p + so.plane) = hi;
+  *reinterpret_cast<ushort4*>(p + 2 * so.plane) = lo;
+}
+template <typename TO, int NV, bool DROP = false, bool SPLIT = false>
 __global__ void k_ln_fwd_v4(const float* __restrict__ x, long ld_x, const float* __restrict__ w, const float* __restrict__ b,
-                            float eps, TO* __restrict__ y, long ld_y, float* __restrict__ stats, long rows, int C, LnDrop dr = LnDrop()) {
+                            float eps, TO* __restrict__ y, long ld_y, float* __restrict__ stats, long rows, int C, LnDrop dr = LnDrop(),
+                            Split3Out so = Split3Out()) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -109,7 +125,8 @@ __global__ void k_ln_fwd_v4(const float* __restrict__ x, long ld_x, const float*
         *reinterpret_cast<ushort4*>((bf16_t*)dr.yd + row * dr.ld_yd + c0) = yd;
       }
     } else {
-      *reinterpret_cast<float4*>(y + row * ld_y + c0) = o;
+      if (!SPLIT || y != nullptr) *reinterpret_cast<float4*>(y + row * ld_y + c0) = o;
+      if constexpr (SPLIT) store_split4(so, row, c0, o);
     }
   }
 }
@@ -268,6 +285,26 @@ __global__ void k_ln_fwd_v4t(const float* __restrict__ x, long ld_x, const float
       }
     }
   }
+}
+
+extern "C" int vfm_layernorm_fwd_split3(const float* x, long ld_x, const float* w, const float* b, float eps, float* y, long ld_y, void* y3,
+                                        long ld3, long plane, float* stats, long rows, long C, void* stream) {
+  const int nv = (int)(C / 256);
+  VFM_CHECK(C > 0 && C % 256 == 0 && (nv == 1 || nv == 2 || nv == 4 || nv == 5 || nv == 8) && ld_x >= C && ld_x % 4 == 0 && (uintptr_t)x % 16 == 0 &&
+                (uintptr_t)w % 16 == 0 && (uintptr_t)b % 16 == 0,
+            VFM_E_SHAPE, "vfm_layernorm_fwd_split3: C=%ld must be 256, 512, 1024, 1280 or 2048 with 16-byte aligned rows", C);
+  VFM_CHECK(y3 && (uintptr_t)y3 % 8 == 0 && plane >= C && plane % 4 == 0 && ld3 >= 3 * plane && ld3 % 4 == 0 && (!y || (ld_y >= C && ld_y % 4 == 0 && (uintptr_t)y % 16 == 0)),
+            VFM_E_ALIGN, "vfm_layernorm_fwd_split3: y3 [rows, >= 3 plane] bf16 with plane >= C, 8-byte aligned; y (optional fp32 copy) 16-byte aligned");
+  if (rows == 0) return VFM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(rows, 4)), blk(256);
+  Split3Out so;
+  so.y3 = (bf16_t*)y3, so.ld3 = ld3, so.plane = plane;
+#define LVS(NV) hipLaunchKernelGGL((k_ln_fwd_v4<float, NV, false, true>), grid, blk, 0, s, x, ld_x, w, b, eps, y, ld_y, stats, rows, (int)C, LnDrop(), so)
+  if (nv == 1) LVS(1); else if (nv == 2) LVS(2); else if (nv == 4) LVS(4); else if (nv == 5) LVS(5); else LVS(8);
+#undef LVS
+  VFM_LAUNCH_CHECK();
+  return VFM_OK;
 }
 
 extern "C" int vfm_layernorm_fwd(const float* x, long ld_x, const float* w, const float* b, float eps, void* y, int y_dt,

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvfmseg_hip.so")
 LIB_PATH_F16 = os.path.join(_HERE, "csrc", "libvfmseg_hip_f16.so")
 
-F32, BF16, U8, I64 = 0, 1, 2, 3
+F32, BF16, U8, I64, SPLIT3 = 0, 1, 2, 3, 4
 EP_NONE, EP_GELU, EP_RELU, EP_MUL_GELU_GRAD, EP_MUL, EP_QGELU, EP_MUL_QGELU_GRAD, EP_GELU_DGELU = 0, 1, 2, 3, 4, 5, 6, 7
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_QGELU = 0, 1, 2, 3
 
@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
         ("ep_mode", ci), ("aux", vp), ("aux_dt", ci), ("ld_aux", cl),
         ("C2", vp), ("c2_dt", ci), ("ldc2", cl),
         ("batch", cl), ("stride_a", cl), ("stride_b", cl), ("stride_c", cl),
+        ("c_plane", cl),
         ("kb_rows", cl),
     ]
 
@@ -118,6 +119,7 @@ SIGNATURES = {
     "vfm_mask_token_fwd": [vp, vp, vp, vp, cl, cl, vp],
     "vfm_mask_token_bwd": [vp, vp, vp, vp, vp, cl, cl, vp],
     "vfm_layernorm_fwd": [vp, cl, vp, vp, cf, vp, ci, cl, vp, cl, cl, vp],
+    "vfm_layernorm_fwd_split3": [vp, cl, vp, vp, cf, vp, cl, vp, cl, cl, vp, cl, cl, vp],
     "vfm_layernorm_dropout_fwd": [vp, cl, vp, vp, cf, vp, cl, vp, vp, cl, vp, cl, cf, u64, u64, cl, cl, vp],
     "vfm_layernorm_bwd_scaled": [vp, ci, cl, vp, cl, vp, vp, vp, cl, ci, vp, cl, vp, cl, cl, vp],
     "vfm_layernorm_bwd": [vp, ci, cl, vp, cl, vp, vp, vp, cl, ci, vp, vp, vp, cl, cl, vp],
@@ -132,6 +134,7 @@ SIGNATURES = {
     "vfm_tune": [C.c_char_p, ci],
     "vfm_attn_fwd": [C.POINTER(AttnDesc), vp],
     "vfm_attn_fwd_x3": [C.POINTER(AttnDesc), cl, vp],
+    "vfm_attn_fwd_x3_split": [C.POINTER(AttnDesc), cl, vp, cl, cl, vp],
     "vfm_attn_bwd": [C.POINTER(AttnDesc), vp],
     "vfm_attn_bwd_x3": [C.POINTER(AttnDesc), vp, vp, vp, cl, cl, vp, cl, cl, vp],
     "vfm_sam_relpos_table": [vp, ci, ci, ci, vp, vp],

@@ -233,9 +233,31 @@ def mask_token_bwd(dout, keep, dx, dtoken):
                                    L.stream()), "vfm_mask_token_bwd")
 
 
-def layernorm_fwd(x, w, b, eps, y, stats=None):
+def _split_key(t):
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t._version)
+
+
+def _register_split_out(t, t3):
+    """t3 is the split-bf16 image (vfm_split3 pattern 0) of the fp32 tensor t, written by t's producer: the GEMM that consumes t finds it on
+    the tensor OBJECT (ops.split3) instead of running vfm_split3.  When the producer skipped the fp32 copy, t holds no data at all."""
+    try:
+        t._vfm_split3_out = (_split_key(t), t3)
+    except AttributeError:
+        pass
+
+
+def layernorm_fwd(x, w, b, eps, y, stats=None, split_out=None):
+    """split_out (bf16x3 mode, y fp32, C % 256 == 0): "also" = y and its split-bf16 image, "only" = the image alone (y is then NOT written:
+    for outputs whose one consumer is a GEMM's A operand); the image is registered on y for ops.split3."""
     lib = L.load()
     rows, c = x.shape
+    if split_out and _split3_on() and y.dtype == torch.float32 and c % 256 == 0 and c // 256 in (1, 2, 4, 5, 8) and y.shape[1] == c:
+        kp = (c + 63) // 64 * 64
+        y3 = torch.empty(rows, 3 * kp, dtype=L.half_dtype(), device=x.device)
+        L.check(lib.vfm_layernorm_fwd_split3(L.ptr(x), _ld(x), L.ptr(w), L.ptr(b), float(eps), None if split_out == "only" else L.ptr(y), _ld(y),
+                                             L.ptr(y3), y3.stride(0), kp, L.ptr(stats), rows, c, L.stream()), "vfm_layernorm_fwd_split3")
+        _register_split_out(y, y3)
+        return y
     L.check(lib.vfm_layernorm_fwd(L.ptr(x), _ld(x), L.ptr(w), L.ptr(b), float(eps), L.ptr(y), L.dt_of(y), _ld(y),
                                   L.ptr(stats), rows, c, L.stream()), "vfm_layernorm_fwd")
     return y
@@ -336,6 +358,10 @@ def split3(x, pattern, trans=False, cache=False):
     """fp32 operand x [rows, K] ([K, rows] if trans) -> bf16 [rows, 3 ceil64(K)] split form (vfm_split3).  cache=True keeps the result on
     the tensor OBJECT (weights packed once by the engines: same object every call) and rebuilds it when the tensor's version counter
     moves (LoRA-merged weights are re-packed in place); activations are fresh objects and never hit."""
+    if pattern == 0 and not trans:   # an image its producer wrote (LayerNorm / attention / GEMM epilogue in the bf16x3 mode)
+        hit = getattr(x, "_vfm_split3_out", None)
+        if hit is not None and hit[0] == _split_key(x):
+            return hit[1]
     if cache:
         from .optim import PARAM_EPOCH   # the fused AdamW / LoRA re-pack kernels rewrite packed operands behind torch's version counters
         key = (PARAM_EPOCH[0], x._version, x.data_ptr(), pattern, trans, tuple(x.shape), tuple(x.stride()))
@@ -356,17 +382,28 @@ def split3(x, pattern, trans=False, cache=False):
 
 
 def gemm(a, b, c, *, alpha=1.0, bias=None, bias_mod=0, colscale=None, residual=None, ep_mode=EP_NONE, aux=None, c2=None,
-         trans_a=False, trans_b=False, kb_rows=0):
+         trans_a=False, trans_b=False, kb_rows=0, c_split=None):
     """c[M,N] = epilogue(alpha * A @ B^T).  a: [M,K] (or [K,M] if trans_a), b: [N,K] (or [K,N] if trans_b); 2-D views
     (or 3-D batched with equal batch).  bf16 inputs require K-contiguous operands with K % 64 == 0.
-    In the bf16x3 mode (precision.split3()) an fp32 x fp32 2-D product is computed by the bf16 MFMA kernels on split operands."""
+    In the bf16x3 mode (precision.split3()) an fp32 x fp32 2-D product is computed by the bf16 MFMA kernels on split operands;
+    c_split="only" (that mode, c fp32, N % 64 == 0, no residual / c2) makes the epilogue write the split-bf16 image of the result
+    INSTEAD of c (c_dt VFM_SPLIT3) and registers it on c for ops.split3: for a result whose one consumer is the next GEMM's A operand."""
     if a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and not kb_rows and _split3_on():
         a3 = split3(a, 0, trans=trans_a)
         b3 = split3(b, 1, trans=trans_b, cache=not b.requires_grad)
-        return gemm(a3, b3, c, alpha=alpha, bias=bias, bias_mod=bias_mod, colscale=colscale, residual=residual, ep_mode=ep_mode, aux=aux, c2=c2)
+        c3 = None
+        if (c_split == "only" and c.dtype == torch.float32 and c.dim() == 2 and c.shape[1] % 64 == 0 and residual is None and c2 is None
+                and ep_mode in (EP_NONE, EP_GELU)):
+            c3 = torch.empty(c.shape[0], 3 * c.shape[1], dtype=L.half_dtype(), device=c.device)
+        gemm(a3, b3, c, alpha=alpha, bias=bias, bias_mod=bias_mod, colscale=colscale, residual=residual, ep_mode=ep_mode, aux=aux, c2=c2, c_split=c3)
+        if c3 is not None:
+            _register_split_out(c, c3)
+        return c
     lib = L.load()
     d = gemm_desc(a, b, c, alpha=alpha, bias=bias, bias_mod=bias_mod, colscale=colscale, residual=residual, ep_mode=ep_mode, aux=aux, c2=c2,
                   trans_a=trans_a, trans_b=trans_b, kb_rows=kb_rows)
+    if torch.is_tensor(c_split):   # the image replaces c as the output
+        d.C, d.c_dt, d.ldc, d.c_plane = L.ptr(c_split), L.SPLIT3, c_split.stride(0), c.shape[1]
     fin = PROFILE("gemm", 2.0 * d.M * d.N * d.K * d.batch, REGION[-1]) if (PROFILE is not None and is_half(a.dtype)) else None
     L.check(lib.vfm_gemm(C.byref(d), L.stream()), "vfm_gemm")
     if fin is not None:
@@ -719,7 +756,7 @@ def _attn_bwd_delta(q, B, H, nq):
     return delta
 
 
-def attn_fwd(q, k, v, o, lse, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, keep_split=False):
+def attn_fwd(q, k, v, o, lse, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, keep_split=False, o_split=None):
     """q,k,v,o: 2-D row-major views [rows, >=H*d] (column slices of a packed qkv buffer are fine).  keep_split (bf16x3 mode): a backward
     pass will follow - split the whole packed qkv buffer once and keep the image for it (a prediction splits only k and v)."""
     lib = L.load()
@@ -732,6 +769,14 @@ def attn_fwd(q, k, v, o, lse, B, H, d, nq_main, nq_extra, nk_main, nk_extra, sca
             k3, v3, lo = split3(k, 1), split3(v, 1), H * d
         a = _attn_desc(q, k3, v3, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, lse)
         a.dt = L.dt_of(q)
+        if o_split and o.shape[1] == H * d and o.stride(1) == 1:
+            # the output as the split operand of the projection GEMM that consumes it (o_split "only": no fp32 copy at all)
+            o3 = torch.empty(o.shape[0], 3 * H * d, dtype=L.half_dtype(), device=o.device)
+            if o_split == "only":
+                a.o = None
+            L.check(lib.vfm_attn_fwd_x3_split(C.byref(a), lo, L.ptr(o3), o3.stride(0), H * d, L.stream()), "vfm_attn_fwd_x3_split")
+            _register_split_out(o, o3)
+            return o
         L.check(lib.vfm_attn_fwd_x3(C.byref(a), lo, L.stream()), "vfm_attn_fwd_x3")
         return o
     a = _attn_desc(q, k, v, o, B, H, d, nq_main, nq_extra, nk_main, nk_extra, scale, lse)
