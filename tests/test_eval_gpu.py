@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 import vfmseg_amd  # noqa: E402,F401
 from oracle import torch_ref as R  # noqa: E402
 from tests.helpers import full_state_dict, rel_err, sl  # noqa: E402
-from vfmseg_amd import metrics as M, ops, presets  # noqa: E402
+from vfmseg_amd import functional as Fh, metrics as M, ops, presets  # noqa: E402
 from vfmseg_amd.precision import set_compute_dtype  # noqa: E402
 from vfmseg_amd.registry import METRICS, MODELS  # noqa: E402
 from vfmseg_amd.segmentors import PixelData, SegDataSample  # noqa: E402
@@ -149,6 +149,41 @@ def test_lr_and_msfull_slide_modes_match_oracle():
 
 
 # (bf16 bounds = 3x the measured values: logits 8.6e-3, mismatches 8.3e-3, margin 3.2e-3 - profiles/r03_parity_gpu_suite.log)
+@pytest.mark.gpu
+def test_coarse_pass_beside_the_window_pass_is_bit_identical(monkeypatch):
+    """msfull_slide_inference, and ms_slide_inference with a gate that cannot fire (conf > 1), run the coarse 512 x 1024 pass on a side
+    stream beside the windows' backbone pass (segmentors._coarse_beside): same kernels on the same data, so the predictions must equal
+    the one-stream path bit for bit - including the first prediction after a weight change, which stays on one stream."""
+    model, _, _ = _small_model("bf16")
+    try:
+        img = synth_image(1, 1024, seed=5).cuda()
+        for mode, conf in (("ms_slide_inference", 2.0), ("msfull_slide_inference", 0.8)):
+            model.test_cfg["mode"], model.test_cfg["conf"] = mode, conf
+            monkeypatch.setenv("VFMSEG_EVAL_OVERLAP", "0")
+            with torch.no_grad():
+                Fh.manual_seed(11)     # (msfull draws the decoder's query mask per call: Ms_VFM_encoder_decoder.py:286-328)
+                ref = model.inference(img, [{}])
+            monkeypatch.setenv("VFMSEG_EVAL_OVERLAP", "1")
+            model._overlap_key = None
+            assert not model._overlap_ok() and model._overlap_ok()       # first call after a change: one stream; then beside
+            with torch.no_grad():
+                for _ in range(3):
+                    Fh.manual_seed(11)
+                    got = model.inference(img, [{}])
+                    assert torch.equal(got, ref), mode
+            if mode == "ms_slide_inference":
+                assert len(model.last_refined) == 9
+        # a live gate keeps the order coarse -> gate -> windows
+        model.test_cfg["mode"], model.test_cfg["conf"], model.test_cfg["threadshod"] = "ms_slide_inference", 0.8, 0.5
+        with torch.no_grad():
+            a = model.inference(img, [{}])
+            monkeypatch.setenv("VFMSEG_EVAL_OVERLAP", "0")
+            b = model.inference(img, [{}])
+        assert torch.equal(a, b)
+    finally:
+        set_compute_dtype("bf16")
+
+
 @pytest.mark.parametrize("prec,ltol,mtol", [("f32", 1e-3, 2e-4), ("bf16x3", 1e-3, 2e-4), ("bf16", 2.6e-2, 2.5e-2),
                                                 ("fp16", 1e-3, 5e-3)])
 def test_slide_modes_match_reference_goldens(golden_dir, prec, ltol, mtol):

@@ -372,7 +372,7 @@ def test_gemm_bf16(M, N, K):
     assert relerr(cw[:, :N], a.double() @ b.double().t()) < 2e-5 and cw[:, N:].abs().sum() == 0
 
 
-@pytest.mark.parametrize("cfg", [17, 16, 30, 31, 32, 33, 34, 35, 36, 39, 40, 50, 10])
+@pytest.mark.parametrize("cfg", [17, 16, 30, 31, 32, 33, 34, 35, 36, 39, 40, 50, 51, 10])
 @pytest.mark.parametrize("M,N,K", [(4100, 1024, 1024), (300, 520, 320), (1024, 2048, 448), (256, 256, 4096), (512, 512, 128)])
 def test_gemm_bf16_configs_fast_epilogues(cfg, M, N, K):
     """Every tile configuration incl. the ping-pong kernels (30: 256x256, 31: 128x128) and the 64-wide-K-tile 256x256 kernels
@@ -382,6 +382,8 @@ def test_gemm_bf16_configs_fast_epilogues(cfg, M, N, K):
         pytest.skip("the 128x128 ping-pong and deep-ring kernels need K >= 256 (the dispatcher rejects shorter K)")
     if cfg == 50 and os.environ.get("VFMSEG_EXPERIMENTAL", "0") != "1":
         pytest.skip("gemm_v5.hip (config 50) is built only with VFMSEG_EXPERIMENTAL=1")
+    if cfg == 51 and (K % 128 or K < 512):
+        pytest.skip("the split-K ring kernel halves K into whole K-tiles: K % 128 == 0, K >= 512")
     a, b = rnd(M, K, seed=80).bfloat16().to(DEV), rnd(N, K, seed=81).bfloat16().to(DEV)
     bias, cs, res = rnd(N, seed=82).to(DEV), (rnd(N, seed=83) * 0.2 + 1).to(DEV), rnd(M, N, seed=84).to(DEV)
     aux = rnd(M, N, seed=85).bfloat16().to(DEV)
@@ -776,6 +778,35 @@ def test_bf16x3_producers_write_the_split_operand_image():
             assert relerr(out, out_ref) < 2e-5
     finally:
         set_compute_dtype("bf16")
+
+
+def test_gemm_split_k_form_is_order_independent_and_stream_safe():
+    """Config 51 (gemm_w4.hip SPLITK): two blocks per tile, one per half of K; the first to finish leaves its partial sums in the stream's
+    workspace, the second adds them and runs the epilogue.  own + partner is one fp32 addition whichever block finishes last, so repeated
+    launches are bit-identical; the counter / flag words are left zero (the next launch works); two streams have separate workspaces."""
+    M, N, K = 2049, 1024, 4096          # the coarse prediction pass' fc2: 128 tiles + one [cls] row as skinny blocks
+    a, b = rnd(M, K, seed=140).bfloat16().to(DEV), (rnd(N, K, seed=141) * 0.05).bfloat16().to(DEV)
+    bias, cs, res = rnd(N, seed=142).to(DEV), (rnd(N, seed=143) * 0.2 + 1).to(DEV), rnd(M, N, seed=144).to(DEV)
+    ref = (a.double() @ b.double().t() + bias.double()) * cs.double() + res.double()
+    ops.tune("gemm_cfg", 51)
+    try:
+        outs = []
+        for _ in range(4):
+            c = torch.full((M, N), float("nan"), device=DEV)
+            ops.gemm(a, b, c, bias=bias, colscale=cs, residual=res)
+            outs.append(c)
+        assert relerr(outs[0], ref) < 2e-5 and all(torch.equal(outs[0], o) for o in outs[1:])
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        c_main, c_side = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+        for _ in range(3):
+            with torch.cuda.stream(side):
+                ops.gemm(a, b, c_side, bias=bias, colscale=cs, residual=res)
+            ops.gemm(a, b, c_main, bias=bias, colscale=cs, residual=res)
+        torch.cuda.synchronize()
+        assert torch.equal(c_main, outs[0]) and torch.equal(c_side, outs[0])
+    finally:
+        ops.tune("gemm_cfg", -1)
 
 
 @pytest.mark.skipif(os.environ.get("VFMSEG_EXPERIMENTAL", "0") != "1", reason="attention_fwd64.hip is built only with VFMSEG_EXPERIMENTAL=1")

@@ -26,7 +26,9 @@ def main():
     ap.add_argument("--models", default="dinov2,sam")
     a = ap.parse_args()
     parsed = [(s, [] if s == "base" else [(x.split("=")[0], int(x.split("=")[1])) for x in s.split(",")]) for s in a.settings]
-    keys = {k for _, kv in parsed for k, _ in kv}
+    # a key "env:NAME" sets the environment variable NAME (read per prediction, e.g. env:VFMSEG_EVAL_OVERLAP=0) instead of a vfm_tune knob
+    envs = {k[4:]: os.environ.get(k[4:]) for _, kv in parsed for k, _ in kv if k.startswith("env:")}
+    keys = {k for _, kv in parsed for k, _ in kv if not k.startswith("env:")}
     img = synth_image(1, 1024, seed=77).cuda()
     for name in a.models.split(","):
         cfg = presets.dinov2_ms_masked() if name == "dinov2" else presets.sam_linear()
@@ -42,8 +44,13 @@ def main():
                 for s, kv in parsed:
                     for k in keys:
                         ops.tune(k, DEFAULTS[k])
+                    for e, v0 in envs.items():
+                        os.environ.pop(e, None) if v0 is None else os.environ.__setitem__(e, v0)
                     for k, v in kv:
-                        ops.tune(k, v)
+                        if k.startswith("env:"):
+                            os.environ[k[4:]] = str(v)
+                        else:
+                            ops.tune(k, v)
                     model.predict(img)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()

@@ -332,6 +332,7 @@ static int g_use_ps = 0;
 // DINOv2 fc2 / proj / fc1 98.1 -> 83.8 / 33.2 -> 29.8 / 100.5 -> 94.8 us, SAM-H qkv / proj / fc2 106.3 -> 89.8 / 42.0 -> 37.0 / 127.5 -> 109.7 us;
 // bit 1: 256 x 256 tiles for the shapes they fill to >= 80 % (DINOv2 qkv [9216 x 3072]: 69.3 -> 64.1 us).  vfm_tune gemm_use_192.
 static int g_use_192 = 3;
+static int g_splitk = 1;       // vfm_tune("gemm_splitk"): bit 0 = the split-K ring kernel where its rule says so (gemm_main), 0 = never
 static int g_deep_sep_k = 0;   // K from which one-tile-per-CU launches WITH tail rows take the seven-chunk ring and leave the tail rows to a skinny
                                // launch of their own (vfm_tune gemm_deep_sep_k; 0 = never)
 static int g_deep_tail_k = 0;  // K from which one-tile-per-CU launches WITH tail rows take the seven-chunk ring, the tail rows riding
@@ -366,6 +367,11 @@ extern "C" int vfm_tune(const char* key, int value) {
   if (key && strcmp(key, "attn_lds_pad") == 0) {
     extern int g_attn_lds_pad;
     g_attn_lds_pad = value;
+    return VFM_OK;
+  }
+  if (key && strcmp(key, "gemm_splitk") == 0) {
+    if (value < 0) VFM_FAIL(VFM_E_INVAL, "vfm_tune(gemm_splitk): negative value");
+    g_splitk = value;
     return VFM_OK;
   }
   if (key && strcmp(key, "gemm_deep_sep_k") == 0) {
@@ -440,6 +446,8 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
 bool vfm_gemm_launch_pp256(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail);  // gemm_pp.hip
 bool vfm_gemm_launch_pp128(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail);  // gemm_pp.hip
 bool vfm_gemm_launch_w4(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail, int waves);  // gemm_w4.hip
+bool vfm_gemm_splitk_ok(const vfm_gemm_desc* d, bool vec);                                                       // gemm_w4.hip
+bool vfm_gemm_launch_w4_splitk(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail);              // gemm_w4.hip
 // experiment vehicles, built only with VFMSEG_EXPERIMENTAL=1 (vfmseg_amd/csrc/build.py EXPERIMENTAL): the persistent two-accumulator kernel
 // (gemm_ps.hip, round 3) and the 4-wave 16x16x32 256x256 kernel (gemm_v5.hip, round 4).  Neither beat the ring kernels of gemm_w4.hip
 // (DESIGN.md section 5.1); without them their configs answer VFM_E_UNSUPPORTED and the knobs that select them are ignored.
@@ -615,6 +623,11 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
                 "vfm_gemm(bf16): the 4-wave 256x256 kernel needs K >= 128 and operands spanning < 4 GiB");
       VFM_CHECK(cfg < 35 || d->K >= 256, VFM_E_UNSUPPORTED, "vfm_gemm(bf16): the deep-ring 128x128 kernels need K >= 256");
       fd = vfm_gemm_launch_w4(d, s, vec, tail, cfg == 32 ? 4 : (cfg == 33 ? 8 : (cfg == 34 ? 2 : (cfg == 35 ? 3 : 5))));
+      break;
+    case 51:   // 128 x 128 ring kernel, two blocks per tile (one per half of K), in-kernel fix-up
+      VFM_CHECK(d->K % 64 == 0 && (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31) && vfm_gemm_splitk_ok(d, vec), VFM_E_UNSUPPORTED,
+                "vfm_gemm(bf16): the split-K ring kernel needs K %% 128 == 0, K >= 512, one batch, <= 512 tiles of 128 x 128, a 16-byte aligned epilogue");
+      fd = vfm_gemm_launch_w4_splitk(d, s, tail);
       break;
     case 39:   // 192 x 256 tiles, 4 waves (gemm_w4.hip form 6)
     case 40:   // 192 x 256 tiles, 8 waves (form 7)

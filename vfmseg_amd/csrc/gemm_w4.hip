@@ -48,16 +48,29 @@ __device__ __forceinline__ void static_for(F&& f) {
 // a CU with a deep ring (they would reserve its whole LDS and wait for a free CU: measured 46 -> 51 us); this way the
 // one-tile-per-CU shapes (N = 1024: 96 launches per train step) get the seven-chunk ring.  The 8 blocks concerned do 3 MFMAs
 // per k-step instead of 2, inside a loop that is bound by the operand stream, not by the matrix pipe.
-template <bool VEC, int MI, int NI, int WM_W, int WN_W, int P = 2, int DBG = 0, bool CLSIN = false>
+// SPLITK: every tile is computed by TWO blocks, one per half of K (adjacent ids after the XCD map: same XCD, same L2).  The block that
+// arrives first at the tile's counter leaves its accumulators in the workspace (fp32, register order: 16 bytes per lane and store) and
+// raises the tile's flag; the second one adds them to its own and runs the epilogue.  own + partner is the same fp32 sum whichever half
+// finishes last, so the result does not depend on the order.  For launches of at most one tile per CU over a long K (the N = 1024
+// GEMMs of the coarse prediction pass: 128 tiles): twice the blocks fill the idle CUs / the second block slot of every CU.
+struct SplitK {
+  float* ws;        // [tile][threads * MI * NI * 16] partial accumulators of the first finisher
+  unsigned* cnt;    // [tile] arrivals (zero between launches)
+  unsigned* flag;   // [tile] partial published (zero between launches)
+};
+
+template <bool VEC, int MI, int NI, int WM_W, int WN_W, int P = 2, int DBG = 0, bool CLSIN = false, bool SPLITK = false>
 __global__ void __launch_bounds__(WM_W* WN_W * 64)
     k_gemm_w4(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, long M, long N, long K, long stride_a,
-              long stride_b, long stride_c, int tiles_m, int tiles_n, EpiParams e, SkinnyTail sk) {
+              long stride_b, long stride_c, int tiles_m, int tiles_n, EpiParams e, SkinnyTail sk, SplitK spk) {
   // block tile TM x TN (rows of A x rows of B); square in every form but the 192 x 256 one (<6, 2, 1, 4>: M = 9216 x N = 1280 / 1024
   // GEMMs of the 1024^2 predictions, where 256 x 256 tiles fill 180 / 144 of the 256 CUs and 128 x 128 tiles take two rounds)
   constexpr int TM = WM_W * MI * 32, TN = WN_W * NI * 32, T = TM > TN ? TM : TN;
   // (MI odd - the 8-wave 192 x 256 form <3, 2, 2, 4> - : the epilogue takes the last 32-row block on its own, and a wave's pieces of
   // an A chunk split 2 + 1 over the two k-steps that issue them)
   static_assert(TM == TN || !CLSIN, "the tail-row-in-block form is written for square tiles");
+  static_assert(!SPLITK || !CLSIN, "the split-K form takes its tail rows as skinny blocks");
+  constexpr int KS = SPLITK ? 2 : 1;
   constexpr int WAVES = WM_W * WN_W, NCH = 2 * P + 1;
   constexpr int CH = T * 128;                        // bytes per ring slot: the larger chunk (rows x one 128-B K-tile row)
   constexpr int PPC_A = TM / 8 / WAVES, PPC_B = TN / 8 / WAVES;   // DMA pieces per wave and chunk
@@ -68,8 +81,8 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   constexpr int NMF = MI * NI, NRD = MI + NI;  // per k-step: MFMAs, fragment reads (+ the DMA pieces of the chunk half issued in it)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if constexpr (NCH * CH >= 65536 && !CLSIN) {  // the tail rows of M run as extra blocks at the end of the grid
-    if (sk.nblk > 0 && (int)blockIdx.x >= tiles_m * tiles_n) {
-      skinny_tile<WAVES>(sk.A, sk.lda, B, ldb, sk.M, N, K, (long)((int)blockIdx.x - tiles_m * tiles_n) * 32, sk.e, 0, smem);
+    if (sk.nblk > 0 && (int)blockIdx.x >= tiles_m * tiles_n * KS) {
+      skinny_tile<WAVES>(sk.A, sk.lda, B, ldb, sk.M, N, K, (long)((int)blockIdx.x - tiles_m * tiles_n * KS) * 32, sk.e, 0, smem);
       return;
     }
   }
@@ -81,9 +94,13 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   const int ntiles = tiles_m * tiles_n;
   int bid = blockIdx.x;
   {
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+    const int nb = ntiles * KS;
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  const int ksplit = SPLITK ? (bid & 1) : 0;   // which half of K
+  if constexpr (SPLITK) bid >>= 1;
+  const int tile_id = bid;
   constexpr int GM = 8;
   const int group = bid / (GM * tiles_n);
   const int first_m = group * GM;
@@ -92,8 +109,9 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
   const int tn = (bid % (GM * tiles_n)) / gsz;
   const long m0 = (long)tm * TM, n0 = (long)tn * TN;
   const long z = blockIdx.y;
-  const bf16_t* Ab = A + z * stride_a;
-  const bf16_t* Bb = B + z * stride_b;
+  if constexpr (SPLITK) K >>= 1;   // (the dispatcher checks K % 128 == 0 and K / 2 >= 64 P)
+  const bf16_t* Ab = A + z * stride_a + (long)ksplit * K;
+  const bf16_t* Bb = B + z * stride_b + (long)ksplit * K;
 
   // ---- per-lane DMA sources (32-bit byte offsets from the scalar matrix base; the dispatcher checks the span < 4 GiB)
   unsigned soff[2][PPCX];  // [0: B, 1: A][piece]
@@ -288,6 +306,51 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
     main_loop(IC<false>{});
   }
 
+  if constexpr (SPLITK) {
+    // The partial sums and the flag travel as relaxed agent-scope atomics (8-byte global stores / loads with sc1: coherent across the
+    // XCDs' L2s by themselves), ordered by vmcnt(0) + the block barrier.  A release / acquire FENCE at agent scope would write back and
+    // invalidate the whole L2 of the XCD per block (buffer_wbl2 / buffer_inv): measured 0.6 us per tile, serialised.
+    constexpr int NT = WAVES * 64, NV = MI * NI * 8;   // 8-byte words per lane
+    unsigned long long* slab = reinterpret_cast<unsigned long long*>(spk.ws) + (long)tile_id * NV * NT;
+    __syncthreads();   // (the ring is no longer read: smem[0] carries the role of this block)
+    if (tid == 0) *reinterpret_cast<unsigned*>(smem) = __hip_atomic_fetch_add(&spk.cnt[tile_id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned arrived = *reinterpret_cast<volatile unsigned*>(smem);
+    if (arrived == 0) {   // first: publish the partial sums, leave
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r2 = 0; r2 < 8; ++r2) {
+            const unsigned long long w = (unsigned long long)__float_as_uint(acc[i][j][2 * r2]) | ((unsigned long long)__float_as_uint(acc[i][j][2 * r2 + 1]) << 32);
+            __hip_atomic_store(&slab[((i * NI + j) * 8 + r2) * NT + tid], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+      __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): this wave's stores have been acknowledged
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(&spk.flag[tile_id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    // second: wait for the partner's partial (it is resident and past its K loop: the wait is short; bounded all the same, so that
+    // no wave can spin forever), add, reset the tile's words for the next launch
+    if (tid == 0) {
+      int spins = 0;
+      while (__hip_atomic_load(&spk.flag[tile_id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(2);
+      __hip_atomic_store(&spk.flag[tile_id], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&spk.cnt[tile_id], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r2 = 0; r2 < 8; ++r2) {
+          const unsigned long long w = __hip_atomic_load(&slab[((i * NI + j) * 8 + r2) * NT + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          acc[i][j][2 * r2] += __uint_as_float((unsigned)w);
+          acc[i][j][2 * r2 + 1] += __uint_as_float((unsigned)(w >> 32));
+        }
+  }
   // ---- epilogue (accumulators -> per-wave fp32 LDS image -> 16-byte rows), one 64-row half of the wave tile at a time
   const long zoff = z * stride_c;
   if constexpr (DBG & 1) return;
@@ -330,7 +393,28 @@ __global__ void __launch_bounds__(WM_W* WN_W * 64)
 }
 
 extern int g_pp_dbg;
-template <bool VEC, int MI, int NI, int WM_W, int WN_W, int P, int DBG, bool CLSIN = false>
+bool vfm_gemm_launch_w4(const vfm_gemm_desc* d, hipStream_t s, bool vec, const vfm_gemm_desc* tail, int form);
+// split-K workspace of a stream: partial sums of up to SPLITK_TILES tiles of 128 x 128 + their counter / flag words (zeroed once: every
+// launch leaves them zero).  One per stream, because launches on different streams may overlap.
+constexpr int SPLITK_TILES = 512;
+static SplitK splitk_ws(hipStream_t s) {
+  struct Ent { hipStream_t s; SplitK w; };
+  static thread_local Ent tab[8];
+  static thread_local int n = 0;
+  for (int i = 0; i < n; ++i)
+    if (tab[i].s == s) return tab[i].w;
+  SplitK w = {nullptr, nullptr, nullptr};
+  if (n == 8) return w;   // (more streams than this process ever uses: the caller falls back to the unsplit form)
+  void* p = nullptr;
+  const size_t slab = (size_t)SPLITK_TILES * 128 * 128 * 4, words = (size_t)SPLITK_TILES * 2 * 4;
+  if (hipMalloc(&p, slab + words) != hipSuccess) return w;
+  (void)hipMemsetAsync((char*)p + slab, 0, words, s);
+  w.ws = (float*)p, w.cnt = (unsigned*)((char*)p + slab), w.flag = w.cnt + SPLITK_TILES;
+  tab[n].s = s, tab[n].w = w, ++n;
+  return w;
+}
+
+template <bool VEC, int MI, int NI, int WM_W, int WN_W, int P, int DBG, bool CLSIN = false, bool SPLITK = false>
 static bool launch_w4_t(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail) {
   constexpr int TM = WM_W * MI * 32, TN = WN_W * NI * 32, T = TM > TN ? TM : TN, WAVES = WM_W * WN_W;
   constexpr int RING = (2 * P + 1) * T * 128 + (CLSIN ? 8 * 1024 : 0), EPI = WAVES * 64 * (NI * 32 + 4) * 4, SMEM = RING > EPI ? RING : EPI;
@@ -338,17 +422,27 @@ static bool launch_w4_t(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_de
   const long batch = d->batch > 0 ? d->batch : 1;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k_gemm_w4<VEC, MI, NI, WM_W, WN_W, P, DBG, CLSIN>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    (void)hipFuncSetAttribute((const void*)k_gemm_w4<VEC, MI, NI, WM_W, WN_W, P, DBG, CLSIN, SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr = true;
   }
+  SplitK spk = {nullptr, nullptr, nullptr};
+  if constexpr (SPLITK) spk = splitk_ws(s);
   SkinnyTail sk;
   sk.nblk = 0;
   const bool fold = tail && batch == 1 && RING >= 65536 && (!CLSIN || (tail->M <= 8 && tail->sa_k == 1));
   if (fold) sk.A = (const bf16_t*)tail->A, sk.lda = tail->sa_m, sk.M = tail->M, sk.nblk = cdiv(tail->N, 32), sk.e = make_epi(tail);
-  hipLaunchKernelGGL((k_gemm_w4<VEC, MI, NI, WM_W, WN_W, P, DBG, CLSIN>), dim3(tiles_m * tiles_n + (CLSIN ? 0 : sk.nblk), (unsigned)batch), dim3(WAVES * 64), SMEM, s,
-                     (const bf16_t*)d->A, d->sa_m, (const bf16_t*)d->B, d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b, d->stride_c,
-                     tiles_m, tiles_n, make_epi(d), sk);
+  hipLaunchKernelGGL((k_gemm_w4<VEC, MI, NI, WM_W, WN_W, P, DBG, CLSIN, SPLITK>), dim3(tiles_m * tiles_n * (SPLITK ? 2 : 1) + (CLSIN ? 0 : sk.nblk), (unsigned)batch),
+                     dim3(WAVES * 64), SMEM, s, (const bf16_t*)d->A, d->sa_m, (const bf16_t*)d->B, d->sb_n, d->M, d->N, d->K, d->stride_a, d->stride_b,
+                     d->stride_c, tiles_m, tiles_n, make_epi(d), sk, spk);
   return fold || !tail;
+}
+// the split-K form of the 128 x 128 ring kernel (see SplitK): K % 128 == 0, K / 2 >= 128, one batch, at most SPLITK_TILES tiles, the vector epilogue
+bool vfm_gemm_splitk_ok(const vfm_gemm_desc* d, bool vec) {
+  return vec && d->batch <= 1 && d->K % 128 == 0 && d->K >= 512 && (long)cdiv(d->M, 128) * cdiv(d->N, 128) <= SPLITK_TILES;
+}
+bool vfm_gemm_launch_w4_splitk(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc* tail) {
+  if (!splitk_ws(s).ws) return vfm_gemm_launch_w4(d, s, true, tail, 2);
+  return launch_w4_t<true, 2, 1, 2, 4, 2, 0, false, true>(d, s, tail);
 }
 // form: 4 = 256x256 / 4 waves, 8 = 256x256 / 8 waves, 6 = 192x256 / 4 waves, 7 = 192x256 / 8 waves, 2 = 128x128 / 8 waves (two blocks per CU), 3 / 5 = 128x128
 // with the seven- / nine-chunk ring (one block per CU).  Returns whether the tail rows were folded into the launch (otherwise

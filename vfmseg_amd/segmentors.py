@@ -2,6 +2,8 @@
 (multi-scale training: LR pass + HR crop, two heads; coarse-to-fine gated sliding inference); EncoderDecoder /
 LoraBackboneEncoderDecoder mirror the mmseg base class slice the reference configs use (SURVEY App. D,
 rein/models/segmentors/Lora_encoder_decoder.py:12-44)."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -457,6 +459,39 @@ class MsVFMEncoderDecoder(EncoderDecoder):
         lr = self.slide_inference(self._resize_nchw(inputs, (lh, lw)), batch_img_metas)
         return self._resize_nchw(lr, (int(lh * 2), int(lw * 2)))
 
+    # ---- coarse pass beside the window pass
+    # When every window is refined whatever the coarse logits say (msfull_slide_inference; ms_slide_inference with a gate that cannot
+    # fire: threadshod >= 1 or conf > 1), the windows' backbone pass does not depend on the coarse pass: only the VFMHead's context does.
+    # The coarse pass (one 512 x 1024 image: GEMMs of 136-544 tiles, attention with 272 blocks - half the chip idle) then runs on a side
+    # stream beside the nine-window pass and is joined in front of the head.  Same kernels on the same data: bit-identical predictions.
+    # The first prediction after a weight change runs on one stream (it builds the packed / merged weights both passes read).
+    _side = {"stream": None}
+
+    def _overlap_ok(self):
+        from .optim import PARAM_EPOCH
+        if os.environ.get("VFMSEG_EVAL_OVERLAP", "1") == "0" or not torch.cuda.is_available():
+            return False
+        key = (PARAM_EPOCH[0], self.training)
+        if getattr(self, "_overlap_key", None) != key:
+            self._overlap_key = key
+            return False
+        return True
+
+    def _coarse_beside(self, coarse_fn, window_fn):
+        """(coarse_fn(), window_fn()): on one stream, or coarse_fn on the side stream while window_fn runs here (joined before returning)."""
+        if not self._overlap_ok():
+            return coarse_fn(), window_fn()
+        if self._side["stream"] is None:
+            self._side["stream"] = torch.cuda.Stream()
+        side, main = self._side["stream"], torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            seg = coarse_fn()
+        out = window_fn()
+        main.wait_stream(side)
+        seg.record_stream(main)
+        return seg, out
+
     def msfull_slide_inference(self, inputs, batch_img_metas):
         """:286-328: coarse sliding LinearHead pass on the input squeezed to (512, 1024), logits resized to the input size,
         then EVERY window refined by the VFMHead with its coarse logits as context (no confidence gate; the decoder's query mask
@@ -464,12 +499,12 @@ class MsVFMEncoderDecoder(EncoderDecoder):
         B, _, H, W = inputs.shape
         C = self.out_channels
         dev = inputs.device
-        coarse = self.slide_inference(self._resize_nchw(inputs, (512, 1024)), batch_img_metas)
-        seg = self._resize_nchw(coarse, (H, W))
         boxes = grid_boxes(H, W, self.test_cfg.crop_size, self.test_cfg.stride)
         hc, wc = boxes[0][1] - boxes[0][0], boxes[0][3] - boxes[0][2]
         assert all((b[1] - b[0], b[3] - b[2]) == (hc, wc) for b in boxes)
-        xcat, hp, wp = self._tokens([(inputs, b) for b in boxes])
+        seg, (xcat, hp, wp) = self._coarse_beside(
+            lambda: self._resize_nchw(self.slide_inference(self._resize_nchw(inputs, (512, 1024)), batch_img_metas), (H, W)),
+            lambda: self._tokens([(inputs, b) for b in boxes]))
         if self.aux_decoder.ctx_windows_ok(seg, boxes, hp, wp):   # the context windows are sampled straight out of the coarse map
             lg = self.aux_decoder.forward_tokens(FeatPack(xcat, B * len(boxes), hp, wp), None, ctx_windows=(seg, boxes))
         else:
@@ -488,32 +523,46 @@ class MsVFMEncoderDecoder(EncoderDecoder):
         B, _, H, W = inputs.shape
         dev = inputs.device
         C = self.out_channels
-        small = torch.empty(B, 3, 512, 1024, dtype=torch.float32, device=dev)
-        ops.resize_bilinear(inputs, True, B, H, W, 3, small, 1, (512, 1024))
-        lg0 = self.enc_dec(small)                                   # NHWC low-res logits of the coarse pass
-        seg = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
-        ops.resize_bilinear(lg0, False, B, lg0.shape[1], lg0.shape[2], C, seg, 1, (H, W))  # predict_by_feat -> image size
+
+        def coarse():
+            small = torch.empty(B, 3, 512, 1024, dtype=torch.float32, device=dev)
+            ops.resize_bilinear(inputs, True, B, H, W, 3, small, 1, (512, 1024))
+            lg0 = self.enc_dec(small)                                   # NHWC low-res logits of the coarse pass
+            seg = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
+            ops.resize_bilinear(lg0, False, B, lg0.shape[1], lg0.shape[2], C, seg, 1, (H, W))  # predict_by_feat -> image size
+            return seg
+
+        boxes = grid_boxes(H, W, self.test_cfg.crop_size, self.test_cfg.stride)
+        # a gate that cannot fire (no pixel's max softmax exceeds 1; no fraction reaches a conf above 1): every window is refined
+        all_refined = conf > 1.0 or (thr >= 1.0 and conf > 0.0)
+        early = None
+        if all_refined:
+            seg, early = self._coarse_beside(coarse, lambda: self._tokens([(inputs, b) for b in boxes]))
+        else:
+            seg = coarse()
         dec = getattr(self.aux_decoder, "transformer_decoder", None)
         had_mask = getattr(dec, "mask_enable", None)
         if had_mask is not None:
             dec.mask_enable = False
-        boxes = grid_boxes(H, W, self.test_cfg.crop_size, self.test_cfg.stride)
         cnt = torch.zeros(len(boxes), dtype=torch.int32, device=dev)
         self.last_refined = []
         try:
             # all gates depend only on the coarse logits: evaluate them together (ONE pass over the map and ONE device->host sync
             # instead of one of each per window), then refine the selected windows in one batched backbone + VFMHead pass
-            if len(boxes) <= 16:
-                ops.conf_gate_windows(seg, [(y1, x1, y2 - y1, x2 - x1) for (y1, y2, x1, x2) in boxes], thr, cnt)
+            if all_refined:          # (no gate to evaluate, no device->host sync)
+                refine = list(range(len(boxes)))
             else:
-                for j, (y1, y2, x1, x2) in enumerate(boxes):
-                    ops.conf_gate_count(seg, (y1, x1, y2 - y1, x2 - x1), thr, cnt[j:j + 1])
-            fracs = [c / float(B * (b[1] - b[0]) * (b[3] - b[2])) for c, b in zip(cnt.tolist(), boxes)]
-            refine = [j for j, f in enumerate(fracs) if f < conf]
+                if len(boxes) <= 16:
+                    ops.conf_gate_windows(seg, [(y1, x1, y2 - y1, x2 - x1) for (y1, y2, x1, x2) in boxes], thr, cnt)
+                else:
+                    for j, (y1, y2, x1, x2) in enumerate(boxes):
+                        ops.conf_gate_count(seg, (y1, x1, y2 - y1, x2 - x1), thr, cnt[j:j + 1])
+                fracs = [c / float(B * (b[1] - b[0]) * (b[3] - b[2])) for c, b in zip(cnt.tolist(), boxes)]
+                refine = [j for j, f in enumerate(fracs) if f < conf]
             hc, wc = boxes[0][1] - boxes[0][0], boxes[0][3] - boxes[0][2]
             assert all((b[1] - b[0], b[3] - b[2]) == (hc, wc) for b in boxes)
             if refine:
-                xcat, hp, wp = self._tokens([(inputs, boxes[j]) for j in refine])
+                xcat, hp, wp = early if early is not None else self._tokens([(inputs, boxes[j]) for j in refine])
                 rboxes = [boxes[j] for j in refine]
                 if self.aux_decoder.ctx_windows_ok(seg, rboxes, hp, wp):   # context windows sampled straight out of the coarse map
                     lg = self.aux_decoder.forward_tokens(FeatPack(xcat, B * len(refine), hp, wp), None, ctx_windows=(seg, rboxes))
