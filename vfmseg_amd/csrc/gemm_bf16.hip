@@ -332,7 +332,6 @@ static int g_use_ps = 0;
 // DINOv2 fc2 / proj / fc1 98.1 -> 83.8 / 33.2 -> 29.8 / 100.5 -> 94.8 us, SAM-H qkv / proj / fc2 106.3 -> 89.8 / 42.0 -> 37.0 / 127.5 -> 109.7 us;
 // bit 1: 256 x 256 tiles for the shapes they fill to >= 80 % (DINOv2 qkv [9216 x 3072]: 69.3 -> 64.1 us).  vfm_tune gemm_use_192.
 static int g_use_192 = 3;
-static int g_splitk = 1;       // vfm_tune("gemm_splitk"): bit 0 = the split-K ring kernel where its rule says so (gemm_main), 0 = never
 static int g_deep_sep_k = 0;   // K from which one-tile-per-CU launches WITH tail rows take the seven-chunk ring and leave the tail rows to a skinny
                                // launch of their own (vfm_tune gemm_deep_sep_k; 0 = never)
 static int g_deep_tail_k = 0;  // K from which one-tile-per-CU launches WITH tail rows take the seven-chunk ring, the tail rows riding
@@ -367,11 +366,6 @@ extern "C" int vfm_tune(const char* key, int value) {
   if (key && strcmp(key, "attn_lds_pad") == 0) {
     extern int g_attn_lds_pad;
     g_attn_lds_pad = value;
-    return VFM_OK;
-  }
-  if (key && strcmp(key, "gemm_splitk") == 0) {
-    if (value < 0) VFM_FAIL(VFM_E_INVAL, "vfm_tune(gemm_splitk): negative value");
-    g_splitk = value;
     return VFM_OK;
   }
   if (key && strcmp(key, "gemm_deep_sep_k") == 0) {
@@ -624,7 +618,9 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
       VFM_CHECK(cfg < 35 || d->K >= 256, VFM_E_UNSUPPORTED, "vfm_gemm(bf16): the deep-ring 128x128 kernels need K >= 256");
       fd = vfm_gemm_launch_w4(d, s, vec, tail, cfg == 32 ? 4 : (cfg == 33 ? 8 : (cfg == 34 ? 2 : (cfg == 35 ? 3 : 5))));
       break;
-    case 51:   // 128 x 128 ring kernel, two blocks per tile (one per half of K), in-kernel fix-up
+    case 51:   // 128 x 128 ring kernel, two blocks per tile (one per half of K), in-kernel fix-up.  Never chosen by the rules above: on the
+               // shapes it was built for (the N = 1024 GEMMs of the coarse prediction pass, 128 tiles) the exchange of the partial sums costs
+               // what the second half of the CUs gains (fc2 [2049 x 1024 x 4096] 38.6 -> 37.6 us, proj 14.0 -> 17.9: profiles/r04_gemm_splitk_eval.log)
       VFM_CHECK(d->K % 64 == 0 && (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31) && vfm_gemm_splitk_ok(d, vec), VFM_E_UNSUPPORTED,
                 "vfm_gemm(bf16): the split-K ring kernel needs K %% 128 == 0, K >= 512, one batch, <= 512 tiles of 128 x 128, a 16-byte aligned epilogue");
       fd = vfm_gemm_launch_w4_splitk(d, s, tail);
