@@ -86,10 +86,21 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
   const bool r1 = NW == 4 && p.nk_extra == 1 && (!DQ || cls_key);
   const int nk_loop = r1 ? p.nk_main : nk;
   const int nt = (nk_loop + TROWS - 1) / TROWS;
+  unsigned koff[8 / NW], voff[8 / NW];   // this lane's byte offsets inside an interior tile
+  tile_offsets<NW>(p.ldk, wave, lane, koff);
+  tile_offsets<NW>(p.ldv, wave, lane, voff);
+  const int n_int = min(nk_loop, p.nk_main) / TROWS;   // tiles 0 .. n_int-1 hold 64 consecutive patch-token rows of image b
+  const bool span_ok = 64l * p.ldk * 2 < (1l << 31) && 64l * p.ldv * 2 < (1l << 31);
   auto stage = [&](int buf, int t) {
     char* kt = smem + buf * 2 * TILE_BYTES;
-    stage_tile<NW>(Kb, p.ldk, col0, b, t * TROWS, nk_loop, p.nk_main, p.B, kt, wave, lane);
-    stage_tile<NW>(Vb, p.ldv, col0, b, t * TROWS, nk_loop, p.nk_main, p.B, kt + TILE_BYTES, wave, lane);
+    if (t < n_int && span_ok) {
+      const long row0 = (long)b * p.nk_main + (long)t * TROWS;
+      stage_tile_fast<NW>(Kb + row0 * p.ldk + col0, koff, kt, wave);
+      stage_tile_fast<NW>(Vb + row0 * p.ldv + col0, voff, kt + TILE_BYTES, wave);
+    } else {
+      stage_tile<NW, true>(Kb, p.ldk, col0, b, t * TROWS, nk_loop, p.nk_main, p.B, kt, wave, lane);
+      stage_tile<NW, true>(Vb, p.ldv, col0, b, t * TROWS, nk_loop, p.nk_main, p.B, kt + TILE_BYTES, wave, lane);
+    }
   };
   // three K/V stages, ONE barrier per tile: the barrier that publishes tile t also certifies that every wave is done with tile
   // t-1, whose stage is the one tile t+2 will be written to (by the stage() call of the NEXT iteration)
@@ -122,6 +133,17 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
         for (int r = 0; r < 16; ++r) oacc[j][r] = ds_cls * oc[j][r];
     }
   }
+  // The stationary operands have landed before the loop starts, and the compiler knows it: with loads still pending on its scoreboard
+  // at the loop head it would wait for them at their first use INSIDE the loop - every iteration, as vmcnt(0), i.e. for the tile that
+  // was just requested (the LDS-DMA loads are invisible to it, its own waits are not).
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    asm volatile("" ::"v"(qf[kk]));
+    if constexpr (DQ) asm volatile("" ::"v"(dof[kk]));
+  }
+  asm volatile("" ::"v"(lse_l), "v"(delta_l), "v"(m), "v"(l), "v"(p_cls), "v"(ds_cls));
+#pragma unroll
+  for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(oacc[j]));
   int buf = 0;
   for (int t = 0; t < nt; ++t) {
     const int nbuf = buf == 2 ? 0 : buf + 1;
@@ -167,16 +189,20 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
       const float mn = need ? mx : m;
       const float alpha = need ? __builtin_amdgcn_exp2f((m - mn) * c) : 1.0f;
       const float mnc = mn * c;
-      float rs4[4] = {0.f, 0.f, 0.f, 0.f};  // four independent row-sum chains
+      // exponent arguments and row sums on register PAIRS (v_pk_fma_f32 / v_pk_add_f32: half the issue slots of the scalar forms; the
+      // 32 v_exp_f32 are quarter rate and cannot be paired)
+      f32x2 rs2[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};  // two independent row-sum chains of pairs
+      const f32x2 c2 = f32x2{c, c}, mnc2 = f32x2{-mnc, -mnc};
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -mnc));
-          sacc[kb][r] = pv;
-          rs4[r & 3] += pv;
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 x = __builtin_elementwise_fma(f32x2{sacc[kb][r], sacc[kb][r + 1]}, c2, mnc2);
+          const f32x2 pv = f32x2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+          sacc[kb][r] = pv.x, sacc[kb][r + 1] = pv.y;
+          rs2[(r >> 1) & 1] += pv;
         }
-      l = l * alpha + ((rs4[0] + rs4[1]) + (rs4[2] + rs4[3]));
+      l = l * alpha + ((rs2[0].x + rs2[0].y) + (rs2[1].x + rs2[1].y));
       m = mn;
       if (__ballot(alpha != 1.0f) != 0ull) {  // the running maximum settles after the first tiles: skip the 32 rescales
 #pragma unroll
@@ -286,15 +312,26 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
   f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
   const int nq_loop = cls_query ? p.nq_main : nq;
   const int nt = (nq_loop + TROWS - 1) / TROWS;
+  unsigned qoff[8 / NW], ooff[8 / NW];   // (see k_attn_bf16_q)
+  tile_offsets<NW>(p.ldq, wave, lane, qoff);
+  tile_offsets<NW>(p.ld_do, wave, lane, ooff);
+  const int n_int = min(nq_loop, p.nq_main) / TROWS;
+  const bool span_ok = 64l * p.ldq * 2 < (1l << 31) && 64l * p.ld_do * 2 < (1l << 31);
   auto stage = [&](int buf, int t) {
     char* qt = smem + buf * STAGE;
-    stage_tile<NW>(Qb, p.ldq, col0, b, t * TROWS, nq_loop, p.nq_main, p.B, qt, wave, lane);
-    stage_tile<NW>(Ob, p.ld_do, col0, b, t * TROWS, nq_loop, p.nq_main, p.B, qt + TILE_BYTES, wave, lane);
+    if (t < n_int && span_ok) {
+      const long row0 = (long)b * p.nq_main + (long)t * TROWS;
+      stage_tile_fast<NW>(Qb + row0 * p.ldq + col0, qoff, qt, wave);
+      stage_tile_fast<NW>(Ob + row0 * p.ld_do + col0, ooff, qt + TILE_BYTES, wave);
+    } else {
+      stage_tile<NW, true>(Qb, p.ldq, col0, b, t * TROWS, nq_loop, p.nq_main, p.B, qt, wave, lane);
+      stage_tile<NW, true>(Ob, p.ld_do, col0, b, t * TROWS, nq_loop, p.nq_main, p.B, qt + TILE_BYTES, wave, lane);
+    }
     int qq = t * TROWS + lane;
     if (qq > nq_loop - 1) qq = nq_loop - 1;
     // one 256-byte piece per wave: wave 0 -> lse, wave 1 -> delta, waves 2,3 -> scratch (keeps vmcnt uniform)
     const float* src = (wave & 1) ? del_g : lse_g;
-    glds4(src + qq, qt + 2 * TILE_BYTES + wave * 256);
+    glds4_raw(src + qq, qt + 2 * TILE_BYTES + wave * 256);
   };
   stage(0, 0);
   if (cls_query) {   // the [cls] query in rank-1 form: dV^T += P dO_cls, dK^T += dS q_cls; dS kept for dQ[cls]
@@ -317,6 +354,11 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dk[j][r] = ds_cls * oc[j][r];
   }
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(kf[kk]), "v"(vf[kk]));   // (landed before the loop: see k_attn_bf16_q)
+  asm volatile("" ::"v"(ds_cls));
+#pragma unroll
+  for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(dk[j]), "v"(dv[j]));
   int buf = 0;
   for (int t = 0; t < nt; ++t) {  // three stages, one barrier per tile (see k_attn_bf16_q)
     const int nbuf = buf == 2 ? 0 : buf + 1;

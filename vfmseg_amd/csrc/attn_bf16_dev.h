@@ -17,6 +17,19 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 __device__ __forceinline__ void glds4(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 4, 0, 0);
 }
+// The same two LDS-DMA loads issued from inline assembly, for kernels that order them by hand (s_waitcnt vmcnt(N) + s_barrier in front of
+// the first read of a tile).  The compiler knows nothing of these: with the builtin it waits for vmcnt(0) in front of every
+// ds_read_b64_tr_b16 (it cannot tell the transposed read from the tile being filled) - in the middle of the K loop, i.e. for the tile
+// that was requested a few hundred clocks earlier - and the three-stage ring hides nothing.  (Its own waits stay safe: loads return in
+// order, so a count that ignores these can only wait longer.)  m0 = LDS byte address of the wave's piece; one wait state before the load.
+__device__ __forceinline__ void glds16_raw(const void* g, void* l) {
+  const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)l;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory", "m0");
+}
+__device__ __forceinline__ void glds4_raw(const void* g, void* l) {
+  const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)l;
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g), "s"(la) : "memory", "m0");
+}
 // XOR swizzle of the eight 16-byte chunks of a 128-byte tile row.  Rows are 128 B = all 32 banks apart, so whatever rows one LDS
 // cycle touches must land in different chunks:
 //   ds_read_b128 row fragments: eight consecutive rows per cycle            -> eight different chunks,
@@ -52,7 +65,7 @@ __device__ __forceinline__ float half_max(float v) {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // stage one [64 x 64] bf16 tile: sequence positions s0..s0+63 of image b (clamped), columns col0..col0+63
-template <int NW = 4>
+template <int NW = 4, bool RAW = false>
 __device__ __forceinline__ void stage_tile(const bf16_t* base, long ld, int col0, int b, int s0, int n, int n_main, int B, char* tile,
                                            int wave, int lane) {
 #pragma unroll
@@ -62,7 +75,31 @@ __device__ __forceinline__ void stage_tile(const bf16_t* base, long ld, int col0
     const int c = (lane & 7) ^ swz(r);
     int s = s0 + r;
     if (s > n - 1) s = n - 1;
-    glds16(base + tok_row(b, s, n_main, B) * ld + col0 + c * 8, tile + piece * 1024);
+    if constexpr (RAW) glds16_raw(base + tok_row(b, s, n_main, B) * ld + col0 + c * 8, tile + piece * 1024);
+    else glds16(base + tok_row(b, s, n_main, B) * ld + col0 + c * 8, tile + piece * 1024);
+  }
+}
+// Interior tiles (all 64 positions are patch tokens of image b: consecutive rows) need no per-lane address arithmetic at all: the lane's
+// byte offsets inside a tile (tile_offsets) are the same for every tile, the tile's first row is a wave-uniform base that stays in
+// SGPRs.  The general form above costs 12 VALU instructions per piece and tile - four of them quarter-rate 64-bit multiplies - i.e.
+// ~380 clocks per wave and tile, a third of what the softmax itself issues.
+template <int NW = 4>
+__device__ __forceinline__ void tile_offsets(long ld, int wave, int lane, unsigned (&off)[8 / NW]) {
+#pragma unroll
+  for (int j = 0; j < 8 / NW; ++j) {
+    const int r = (wave * (8 / NW) + j) * 8 + (lane >> 3);
+    off[j] = (unsigned)((r * ld + (((lane & 7) ^ swz(r)) << 3)) * 2);
+  }
+}
+template <int NW = 4>
+__device__ __forceinline__ void stage_tile_fast(const bf16_t* tile_base, const unsigned (&off)[8 / NW], char* tile, int wave) {
+  const unsigned long long bv = (unsigned long long)tile_base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)bv), hi = __builtin_amdgcn_readfirstlane((unsigned)(bv >> 32));
+  const unsigned long long base = ((unsigned long long)hi << 32) | lo;   // pinned to SGPRs
+#pragma unroll
+  for (int j = 0; j < 8 / NW; ++j) {
+    const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(tile + (wave * (8 / NW) + j) * 1024);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off[j]), "s"(base), "s"(la) : "memory", "m0");
   }
 }
 // first-product A operand: rows rb*32 + (lane&31), 8 consecutive columns of k-step kk (16 columns per step)
