@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
   const int b = bh / p.H, hh = bh % p.H;
   const int col0 = hh * 64;
   const int h = lane >> 5;
+  const FragOff fo = frag_offsets(lane);
   const int q0 = bx * (NW * 32) + wave * 32;
   const int qi = q0 + (lane & 31);
   const bool qvalid = qi < nq;
@@ -161,7 +162,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) sacc[kb] = MFMA(row_frag(kt, kb, kk, lane), qf[kk], sacc[kb]);
+      for (int kk = 0; kk < 4; ++kk) sacc[kb] = MFMA(row_frag(kt, fo, kb, kk), qf[kk], sacc[kb]);
     const bool tail = (t == nt - 1) && (nk_loop % TROWS != 0);
     if (!DQ) {
       // ---- online softmax over this lane's 32 keys of the tile (the other 32 live in lane ^ 32)
@@ -216,14 +217,19 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) dpacc[kb] = MFMA(row_frag(vt, kb, kk, lane), dof[kk], dpacc[kb]);
+        for (int kk = 0; kk < 4; ++kk) dpacc[kb] = MFMA(row_frag(vt, fo, kb, kk), dof[kk], dpacc[kb]);
+      {   // on register pairs (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32), as the forward's softmax
+        const f32x2 c2 = f32x2{c, c}, nl2 = f32x2{-lse_l, -lse_l}, nd2 = f32x2{-delta_l, -delta_l};
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c, -lse_l));
-          sacc[kb][r] = pv * (dpacc[kb][r] - delta_l);
-        }
+          for (int r = 0; r < 16; r += 2) {
+            const f32x2 x = __builtin_elementwise_fma(f32x2{sacc[kb][r], sacc[kb][r + 1]}, c2, nl2);
+            const f32x2 pv = f32x2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+            const f32x2 ds = pv * (f32x2{dpacc[kb][r], dpacc[kb][r + 1]} + nd2);
+            sacc[kb][r] = ds.x, sacc[kb][r + 1] = ds.y;
+          }
+      }
       if (tail) {  asm volatile("" ::: "memory");  // keeps this a real branch; wave-uniform: clamped duplicate keys of the ragged last tile contribute nothing
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -240,7 +246,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
       for (int s = 0; s < 2; ++s) {
         const bf16x8 pb = acc_frag(sacc[kb], s);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) oacc[j] = MFMA(tr_frag(t2, kb, s, j, lane), pb, oacc[j]);
+        for (int j = 0; j < 2; ++j) oacc[j] = MFMA(tr_frag(t2, fo, kb, s, j), pb, oacc[j]);
       }
     buf = nbuf;
   }
@@ -297,6 +303,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
   const int b = bh / p.H, hh = bh % p.H;
   const int col0 = hh * 64;
   const int h = lane >> 5;
+  const FragOff fo = frag_offsets(lane);
   const int k0 = bx * (NW * 32) + wave * 32;
   const int ki = k0 + (lane & 31);
   const bool kvalid = ki < nk;
@@ -380,21 +387,24 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
       f32x16 sacc = zero16(), dpacc = zero16();
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        sacc = MFMA(row_frag(qt, qb, kk, lane), kf[kk], sacc);
-        dpacc = MFMA(row_frag(ot, qb, kk, lane), vf[kk], dpacc);
+        sacc = MFMA(row_frag(qt, fo, qb, kk), kf[kk], sacc);
+        dpacc = MFMA(row_frag(ot, fo, qb, kk), vf[kk], dpacc);
       }
       f32x16 pacc;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 ls = *reinterpret_cast<const float4*>(lse_s + qb * 32 + 8 * g + 4 * h);
         const float4 dl = *reinterpret_cast<const float4*>(del_s + qb * 32 + 8 * g + 4 * h);
-        const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+        const f32x2 c2 = f32x2{c, c}, nl2e = f32x2{-LOG2E, -LOG2E};
+        const f32x2 lsv[2] = {f32x2{ls.x, ls.y} * nl2e, f32x2{ls.z, ls.w} * nl2e}, ndl[2] = {f32x2{-dl.x, -dl.y}, f32x2{-dl.z, -dl.w}};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[r], c, -lsv[e] * LOG2E));
-          pacc[r] = pv;
-          sacc[r] = pv * (dpacc[r] - dlv[e]);
+        for (int e = 0; e < 2; ++e) {   // register pairs: v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32
+          const int r = 4 * g + 2 * e;
+          const f32x2 x = __builtin_elementwise_fma(f32x2{sacc[r], sacc[r + 1]}, c2, lsv[e]);
+          const f32x2 pv = f32x2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+          const f32x2 ds = pv * (f32x2{dpacc[r], dpacc[r + 1]} + ndl[e]);
+          pacc[r] = pv.x, pacc[r + 1] = pv.y;
+          sacc[r] = ds.x, sacc[r + 1] = ds.y;
         }
       }
       if (tail) {  asm volatile("" ::: "memory");  // keeps this a real branch; wave-uniform: clamped duplicate queries of the ragged last tile contribute nothing
@@ -407,8 +417,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
         const bf16x8 pb = acc_frag(pacc, s), dsb = acc_frag(sacc, s);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          dv[j] = MFMA(tr_frag(ot, qb, s, j, lane), pb, dv[j]);
-          dk[j] = MFMA(tr_frag(qt, qb, s, j, lane), dsb, dk[j]);
+          dv[j] = MFMA(tr_frag(ot, fo, qb, s, j), pb, dv[j]);
+          dk[j] = MFMA(tr_frag(qt, fo, qb, s, j), dsb, dk[j]);
         }
       }
     }

@@ -123,6 +123,34 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int rb, int s, int j
   u.s.b = hi;
   return u.v;
 }
+// The same two fragments from lane offsets computed ONCE per kernel: the swizzle depends only on (row & 3, (row >> 2) & 1), which the
+// row-block (32 rows), the k-step (16 rows) and the second half of a transposed read (8 rows) leave alone - so those are immediate
+// offsets, and a tile costs one v_add per distinct lane offset (six) instead of one per read (the compiler does not see through the XOR).
+struct FragOff {
+  int row[4];   // row_frag: [kk]
+  int tr[2];    // tr_frag:  [j]
+};
+__device__ __forceinline__ FragOff frag_offsets(int lane) {
+  FragOff o;
+  const int r = lane & 31;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) o.row[kk] = r * 128 + (((2 * kk + (lane >> 5)) ^ swz(r)) << 4);
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, h = g >> 1;
+  const int r0 = 4 * h + q;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) o.tr[j] = r0 * 128 + (((4 * j + 2 * (g & 1) + (p >> 1)) ^ swz(r0)) << 4) + ((p & 1) << 3);
+  return o;
+}
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, const FragOff& o, int rb, int kk) {
+  return *reinterpret_cast<const bf16x8*>(tile + o.row[kk] + rb * 4096);
+}
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, const FragOff& o, int rb, int s, int j) {
+  const char* a = tile + o.tr[j] + rb * 4096 + s * 2048;
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+  u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 1024));
+  return u.v;
+}
 // registers 8s..8s+7 of a 32x32 f32 accumulator -> bf16x8 B operand of k-step s
 __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
   bf16x8 r;
