@@ -30,7 +30,8 @@ def test_library_exports_every_declared_symbol(which, kind):
     missing = [n for n in _declared() if not hasattr(lib, n)]
     assert not missing, missing
     lib.vfm_abi_version.restype = ctypes.c_int
-    assert lib.vfm_abi_version() >= 1
+    from vfmseg_amd.lib import ABI_VERSION
+    assert lib.vfm_abi_version() == ABI_VERSION   # (the binding refuses an older in-tree library: descriptor layouts changed)
     lib.vfm_half_kind.restype = ctypes.c_int
     assert lib.vfm_half_kind() == kind
 

@@ -4,7 +4,7 @@
 thread_local char g_vfm_err[512] = {0};
 
 extern "C" const char* vfm_last_error(void) { return g_vfm_err; }
-extern "C" int vfm_abi_version(void) { return 2; }   // 2: launch plans (vfm_run_plan, vfm_prof_*)
+extern "C" int vfm_abi_version(void) { return 3; }   // 2: launch plans (vfm_run_plan, vfm_prof_*); 3: vfm_gemm_desc.c_plane (c_dt VFM_SPLIT3)
 extern "C" int vfm_half_kind(void) { return VFM_HALF_KIND; }
 
 // ------------------------------------------------------------------------------------------------ cast

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvfmseg_hip.so")
 LIB_PATH_F16 = os.path.join(_HERE, "csrc", "libvfmseg_hip_f16.so")
 
 F32, BF16, U8, I64, SPLIT3 = 0, 1, 2, 3, 4
+ABI_VERSION = 3   # include/vfmseg_hip.h as of round 4 (vfm_gemm_desc.c_plane): an older in-tree .so would misread the descriptors
 EP_NONE, EP_GELU, EP_RELU, EP_MUL_GELU_GRAD, EP_MUL, EP_QGELU, EP_MUL_QGELU_GRAD, EP_GELU_DGELU = 0, 1, 2, 3, 4, 5, 6, 7
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_QGELU = 0, 1, 2, 3
 
@@ -190,6 +191,8 @@ def _open(kind):
     lib.vfm_last_error.restype = C.c_char_p
     lib.vfm_abi_version.restype = ci
     lib.vfm_half_kind.restype = ci
+    if lib.vfm_abi_version() < ABI_VERSION:
+        raise HipLibraryMissing(f"{path} has ABI version {lib.vfm_abi_version()}, this binding needs {ABI_VERSION}: rebuild (python -m vfmseg_amd.csrc.build)")
     if lib.vfm_half_kind() != kind:
         raise HipLibraryMissing(f"{path} reports half kind {lib.vfm_half_kind()}, expected {kind}: stale build")
     for name, args in SIGNATURES.items():
