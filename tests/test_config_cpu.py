@@ -63,3 +63,21 @@ def test_bench_cpu_baseline_runs():
     spec.loader.exec_module(bench)
     out = bench.cpu_baseline()
     assert out["kind"] == "port" and out["unit"] == "images/s" and out["value"] > 0 and out["cores"] >= 1
+
+
+def test_gate_that_cannot_fire_is_recognised():
+    """segmentors.gate_cannot_fire decides whether a prediction's coarse pass may run beside its window pass: only when the confidence gate of
+    Ms_VFM_encoder_decoder.py:430-461 (keep the coarse logits of a window whose fraction of pixels with max softmax > threadshod reaches conf)
+    refines every window whatever the coarse logits say.  The reference's own setting (0.968 / 0.8) is a live gate."""
+    from vfmseg_amd import presets
+    from vfmseg_amd.segmentors import gate_cannot_fire
+    assert gate_cannot_fire(0.968, 2.0) and gate_cannot_fire(1.0, 0.8) and gate_cannot_fire(1.5, 1e-6)
+    assert not gate_cannot_fire(0.968, 0.8) and not gate_cannot_fire(0.999, 1.0) and not gate_cannot_fire(1.0, 0.0)
+    tc = presets.dinov2_ms_masked()["test_cfg"]
+    assert not gate_cannot_fire(tc["threadshod"], tc["conf"])
+    # brute force against the gate's own arithmetic: fraction = (#pixels with p_max > thr) / #pixels, p_max in [0, 1]
+    import itertools
+    for thr, conf in itertools.product((0.0, 0.5, 0.968, 1.0, 1.2), (0.0, 0.3, 0.8, 1.0, 1.01)):
+        always_refined = all((sum(p > thr for p in ps) / len(ps)) < conf for ps in ((0.0, 0.0), (1.0, 1.0), (0.2, 1.0), (0.97, 0.99)))
+        if gate_cannot_fire(thr, conf):
+            assert always_refined, (thr, conf)

@@ -118,6 +118,13 @@ def get_crop_bbox(img_h, img_w, crop_size, divisible=1):
     return offset_h, offset_h + crop_size[0], offset_w, offset_w + crop_size[1]
 
 
+def gate_cannot_fire(threadshod, conf):
+    """ms_inference's gate keeps a window's coarse logits when the fraction of its pixels whose max softmax exceeds `threadshod` reaches
+    `conf` (Ms_VFM_encoder_decoder.py:430-461).  No softmax exceeds 1 and no fraction exceeds 1: with threadshod >= 1 (and conf > 0) or
+    conf > 1 every window is refined whatever the coarse logits say - the case in which the coarse pass may run beside the window pass."""
+    return conf > 1.0 or (threadshod >= 1.0 and conf > 0.0)
+
+
 def add_prefix(d, prefix):
     return {f"{prefix}.{k}": v for k, v in d.items()}
 
@@ -534,7 +541,7 @@ class MsVFMEncoderDecoder(EncoderDecoder):
 
         boxes = grid_boxes(H, W, self.test_cfg.crop_size, self.test_cfg.stride)
         # a gate that cannot fire (no pixel's max softmax exceeds 1; no fraction reaches a conf above 1): every window is refined
-        all_refined = conf > 1.0 or (thr >= 1.0 and conf > 0.0)
+        all_refined = gate_cannot_fire(thr, conf)
         early = None
         if all_refined:
             seg, early = self._coarse_beside(coarse, lambda: self._tokens([(inputs, b) for b in boxes]))
