@@ -274,16 +274,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
     bf16_t* out = DQ ? (bf16_t*)p.dq : (bf16_t*)p.o;
     const long ldo = DQ ? p.ld_dq : p.ldo;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        ushort4 v;
-        v.x = f32_to_bf16(oacc[j][4 * g + 0] * mult);
-        v.y = f32_to_bf16(oacc[j][4 * g + 1] * mult);
-        v.z = f32_to_bf16(oacc[j][4 * g + 2] * mult);
-        v.w = f32_to_bf16(oacc[j][4 * g + 3] * mult);
-        *reinterpret_cast<ushort4*>(out + qrow * ldo + col0 + 32 * j + 8 * g + 4 * h) = v;
-      }
+    for (int j = 0; j < 2; ++j) store_block_rows(oacc[j], mult, out + qrow * ldo + col0 + 32 * j, h);
   }
 }
 
@@ -435,21 +426,10 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
     bf16_t* odk = (bf16_t*)p.dk;
     bf16_t* odv = (bf16_t*)p.dv;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        ushort4 a, bq;
-        a.x = f32_to_bf16(dk[j][4 * g + 0] * p.scale);
-        a.y = f32_to_bf16(dk[j][4 * g + 1] * p.scale);
-        a.z = f32_to_bf16(dk[j][4 * g + 2] * p.scale);
-        a.w = f32_to_bf16(dk[j][4 * g + 3] * p.scale);
-        bq.x = f32_to_bf16(dv[j][4 * g + 0]);
-        bq.y = f32_to_bf16(dv[j][4 * g + 1]);
-        bq.z = f32_to_bf16(dv[j][4 * g + 2]);
-        bq.w = f32_to_bf16(dv[j][4 * g + 3]);
-        *reinterpret_cast<ushort4*>(odk + krow * p.ld_dk + col0 + 32 * j + 8 * g + 4 * h) = a;
-        *reinterpret_cast<ushort4*>(odv + krow * p.ld_dv + col0 + 32 * j + 8 * g + 4 * h) = bq;
-      }
+    for (int j = 0; j < 2; ++j) {
+      store_block_rows(dk[j], p.scale, odk + krow * p.ld_dk + col0 + 32 * j, h);
+      store_block_rows(dv[j], 1.0f, odv + krow * p.ld_dv + col0 + 32 * j, h);
+    }
   }
 }
 

@@ -151,6 +151,26 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, const FragOff& o, in
   u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 1024));
   return u.v;
 }
+// Row-per-lane epilogue store of a 32 x 32 accumulator block pair: lane i holds columns 8g .. 8g+3 of its row, lane i + 32 columns 8g+4 ..
+// 8g+7 (8 bytes each).  One v_permlane32_swap per dword between column groups g and g+1 leaves lanes 0-31 with the 16 contiguous bytes of
+// group g and lanes 32-63 with those of group g+1: ONE 16-byte store per lane and pair of groups instead of two 8-byte ones.  The tail of
+// these kernels is bound by the number of store instructions (64 rows = 64 lines touched by each), not by bytes (guide T21).
+// `acc` = 16 registers of the block (columns acc_row(r, h) of this lane's row), `mult` applied first; row_ptr = this lane's row, first column
+// of the block; h = lane >> 5.
+__device__ __forceinline__ void store_block_rows(const f32x16& acc, float mult, bf16_t* row_ptr, int h) {
+#pragma unroll
+  for (int g = 0; g < 4; g += 2) {
+    uint32_t a[2], b[2];   // groups g, g + 1: two dwords (4 bf16) each
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      a[w] = (uint32_t)f32_to_bf16(acc[4 * g + 2 * w] * mult) | ((uint32_t)f32_to_bf16(acc[4 * g + 2 * w + 1] * mult) << 16);
+      b[w] = (uint32_t)f32_to_bf16(acc[4 * g + 4 + 2 * w] * mult) | ((uint32_t)f32_to_bf16(acc[4 * g + 4 + 2 * w + 1] * mult) << 16);
+      const auto r = __builtin_amdgcn_permlane32_swap(a[w], b[w], false, false);   // vdst = group g, src = group g + 1
+      a[w] = r[0], b[w] = r[1];
+    }
+    *reinterpret_cast<uint4*>(row_ptr + 8 * g + 8 * h) = make_uint4(a[0], a[1], b[0], b[1]);
+  }
+}
 // registers 8s..8s+7 of a 32x32 f32 accumulator -> bf16x8 B operand of k-step s
 __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s) {
   bf16x8 r;
