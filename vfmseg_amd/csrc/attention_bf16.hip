@@ -54,8 +54,9 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
   if (DQ) {
     load_stationary((const bf16_t*)p.dout, p.ld_do, qrow, col0, h, dof);
     lse_l = p.lse[((long)b * p.H + hh) * nq + (qvalid ? qi : nq - 1)] * LOG2E;
-    // delta = rowsum(dO o O), computed here (each lane holds half of the row's 64 columns) and published for the dK/dV
-    // kernel that runs next - no separate delta launch
+    // delta = rowsum(dO o O), computed here (each lane holds half of the row's 64 columns) and published - NEGATED - for the dK/dV
+    // kernel that runs next (no separate delta launch): there -delta is the initial value of the dP accumulators, so that
+    // dS = P (dP - delta) needs no subtraction (32 vector instructions per wave and tile that the compiler does not pair)
     bf16x8 of[4];
     load_stationary((const bf16_t*)p.o, p.ldo, qrow, col0, h, of);
     float dsum = 0.f;
@@ -64,7 +65,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
 #pragma unroll
       for (int e2 = 0; e2 < 8; ++e2) dsum = fmaf((float)dof[kk][e2], (float)of[kk][e2], dsum);
     delta_l = half_sum(dsum);
-    if (qvalid && h == 0) p.delta[((long)b * p.H + hh) * nq + qi] = delta_l;
+    if (qvalid && h == 0) p.delta[((long)b * p.H + hh) * nq + qi] = -delta_l;
     if (cls_key && p.nq_extra == 1 && bx == 0 && wave == 0) {   // delta of the [cls] query, for the dK/dV kernel's last query tile
       const long crow = tok_row(b, p.nq_main, p.nq_main, p.B);
       bf16x8 cg[4], co[4];
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
 #pragma unroll
         for (int e2 = 0; e2 < 8; ++e2) cs = fmaf((float)cg[kk][e2], (float)co[kk][e2], cs);
       cs = half_sum(cs);
-      if (lane == 0) p.delta[((long)b * p.H + hh) * nq + p.nq_main] = cs;
+      if (lane == 0) p.delta[((long)b * p.H + hh) * nq + p.nq_main] = -cs;
     }
   }
   float p_cls = 0.f, ds_cls = 0.f;   // P^T / dS^T of this lane's query against the [cls] key (row 0 of the ragged last tile)
@@ -339,7 +340,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
     load_stationary(Ob, p.ld_do, crow, col0, h, gcf);
     const float s_e = dot_frag(kf, qcf), dp_e = dot_frag(vf, gcf);
     const float p_e = __builtin_amdgcn_exp2f(fmaf(s_e, c, -lse_g[p.nq_main] * LOG2E));
-    ds_cls = p_e * (dp_e - del_g[p.nq_main]);
+    ds_cls = p_e * (dp_e + del_g[p.nq_main]);   // (p.delta holds -delta)
     float oc[2][16];
     load_outcols(Ob, p.ld_do, crow, col0, h, oc);
 #pragma unroll
@@ -375,7 +376,12 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
     const bool tail = (t == nt - 1) && (nq_loop % TROWS != 0);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-      f32x16 sacc = zero16(), dpacc = zero16();
+      f32x16 sacc = zero16(), dpacc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {   // dP starts from -delta of its query row (register r <-> row acc_row(r, h))
+        const float4 nd = *reinterpret_cast<const float4*>(del_s + qb * 32 + 8 * g + 4 * h);
+        dpacc[4 * g] = nd.x, dpacc[4 * g + 1] = nd.y, dpacc[4 * g + 2] = nd.z, dpacc[4 * g + 3] = nd.w;
+      }
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         sacc = MFMA(row_frag(qt, fo, qb, kk), kf[kk], sacc);
@@ -385,15 +391,14 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 ls = *reinterpret_cast<const float4*>(lse_s + qb * 32 + 8 * g + 4 * h);
-        const float4 dl = *reinterpret_cast<const float4*>(del_s + qb * 32 + 8 * g + 4 * h);
         const f32x2 c2 = f32x2{c, c}, nl2e = f32x2{-LOG2E, -LOG2E};
-        const f32x2 lsv[2] = {f32x2{ls.x, ls.y} * nl2e, f32x2{ls.z, ls.w} * nl2e}, ndl[2] = {f32x2{-dl.x, -dl.y}, f32x2{-dl.z, -dl.w}};
+        const f32x2 lsv[2] = {f32x2{ls.x, ls.y} * nl2e, f32x2{ls.z, ls.w} * nl2e};
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {   // register pairs: v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32
+        for (int e = 0; e < 2; ++e) {   // register pairs: v_pk_fma_f32 / v_pk_mul_f32
           const int r = 4 * g + 2 * e;
           const f32x2 x = __builtin_elementwise_fma(f32x2{sacc[r], sacc[r + 1]}, c2, lsv[e]);
           const f32x2 pv = f32x2{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-          const f32x2 ds = pv * (f32x2{dpacc[r], dpacc[r + 1]} + ndl[e]);
+          const f32x2 ds = pv * f32x2{dpacc[r], dpacc[r + 1]};
           pacc[r] = pv.x, pacc[r + 1] = pv.y;
           sacc[r] = ds.x, sacc[r + 1] = ds.y;
         }
@@ -484,8 +489,8 @@ __global__ void __launch_bounds__(64) k_attn_cls_finish(AttnP p) {
   const float qc = bf16_to_f32(((const bf16_t*)p.q)[row * p.ldq + col]), kc = bf16_to_f32(((const bf16_t*)p.k)[row * p.ldk + col]);
   const float vc = bf16_to_f32(((const bf16_t*)p.v)[row * p.ldv + col]), gc = bf16_to_f32(((const bf16_t*)p.dout)[row * p.ld_do + col]);
   const float s = wave_sum(qc * kc) * p.scale, dp = wave_sum(gc * vc);
-  const float lse = p.lse[(long)bh * nq + p.nq_main], delta = p.delta[(long)bh * nq + p.nq_main];
-  const float pv = __expf(s - lse), ds = pv * (dp - delta);
+  const float lse = p.lse[(long)bh * nq + p.nq_main], ndelta = p.delta[(long)bh * nq + p.nq_main];   // (p.delta holds -delta)
+  const float pv = __expf(s - lse), ds = pv * (dp + ndelta);
   float* scr = p.cls_scratch + (long)bh * 192;
   ((bf16_t*)p.dq)[row * p.ld_dq + col] = f32_to_bf16((scr[lane] + ds * kc) * p.scale);
   ((bf16_t*)p.dk)[row * p.ld_dk + col] = f32_to_bf16((scr[64 + lane] + ds * qc) * p.scale);
