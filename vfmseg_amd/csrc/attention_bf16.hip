@@ -146,10 +146,17 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
   asm volatile("" ::"v"(lse_l), "v"(delta_l), "v"(m), "v"(l), "v"(p_cls), "v"(ds_cls));
 #pragma unroll
   for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(oacc[j]));
+  // Where the next tile is requested.  At the top of the iteration the four waves of a block - and those of the block that shares the CU -
+  // issue their LDS-DMA pieces at the same moment: 16-32 wave-instructions queue in front of the CU's address unit and every wave stands
+  // ~370 clocks in front of its barrier (s_memtime stamps: 15 % of a 2400-clock tile).  An interior next tile is therefore requested
+  // piece by piece BETWEEN the MFMAs of Q K^T (its stage was released by the barrier this iteration has just passed; it has a whole
+  // iteration to land and is waited for, as vmcnt(0), at the top of the next one).  Ragged / [cls]-carrying tiles keep the request at the top.
+  constexpr int PT = 8 / NW;   // pieces per wave and tile
   int buf = 0;
   for (int t = 0; t < nt; ++t) {
     const int nbuf = buf == 2 ? 0 : buf + 1;
-    if (t + 1 < nt) {
+    const bool il = (t + 1 < nt) && (t + 1 < n_int) && span_ok;   // next tile: requested between the MFMAs below
+    if (t + 1 < nt && !il) {
       stage(nbuf, t + 1);
       if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -160,10 +167,29 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
     const char* kt = smem + buf * 2 * TILE_BYTES;
     const char* vt = kt + TILE_BYTES;
     f32x16 sacc[2] = {zero16(), zero16()};
+    {
+      bf16x8 kfr[8];   // all row fragments of the K tile first: no LDS read has to cross a DMA request (the asm is a memory barrier to the compiler)
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int i = 0; i < 8; ++i) kfr[i] = row_frag(kt, fo, i >> 2, i & 3);
+      char* nkt = smem + nbuf * 2 * TILE_BYTES;
+      const long row1 = (long)b * p.nk_main + (long)(t + 1) * TROWS;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) sacc[kb] = MFMA(row_frag(kt, fo, kb, kk), qf[kk], sacc[kb]);
+      for (int i = 0; i < 8; ++i) {
+        sacc[i >> 2] = MFMA(kfr[i], qf[i & 3], sacc[i >> 2]);
+        if (il) {
+          if constexpr (NW == 4) {
+            if (i & 1) {
+              const int j = i >> 1;   // 0, 1: K pieces; 2, 3: V pieces
+              if (j < PT) stage_piece_fast<NW>(Kb + row1 * p.ldk + col0, koff[j], nkt, wave, j);
+              else stage_piece_fast<NW>(Vb + row1 * p.ldv + col0, voff[j - PT], nkt + TILE_BYTES, wave, j - PT);
+            }
+          } else {
+            if (i < PT) stage_piece_fast<NW>(Kb + row1 * p.ldk + col0, koff[i], nkt, wave, i);
+            else stage_piece_fast<NW>(Vb + row1 * p.ldv + col0, voff[i - PT], nkt + TILE_BYTES, wave, i - PT);
+          }
+        }
+      }
+    }
     const bool tail = (t == nt - 1) && (nk_loop % TROWS != 0);
     if (!DQ) {
       // ---- online softmax over this lane's 32 keys of the tile (the other 32 live in lane ^ 32)

@@ -102,6 +102,15 @@ __device__ __forceinline__ void stage_tile_fast(const bf16_t* tile_base, const u
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off[j]), "s"(base), "s"(la) : "memory", "m0");
   }
 }
+// ... one piece (j of this wave's 8 / NW) of an interior tile: issued between the MFMAs of the first product (see k_attn_bf16_q)
+template <int NW = 4>
+__device__ __forceinline__ void stage_piece_fast(const bf16_t* tile_base, unsigned off, char* tile, int wave, int j) {
+  const unsigned long long bv = (unsigned long long)tile_base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)bv), hi = __builtin_amdgcn_readfirstlane((unsigned)(bv >> 32));
+  const unsigned long long base = ((unsigned long long)hi << 32) | lo;
+  const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(tile + (wave * (8 / NW) + j) * 1024);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(la) : "memory", "m0");
+}
 // first-product A operand: rows rb*32 + (lane&31), 8 consecutive columns of k-step kk (16 columns per step)
 __device__ __forceinline__ bf16x8 row_frag(const char* tile, int rb, int kk, int lane) {
   const int r = rb * 32 + (lane & 31);
