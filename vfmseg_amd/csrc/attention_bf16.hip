@@ -385,7 +385,8 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_dkv(AttnP p) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(dk[j]), "v"(dv[j]));
   int buf = 0;
-  for (int t = 0; t < nt; ++t) {  // three stages, one barrier per tile (see k_attn_bf16_q)
+  for (int t = 0; t < nt; ++t) {  // three stages, one barrier per tile (see k_attn_bf16_q; requesting the next tile between the MFMAs
+                                   // measured no gain here - 91.6 / 92.9 us per layer with / without -, so the request stays at the top)
     const int nbuf = buf == 2 ? 0 : buf + 1;
     if (t + 1 < nt) {
       stage(nbuf, t + 1);

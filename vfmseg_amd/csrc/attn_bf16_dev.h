@@ -109,7 +109,9 @@ __device__ __forceinline__ void stage_piece_fast(const bf16_t* tile_base, unsign
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)bv), hi = __builtin_amdgcn_readfirstlane((unsigned)(bv >> 32));
   const unsigned long long base = ((unsigned long long)hi << 32) | lo;
   const unsigned la = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(tile + (wave * (8 / NW) + j) * 1024);
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(la) : "memory", "m0");
+  // (no "memory" clobber: the piece fills a stage nobody reads during this iteration, so the compiler may move this iteration's LDS reads
+  // across it; volatile keeps its order against the other requests, the waits and the barrier)
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(la) : "m0");
 }
 // first-product A operand: rows rb*32 + (lane&31), 8 consecutive columns of k-step kk (16 columns per step)
 __device__ __forceinline__ bf16x8 row_frag(const char* tile, int rb, int kk, int lane) {
