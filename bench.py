@@ -291,7 +291,8 @@ def parity_leg(device, batch, steps=3, iters=2, modes=("bf16x3", "f32")):
             model = model.to(device).eval()
             img = synth_image(1, 1024, seed=77).to(device)
             with torch.no_grad():
-                model.predict(img)
+                for _ in range(2):   # (the second prediction is the first one with the coarse pass on its side stream: that stream's allocator pool fills here)
+                    model.predict(img)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(iters):
