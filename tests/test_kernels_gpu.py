@@ -372,7 +372,7 @@ def test_gemm_bf16(M, N, K):
     assert relerr(cw[:, :N], a.double() @ b.double().t()) < 2e-5 and cw[:, N:].abs().sum() == 0
 
 
-@pytest.mark.parametrize("cfg", [17, 16, 30, 31, 32, 33, 34, 35, 36, 39, 40, 50, 51, 10])
+@pytest.mark.parametrize("cfg", [17, 16, 30, 31, 32, 33, 34, 35, 36, 39, 40, 50, 51, 52, 10])
 @pytest.mark.parametrize("M,N,K", [(4100, 1024, 1024), (300, 520, 320), (1024, 2048, 448), (256, 256, 4096), (512, 512, 128)])
 def test_gemm_bf16_configs_fast_epilogues(cfg, M, N, K):
     """Every tile configuration incl. the ping-pong kernels (30: 256x256, 31: 128x128) and the 64-wide-K-tile 256x256 kernels

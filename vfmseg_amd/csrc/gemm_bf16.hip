@@ -625,6 +625,11 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
                 "vfm_gemm(bf16): the split-K ring kernel needs K %% 128 == 0, K >= 512, one batch, <= 512 tiles of 128 x 128, a 16-byte aligned epilogue");
       fd = vfm_gemm_launch_w4_splitk(d, s, tail);
       break;
+    case 52:   // 128 x 128 tiles, 4 waves of 64 x 64 (gemm_w4.hip form 9)
+      VFM_CHECK(d->K >= 128 && d->K % 64 == 0 && (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31), VFM_E_UNSUPPORTED,
+                "vfm_gemm(bf16): the 4-wave 128x128 kernel needs K >= 128 and operands spanning < 4 GiB");
+      fd = vfm_gemm_launch_w4(d, s, vec, tail, 9);
+      break;
     case 39:   // 192 x 256 tiles, 4 waves (gemm_w4.hip form 6)
     case 40:   // 192 x 256 tiles, 8 waves (form 7)
       VFM_CHECK(d->K >= 128 && d->K % 64 == 0 && (d->M + 256) * d->sa_m < (1l << 31) && (d->N + 256) * d->sb_n < (1l << 31), VFM_E_UNSUPPORTED,

@@ -60,7 +60,7 @@ struct SplitK {
 };
 
 template <bool VEC, int MI, int NI, int WM_W, int WN_W, int P = 2, int DBG = 0, bool CLSIN = false, bool SPLITK = false>
-__global__ void __launch_bounds__(WM_W* WN_W * 64)
+__global__ void __launch_bounds__(WM_W* WN_W * 64, (WM_W * WN_W == 4 && MI == 2 && NI == 2) ? 2 : 1)   // (the 4-wave 128 x 128 form: two blocks per CU)
     k_gemm_w4(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B, long ldb, long M, long N, long K, long stride_a,
               long stride_b, long stride_c, int tiles_m, int tiles_n, EpiParams e, SkinnyTail sk, SplitK spk) {
   // block tile TM x TN (rows of A x rows of B); square in every form but the 192 x 256 one (<6, 2, 1, 4>: M = 9216 x N = 1280 / 1024
@@ -452,6 +452,8 @@ bool vfm_gemm_launch_w4(const vfm_gemm_desc* d, hipStream_t s, bool vec, const v
     if (!vec) return launch_w4_t<false, 4, 4, 2, 2, 2, 0>(d, s, tail);
     return g_pp_dbg == 1 ? launch_w4_t<true, 4, 4, 2, 2, 2, 1>(d, s, tail) : launch_w4_t<true, 4, 4, 2, 2, 2, 0>(d, s, tail);
   }
+  if (form == 9)   // 128 x 128, FOUR waves with 64 x 64 wave tiles (1.0 fragment reads per MFMA instead of the 8-wave form's 1.5), two blocks per CU
+    return vec ? launch_w4_t<true, 2, 2, 2, 2, 2, 0>(d, s, tail) : launch_w4_t<false, 2, 2, 2, 2, 2, 0>(d, s, tail);
   if (form == 7) return vec ? launch_w4_t<true, 3, 2, 2, 4, 2, 0>(d, s, tail) : launch_w4_t<false, 3, 2, 2, 4, 2, 0>(d, s, tail);
   if (form == 6) return vec ? launch_w4_t<true, 6, 2, 1, 4, 2, 0>(d, s, tail) : launch_w4_t<false, 6, 2, 1, 4, 2, 0>(d, s, tail);
   if (form == 8) {
