@@ -780,6 +780,33 @@ def test_bf16x3_producers_write_the_split_operand_image():
         set_compute_dtype("bf16")
 
 
+@pytest.mark.parametrize("mode,dt", [("bf16", torch.bfloat16), ("fp16", torch.float16)])
+def test_gemm_tile_configurations_agree_bit_for_bit(mode, dt):
+    """The ring-kernel forms (34: 128^2 / 8 waves, 52: 128^2 / 4 waves - what the dispatcher uses from K = 1024 on -, 33: 256^2 / 8 waves) and
+    the two-stage kernel (17) accumulate every output element over K in the same order, and the [cls] tail rows of M (skinny blocks) always
+    split K eight ways whatever the block's wave count: the same bits from every configuration, so a dispatch rule can change without moving
+    any parity number (the fp16 logits bound sits at 9.5e-4 of 1e-3)."""
+    from vfmseg_amd.precision import set_compute_dtype
+    set_compute_dtype(mode)
+    try:
+        for (M, N, K) in ((4100, 1024, 1024), (2049, 1024, 4096), (1300, 384, 1088)):
+            a, b = rnd(M, K, seed=150).to(dt).to(DEV), (rnd(N, K, seed=151) * 0.05).to(dt).to(DEV)
+            bias, res = rnd(N, seed=152).to(DEV), rnd(M, N, seed=153).to(DEV)
+            outs = []
+            for cfg in (34, 52, 33, 17):
+                ops.tune("gemm_cfg", cfg)
+                c = torch.empty(M, N, device=DEV)
+                ops.gemm(a, b, c, bias=bias, residual=res)
+                ch = torch.empty(M, N, dtype=dt, device=DEV)
+                ops.gemm(a, b, ch, bias=bias, ep_mode=ops.EP_GELU)
+                outs.append((c, ch))
+            for c, ch in outs[1:]:
+                assert torch.equal(c, outs[0][0]) and torch.equal(ch, outs[0][1]), (mode, M, N, K)
+    finally:
+        ops.tune("gemm_cfg", -1)
+        set_compute_dtype("bf16")
+
+
 def test_gemm_split_k_form_is_order_independent_and_stream_safe():
     """Config 51 (gemm_w4.hip SPLITK): two blocks per tile, one per half of K; the first to finish leaves its partial sums in the stream's
     workspace, the second adds them and runs the epilogue.  own + partner is one fp32 addition whichever block finishes last, so repeated

@@ -15,7 +15,7 @@ from vfmseg_amd import ops, presets  # noqa: E402
 from vfmseg_amd.registry import MODELS  # noqa: E402
 from vfmseg_amd.synth import synth_image, synth_like  # noqa: E402
 
-DEFAULTS = {"gemm_use_192": 3, "gemm_use_pp": 184, "gemm_cfg": -1, "attn_xcd": 1, "attn_short_grid": 256}
+DEFAULTS = {"gemm_w44_k": 1024, "gemm_use_192": 3, "gemm_use_pp": 184, "gemm_cfg": -1, "attn_xcd": 1, "attn_short_grid": 256}
 
 
 def main():

@@ -37,7 +37,7 @@ def main():
     env_names = {n for v in envs.values() for n, _ in v}
     env_base = {n: os.environ.get(n) for n in env_names}
     defaults = {"gemm_use_ps": 0, "gemm_use_pp": 184, "ps_burst": 0, "gemm_cfg": -1, "pp_dbg": 0, "attn_fwd64": 0, "attn_xcd": 1, "gemm_deep_tail_k": 0,
-                "attn_v2": 1, "gemm_nt_mb": 0, "gemm_deep_sep_k": 0, "attn_short_grid": 256, "gemm_use_192": 3}
+                "attn_v2": 1, "gemm_nt_mb": 0, "gemm_deep_sep_k": 0, "attn_short_grid": 256, "gemm_use_192": 3, "gemm_w44_k": 1024}
     for _ in range(4):
         model.train_step(data, ow)
     torch.cuda.synchronize()

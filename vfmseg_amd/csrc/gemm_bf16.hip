@@ -332,6 +332,8 @@ static int g_use_ps = 0;
 // DINOv2 fc2 / proj / fc1 98.1 -> 83.8 / 33.2 -> 29.8 / 100.5 -> 94.8 us, SAM-H qkv / proj / fc2 106.3 -> 89.8 / 42.0 -> 37.0 / 127.5 -> 109.7 us;
 // bit 1: 256 x 256 tiles for the shapes they fill to >= 80 % (DINOv2 qkv [9216 x 3072]: 69.3 -> 64.1 us).  vfm_tune gemm_use_192.
 static int g_use_192 = 3;
+static int g_w44_k = 1024;     // vfm_tune("gemm_w44_k"): from this K on the 128 x 128 ring kernel runs as four waves of 64 x 64 (config 52) instead of eight of
+                               // 64 x 32 (config 34): +0.6 % images/s inside the train step, one process, interleaved (profiles/r04_ab_step_w44.log); 0 = never
 static int g_deep_sep_k = 0;   // K from which one-tile-per-CU launches WITH tail rows take the seven-chunk ring and leave the tail rows to a skinny
                                // launch of their own (vfm_tune gemm_deep_sep_k; 0 = never)
 static int g_deep_tail_k = 0;  // K from which one-tile-per-CU launches WITH tail rows take the seven-chunk ring, the tail rows riding
@@ -366,6 +368,11 @@ extern "C" int vfm_tune(const char* key, int value) {
   if (key && strcmp(key, "attn_lds_pad") == 0) {
     extern int g_attn_lds_pad;
     g_attn_lds_pad = value;
+    return VFM_OK;
+  }
+  if (key && strcmp(key, "gemm_w44_k") == 0) {
+    if (value < 0) VFM_FAIL(VFM_E_INVAL, "vfm_tune(gemm_w44_k): negative value");
+    g_w44_k = value;
     return VFM_OK;
   }
   if (key && strcmp(key, "gemm_deep_sep_k") == 0) {
@@ -561,6 +568,7 @@ static int gemm_main(const vfm_gemm_desc* d, hipStream_t s, const vfm_gemm_desc*
     else cfg = 17;                                                   // 128x128, 8 waves, 2 blocks per CU
     if (cfg == 17 && (g_use_pp & 32) && d->K >= 128 && (d->M + 128) * d->sa_m < (1l << 31) && (d->N + 128) * d->sb_n < (1l << 31))
       cfg = 34;  // same tile and wave layout, operands through the five-chunk (2.5 K-tile) LDS-DMA ring of gemm_w4.hip
+    if (cfg == 34 && g_w44_k > 0 && d->K >= g_w44_k) cfg = 52;   // vfm_tune("gemm_w44_k"): the 4-wave form of the same tile from this K on (0 = never)
     // at most one tile per CU and no tail blocks to squeeze in: the second block's LDS buys a seven-chunk ring instead
     if (cfg == 34 && !tail && t128 <= 256 && d->K >= 256 && d->M % 128 == 0) cfg = 35;
     // ... and with tail blocks riding along when K is long: one tile per CU streams its operands latency-bound (bytes in flight /

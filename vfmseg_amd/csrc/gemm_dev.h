@@ -594,9 +594,13 @@ __device__ __forceinline__ void epi_scalar(const EpiParams& e, long zoff, f32x16
 struct SkinnyTail {
   const bf16_t* A; long lda; long M; int nblk; EpiParams e;
 };
+// K is ALWAYS split eight ways and the eight partial sums are added in the same order, whatever the number of waves of the block (a
+// 4-wave block runs slices w and w + 4 one after the other): the tail rows get the same bits from every tile configuration.
 template <int NW = 8>
 __device__ __forceinline__ void skinny_tile(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ Bz, long ldb, long M, long N,
                                             long K, long n0, const EpiParams& e, long zoff, char* smem) {
+  constexpr int VW = 8;   // K slices
+  static_assert(VW % NW == 0, "whole slices per wave");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   long am = fr;
@@ -612,50 +616,56 @@ __device__ __forceinline__ void skinny_tile(const bf16_t* __restrict__ A, long l
     bsrc[i] = Bz + bn * ldb + lch * 8;
   }
   const long nchunk = K / 128;                       // K % 128 may be 64: handled by the remainder chunk below
-  const long per = (nchunk + NW - 1) / NW;   // NW waves split K
-  const long c_beg = wave * per, c_end = (c_beg + per < nchunk) ? c_beg + per : nchunk;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const long per = (nchunk + VW - 1) / VW;   // eight slices of K
+  f32x16 acc[VW / NW];
   char* W = smem + wave * 8192;  // [32 columns(n) x 128 k] slice of B: 256-B rows, chunk c of row r at c ^ (r & 15)
-  for (long cidx = c_beg; cidx < c_end; ++cidx) {
-    const long k0 = cidx * 128;
-    uint4 v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const uint4*>(bsrc[i] + k0);
-    bf16x8 af[8];
+  for (int u = 0; u < VW / NW; ++u) {
+    const int vw = wave + u * NW;   // this wave's u-th slice
+    const long c_beg = vw * per, c_end = (c_beg + per < nchunk) ? c_beg + per : nchunk;
 #pragma unroll
-    for (int s2 = 0; s2 < 8; ++s2) af[s2] = *reinterpret_cast<const bf16x8*>(ap + k0 + 16 * s2);
+    for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+    for (long cidx = c_beg; cidx < c_end; ++cidx) {
+      const long k0 = cidx * 128;
+      uint4 v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = 4 * i + lrow;
-      *reinterpret_cast<uint4*>(W + row * 256 + ((lch ^ (row & 15)) << 4)) = v[i];
+      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const uint4*>(bsrc[i] + k0);
+      bf16x8 af[8];
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) af[s2] = *reinterpret_cast<const bf16x8*>(ap + k0 + 16 * s2);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + lrow;
+        *reinterpret_cast<uint4*>(W + row * 256 + ((lch ^ (row & 15)) << 4)) = v[i];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2) {
+        const bf16x8 bf = *reinterpret_cast<const bf16x8*>(W + fr * 256 + (((2 * s2 + fh) ^ (fr & 15)) << 4));
+        acc[u] = VFM_MFMA16(af[s2], bf, acc[u]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    if ((K % 128) != 0 && vw == VW - 1) {  // trailing 64-wide half chunk (K % 64 == 0 is guaranteed by the caller): the last slice's
+      const long k0 = nchunk * 128;
+      long bn = n0 + fr;
+      if (bn > N - 1) bn = N - 1;
 #pragma unroll
-    for (int s2 = 0; s2 < 8; ++s2) {
-      const bf16x8 bf = *reinterpret_cast<const bf16x8*>(W + fr * 256 + (((2 * s2 + fh) ^ (fr & 15)) << 4));
-      acc = VFM_MFMA16(af[s2], bf, acc);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-  }
-  if ((K % 128) != 0 && wave == NW - 1) {  // trailing 64-wide half chunk (K % 64 == 0 is guaranteed by the caller)
-    const long k0 = nchunk * 128;
-    long bn = n0 + fr;
-    if (bn > N - 1) bn = N - 1;
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + k0 + 16 * s2);
-      const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bz + bn * ldb + fh * 8 + k0 + 16 * s2);
-      acc = VFM_MFMA16(a, b, acc);
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap + k0 + 16 * s2);
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bz + bn * ldb + fh * 8 + k0 + 16 * s2);
+        acc[u] = VFM_MFMA16(a, b, acc[u]);
+      }
     }
   }
   __syncthreads();  // every wave is done with its staging slice: the partial sums reuse that memory
-  float* part = reinterpret_cast<float*>(smem);  // [NW][32][33]
+  float* part = reinterpret_cast<float*>(smem);  // [VW][32][33]
 #pragma unroll
-  for (int r = 0; r < 16; ++r) part[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 33 + fr] = acc[r];
+  for (int u = 0; u < VW / NW; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[((wave + u * NW) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 33 + fr] = acc[u][r];
   __syncthreads();
   for (int i = tid; i < 32 * 32; i += NW * 64) {
     const int row = i >> 5, col = i & 31;
@@ -663,7 +673,7 @@ __device__ __forceinline__ void skinny_tile(const bf16_t* __restrict__ A, long l
     if (m < M && n < N) {
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) v += part[(w * 32 + row) * 33 + col];
+      for (int w = 0; w < VW; ++w) v += part[(w * 32 + row) * 33 + col];
       epi_store(e, zoff, m, n, v);
     }
   }
