@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(NW * 64, 2) k_attn_bf16_q(AttnP p) {
   int buf = 0;
   for (int t = 0; t < nt; ++t) {
     const int nbuf = buf == 2 ? 0 : buf + 1;
-    const bool il = (t + 1 < nt) && (t + 1 < n_int) && span_ok;   // next tile: requested between the MFMAs below
+    const bool il = (p.il & (DQ ? 2 : 1)) && (t + 1 < nt) && (t + 1 < n_int) && span_ok;   // next tile: requested between the MFMAs below
     if (t + 1 < nt && !il) {
       stage(nbuf, t + 1);
       if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -478,6 +478,7 @@ static bool aligned_ok(const vfm_attn_desc* d, bool bwd) {
 int g_attn_short_grid = 256;   // (384 measured neutral on the eval leg: 16.6 ms/img either way)
 static bool short_grid(const vfm_attn_desc* d, int n) { return (long)cdiv(n, 128) * d->B * d->H < g_attn_short_grid; }
 
+int g_attn_il = 3;        // vfm_tune("attn_il")
 int g_attn_xcd = 1;       // vfm_tune("attn_xcd"): 0 = plain (block, pair) order (A/B of the XCD-local order)
 int g_attn_fwd64 = 0;     // vfm_tune("attn_fwd64"): 1 = use the experimental 64-queries-per-wave forward (attention_fwd64.hip) where it fits
 #ifdef VFM_EXPERIMENTAL_FWD64

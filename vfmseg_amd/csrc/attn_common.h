@@ -14,6 +14,7 @@ struct AttnP {
   float* delta;
   float* cls_scratch;   // backward: fp32 [B*H][3][64] partial dq / dk / dv rows of the extra ([cls]) token, or null
   int xcd;              // 1: all blocks of an (image, head) pair on one XCD (vfm_tune "attn_xcd", default 1)
+  int il;               // vfm_tune("attn_il"): bit 0 / 1 = the forward / dQ kernel requests its next tile between the MFMAs of Q K^T (attention_bf16.hip)
 };
 
 __device__ __forceinline__ long tok_row(int b, int i, int n_main, int B) {
@@ -34,6 +35,8 @@ static inline AttnP to_p(const vfm_attn_desc* d) {
   p.cls_scratch = nullptr;
   extern int g_attn_xcd;
   p.xcd = g_attn_xcd;
+  extern int g_attn_il;
+  p.il = g_attn_il;
   return p;
 }
 

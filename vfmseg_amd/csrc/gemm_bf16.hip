@@ -355,6 +355,12 @@ extern "C" int vfm_tune(const char* key, int value) {
     g_attn_short_grid = value;
     return VFM_OK;
   }
+  if (key && strcmp(key, "attn_il") == 0) {
+    if (value < 0 || value > 3) VFM_FAIL(VFM_E_INVAL, "vfm_tune(attn_il): 0 .. 3");
+    extern int g_attn_il;
+    g_attn_il = value;
+    return VFM_OK;
+  }
   if (key && strcmp(key, "attn_xcd") == 0) {
     extern int g_attn_xcd;
     g_attn_xcd = value;
