@@ -92,6 +92,36 @@ def test_geglu_masktoken():
     assert relerr(dx, x * keep[:, None]) < 1e-6 and relerr(dt, (x * (~keep)[:, None]).sum(0)) < 1e-5
 
 
+def test_vector_forms_of_mul_mask_and_geglu_equal_the_scalar_kernels():
+    """The eight-columns-per-thread forms (any mix of the 16-bit type and fp32 for mul_mask; 16-bit GEGLU forward / backward) against the
+    element-per-thread kernels, which an unaligned leading dimension still selects: same arithmetic, so the same bits."""
+    rows, C = 300, 512
+    bf = torch.bfloat16
+    for sdt, mdt, ddt in ((bf, torch.float32, bf), (torch.float32, torch.float32, torch.float32), (torch.float32, bf, torch.float32),
+                          (bf, torch.float32, torch.float32), (torch.float32, torch.float32, bf), (torch.float32, bf, bf), (bf, bf, torch.float32)):
+        for rpg in (1, 20):
+            src = rnd(rows, C, seed=160).to(sdt).to(DEV)
+            msk = ((rnd((rows + rpg - 1) // rpg, C, seed=161) > 0).float() * 1.25).to(mdt).to(DEV)
+            fast = torch.empty(rows, C, dtype=ddt, device=DEV)
+            ops.mul_mask(src, msk, fast, rows_per_group=rpg)
+            wide = torch.empty(rows, C + 4, dtype=ddt, device=DEV)          # ld % 8 != 0: the scalar kernel
+            ops.mul_mask(src, msk, wide[:, :C], rows_per_group=rpg)
+            assert torch.equal(fast, wide[:, :C]), (sdt, mdt, ddt, rpg)
+            ref = src.float() * msk.float().repeat_interleave(rpg, 0)[:rows]
+            assert torch.equal(fast.float(), ref.to(ddt).float())
+    h = rnd(rows, 2 * C, seed=162).to(bf).to(DEV)
+    do = rnd(rows, C, seed=163).to(bf).to(DEV)
+    out, dh = torch.empty(rows, C, dtype=bf, device=DEV), torch.empty(rows, 2 * C, dtype=bf, device=DEV)
+    ops.geglu_fwd(h, out)
+    ops.geglu_bwd(h, do, dh)
+    out_s, dh_s = torch.empty(rows, C + 4, dtype=bf, device=DEV), torch.empty(rows, 2 * C + 4, dtype=bf, device=DEV)
+    ops.geglu_fwd(h, out_s[:, :C])
+    ops.geglu_bwd(h, do, dh_s[:, :2 * C])
+    assert torch.equal(out, out_s[:, :C]) and torch.equal(dh, dh_s[:, :2 * C])
+    a, g = h.float().chunk(2, -1)
+    assert relerr(out.float(), a * F.gelu(g)) < 1e-2
+
+
 @pytest.mark.parametrize("C", [256, 1024])
 def test_layernorm(C):
     rows = 77

@@ -498,11 +498,54 @@ __global__ void k_mul_mask(const void* __restrict__ src, int src_dt, long ld_src
     st_any(dst, r * ld_dst + c, dst_dt, ld_any(src, r * ld_src + c, src_dt) * m);
   }
 }
+// eight columns per thread for any mix of the 16-bit type and fp32 (the decoder's Dropout draws fp32 multipliers for bf16 activations: the
+// element-per-thread kernel above moved those 16 MB at 1.7 TB/s, 16 launches per train step)
+template <typename TS, typename TM, typename TD>
+__global__ void k_mul_mask_x8(const TS* __restrict__ src, long ld_src, const TM* __restrict__ mask, long mask_ld, long rpg, TD* __restrict__ dst,
+                              long ld_dst, long rows, int cols8) {
+  const long total = rows * cols8;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols8;
+    const int c = (int)(i - r * cols8) * 8;
+    F8 a, m;
+    if constexpr (sizeof(TS) == 2) a = ld8_bf16(src + r * ld_src + c); else a = ld8_f32(src + r * ld_src + c);
+    if constexpr (sizeof(TM) == 2) m = ld8_bf16(mask + (r / rpg) * mask_ld + c); else m = ld8_f32(mask + (r / rpg) * mask_ld + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a.v[e] *= m.v[e];
+    if constexpr (sizeof(TD) == 2) st8_bf16(dst + r * ld_dst + c, a); else st8_f32(dst + r * ld_dst + c, a);
+  }
+}
+template <typename TS, typename TM, typename TD>
+static void launch_mul_mask_x8(const void* src, long ld_src, const void* mask, long mask_ld, long rpg, void* dst, long ld_dst, long rows, long cols,
+                               hipStream_t s) {
+  hipLaunchKernelGGL((k_mul_mask_x8<TS, TM, TD>), dim3(grid8(rows * cols / 8)), dim3(256), 0, s, (const TS*)src, ld_src, (const TM*)mask, mask_ld, rpg,
+                     (TD*)dst, ld_dst, rows, (int)(cols / 8));
+}
 extern "C" int vfm_mul_mask(const void* src, int src_dt, long ld_src, const void* mask, int mask_dt, long mask_ld,
                             long rows_per_group, void* dst, int dst_dt, long ld_dst, long rows, long cols, void* stream) {
   VFM_CHECK(rows_per_group >= 1, VFM_E_INVAL, "vfm_mul_mask: rows_per_group");
   const long total = rows * cols;
   if (total == 0) return VFM_OK;
+  auto h16 = [](int dt) { return dt == VFM_BF16; };
+  auto okdt = [](int dt) { return dt == VFM_BF16 || dt == VFM_F32; };
+  if (okdt(src_dt) && okdt(mask_dt) && okdt(dst_dt) && !(h16(src_dt) && h16(mask_dt) && h16(dst_dt)) && cols % 8 == 0 && ld_src % 8 == 0 &&
+      mask_ld % 8 == 0 && ld_dst % 8 == 0 && al16(src) && al16(mask) && al16(dst)) {
+    hipStream_t s = (hipStream_t)stream;
+    const int key = (h16(src_dt) ? 4 : 0) | (h16(mask_dt) ? 2 : 0) | (h16(dst_dt) ? 1 : 0);
+#define MM(TS, TM, TD) launch_mul_mask_x8<TS, TM, TD>(src, ld_src, mask, mask_ld, rows_per_group, dst, ld_dst, rows, cols, s)
+    switch (key) {
+      case 0: MM(float, float, float); break;
+      case 1: MM(float, float, bf16_t); break;
+      case 2: MM(float, bf16_t, float); break;
+      case 3: MM(float, bf16_t, bf16_t); break;
+      case 4: MM(bf16_t, float, float); break;
+      case 5: MM(bf16_t, float, bf16_t); break;
+      default: MM(bf16_t, bf16_t, float); break;
+    }
+#undef MM
+    VFM_LAUNCH_CHECK();
+    return VFM_OK;
+  }
   if (src_dt == VFM_BF16 && mask_dt == VFM_BF16 && dst_dt == VFM_BF16 && cols % 8 == 0 && ld_src % 8 == 0 && mask_ld % 8 == 0 && ld_dst % 8 == 0 &&
       al16(src) && al16(mask) && al16(dst)) {
     hipLaunchKernelGGL(k_mul_mask_bf16x8, dim3(grid8(total / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src, (const bf16_t*)mask,
@@ -538,10 +581,46 @@ __global__ void k_geglu_bwd(const void* __restrict__ h, int h_dt, long ld_h, con
     st_any(dh, r * ld_dh + C + c, dh_dt, d * a * gelu_grad_f(g));
   }
 }
+// eight columns per thread, 16-bit h / dout / dh (the decoder's three GEGLU feed-forwards: the element-per-thread kernels took 9 + 12 us each)
+__global__ void k_geglu_fwd_x8(const bf16_t* __restrict__ h, long ld_h, bf16_t* __restrict__ out, long ld_out, long rows, long C, int c8) {
+  const long total = rows * c8;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / c8;
+    const int c = (int)(i - r * c8) * 8;
+    F8 a = ld8_bf16(h + r * ld_h + c);
+    const F8 g = ld8_bf16(h + r * ld_h + C + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a.v[e] *= gelu_f(g.v[e]);
+    st8_bf16(out + r * ld_out + c, a);
+  }
+}
+__global__ void k_geglu_bwd_x8(const bf16_t* __restrict__ h, long ld_h, const bf16_t* __restrict__ dout, long ld_do, bf16_t* __restrict__ dh,
+                               long ld_dh, long rows, long C, int c8) {
+  const long total = rows * c8;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / c8;
+    const int c = (int)(i - r * c8) * 8;
+    const F8 a = ld8_bf16(h + r * ld_h + c), g = ld8_bf16(h + r * ld_h + C + c), d = ld8_bf16(dout + r * ld_do + c);
+    F8 da, dg;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      da.v[e] = d.v[e] * gelu_f(g.v[e]);
+      dg.v[e] = d.v[e] * a.v[e] * gelu_grad_f(g.v[e]);
+    }
+    st8_bf16(dh + r * ld_dh + c, da);
+    st8_bf16(dh + r * ld_dh + C + c, dg);
+  }
+}
 extern "C" int vfm_geglu_fwd(const void* h, int h_dt, long ld_h, void* out, int out_dt, long ld_out, long rows, long C,
                              void* stream) {
   const long total = rows * C;
   if (total == 0) return VFM_OK;
+  if (h_dt == VFM_BF16 && out_dt == VFM_BF16 && C % 8 == 0 && ld_h % 8 == 0 && ld_out % 8 == 0 && al16(h) && al16(out)) {
+    hipLaunchKernelGGL(k_geglu_fwd_x8, dim3(grid8(total / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, ld_h, (bf16_t*)out, ld_out, rows, C,
+                       (int)(C / 8));
+    VFM_LAUNCH_CHECK();
+    return VFM_OK;
+  }
   const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipLaunchKernelGGL(k_geglu_fwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, h_dt, ld_h, out, out_dt, ld_out, rows, C);
   VFM_LAUNCH_CHECK();
@@ -551,6 +630,13 @@ extern "C" int vfm_geglu_bwd(const void* h, int h_dt, long ld_h, const void* dou
                              long ld_dh, long rows, long C, void* stream) {
   const long total = rows * C;
   if (total == 0) return VFM_OK;
+  if (h_dt == VFM_BF16 && do_dt == VFM_BF16 && dh_dt == VFM_BF16 && C % 8 == 0 && ld_h % 8 == 0 && ld_do % 8 == 0 && ld_dh % 8 == 0 && al16(h) &&
+      al16(dout) && al16(dh)) {
+    hipLaunchKernelGGL(k_geglu_bwd_x8, dim3(grid8(total / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, ld_h, (const bf16_t*)dout, ld_do,
+                       (bf16_t*)dh, ld_dh, rows, C, (int)(C / 8));
+    VFM_LAUNCH_CHECK();
+    return VFM_OK;
+  }
   const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipLaunchKernelGGL(k_geglu_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, h_dt, ld_h, dout, do_dt, ld_do, dh, dh_dt,
                      ld_dh, rows, C);
